@@ -1,0 +1,151 @@
+"""Oracle: DualStreamCrossAttention.forward restated with explicit torch-CPU math.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Every step cites the reference line it
+follows in /root/reference/src/model/dual_stream_attention.py.  ``nn.MultiheadAttention``
+is written out (packed in-projection, per-head scaled dot product, softmax, out
+projection, head-averaged weights) after torch.nn.functional.multi_head_attention_forward,
+which is what the reference's two ``nn.MultiheadAttention`` modules execute (:104-109,
+:113-118, batch_first=True, eval mode => dropout is the identity).
+
+All tensors are float32 by default (the reference's dtype); pass dtype=torch.float64 for
+a high-precision version used to bound the fp32 rounding noise of both sides.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+MOUTH_INDICES = list(range(14, 41)) + [51]          # dual_stream_attention.py:14-45
+EXPRESSION_INDICES = list(range(0, 14)) + list(range(41, 51))
+
+
+def _t(x, dtype):
+    if isinstance(x, torch.Tensor):
+        return x.to(dtype)
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dtype)
+
+
+def mha_forward(query, key_value, in_w, in_b, out_w, out_b, num_heads: int,
+                need_weights: bool, dropout_p: float = 0.0,
+                drop_mask: Optional[torch.Tensor] = None):
+    """nn.MultiheadAttention(embed_dim, num_heads, batch_first=True)(q, kv, kv).
+
+    query (B,Lq,d), key_value (B,Lk,d).  Returns (out (B,Lq,d), weights (B,Lq,Lk) or None)
+    where weights are averaged over heads (average_attn_weights=True, the default the
+    reference relies on at :225-230).
+    """
+    B, Lq, d = query.shape
+    Lk = key_value.shape[1]
+    hd = d // num_heads
+    wq, wk, wv = in_w[:d], in_w[d:2 * d], in_w[2 * d:]
+    bq, bk, bv = in_b[:d], in_b[d:2 * d], in_b[2 * d:]
+    q = F.linear(query, wq, bq).view(B, Lq, num_heads, hd).transpose(1, 2)      # (B,H,Lq,hd)
+    k = F.linear(key_value, wk, bk).view(B, Lk, num_heads, hd).transpose(1, 2)
+    v = F.linear(key_value, wv, bv).view(B, Lk, num_heads, hd).transpose(1, 2)
+    q = q * math.sqrt(1.0 / float(hd))                 # torch scales q before the product
+    p = torch.softmax(q @ k.transpose(-1, -2), dim=-1)                          # (B,H,Lq,Lk)
+    p_used = p
+    if drop_mask is not None:                          # training-mode hook for the tests
+        p_used = p * drop_mask / (1.0 - dropout_p)
+    o = (p_used @ v).transpose(1, 2).reshape(B, Lq, d)
+    o = F.linear(o, out_w, out_b)
+    return o, (p.mean(dim=1) if need_weights else None)
+
+
+def core_forward(params: Dict[str, "np.ndarray | torch.Tensor"],
+                 mel_features, mel_temporal_features, emotion_features,
+                 num_heads: int = 8, mel_sequence_length: int = 256,
+                 temperature: float = 1.0, return_attention: bool = False,
+                 dtype=torch.float32, return_intermediates: bool = False
+                 ) -> Dict[str, torch.Tensor]:
+    """DualStreamCrossAttention.forward (dual_stream_attention.py:162-280)."""
+    P = {k: _t(v, dtype) for k, v in params.items()}
+    mel = _t(mel_features, dtype)
+    short = _t(mel_temporal_features, dtype)
+    emo = _t(emotion_features, dtype)
+    B = mel.shape[0]
+    d = P["mel_channel_encoder.weight"].shape[0]
+
+    # :189-202  (B,T,80) -> (B,80,T); zero-pad or truncate the time axis to T_seq
+    x = mel.transpose(1, 2)
+    T = x.shape[2]
+    if T < mel_sequence_length:
+        x = torch.cat([x, torch.zeros(B, x.shape[1], mel_sequence_length - T, dtype=dtype)], dim=2)
+    elif T > mel_sequence_length:
+        x = x[:, :, :mel_sequence_length]
+    # :205-208  append the 3 short-term frames -> (B,80,T_seq+3)
+    x = torch.cat([x, short.transpose(1, 2)], dim=2)
+    # :211-212  per-channel encoder + LayerNorm(eps=1e-5)
+    y = F.linear(x, P["mel_channel_encoder.weight"], P["mel_channel_encoder.bias"])
+    y = F.layer_norm(y, (d,), P["mel_norm.weight"], P["mel_norm.bias"], 1e-5)
+    # :216-218  emotion vector -> one token
+    e = F.linear(emo, P["emotion_encoder.weight"], P["emotion_encoder.bias"]).unsqueeze(1)
+    e = F.layer_norm(e, (d,), P["emotion_norm.weight"], P["emotion_norm.bias"], 1e-5)
+    # :221-222
+    qm = P["mouth_queries"].unsqueeze(0).expand(B, -1, -1)
+    qe = P["expression_queries"].unsqueeze(0).expand(B, -1, -1)
+    # :225-231
+    mo, mw = mha_forward(qm, y, P["mel_attention.in_proj_weight"], P["mel_attention.in_proj_bias"],
+                         P["mel_attention.out_proj.weight"], P["mel_attention.out_proj.bias"],
+                         num_heads, return_attention)
+    mo = F.linear(mo, P["mel_output_proj.weight"], P["mel_output_proj.bias"])
+    # :234-240
+    eo, ew = mha_forward(qe, e, P["emotion_attention.in_proj_weight"], P["emotion_attention.in_proj_bias"],
+                         P["emotion_attention.out_proj.weight"], P["emotion_attention.out_proj.bias"],
+                         num_heads, return_attention)
+    eo = F.linear(eo, P["emotion_output_proj.weight"], P["emotion_output_proj.bias"])
+    # :243-245
+    nb = P["mel_weights"].shape[0]
+    comb = torch.zeros(B, nb, d, dtype=dtype)
+    comb[:, MOUTH_INDICES] = mo
+    comb[:, EXPRESSION_INDICES] = eo
+    # :248 (decoder :150-156; Dropout is identity in eval)
+    h = torch.relu(F.linear(comb, P["blendshape_decoder.0.weight"], P["blendshape_decoder.0.bias"]))
+    z = F.linear(h, P["blendshape_decoder.3.weight"], P["blendshape_decoder.3.bias"]).squeeze(-1)
+    bs = torch.sigmoid(z)
+    # :252-253
+    wm = torch.softmax(P["mel_weights"] / temperature, dim=0)
+    we = torch.softmax(P["emotion_weights"] / temperature, dim=0)
+    # :264-270
+    final = torch.clamp(wm * bs * 0.5 + we * bs * 0.5, 0, 1)
+    out = {"blendshapes": final}
+    if return_attention:                               # :273-278
+        mb = torch.zeros_like(bs)
+        eb = torch.zeros_like(bs)
+        mb[:, MOUTH_INDICES] = bs[:, MOUTH_INDICES]
+        eb[:, EXPRESSION_INDICES] = bs[:, EXPRESSION_INDICES]
+        out["mel_attention_weights"] = mw
+        out["emotion_attention_weights"] = ew
+        out["mel_blendshapes"] = mb
+        out["emotion_blendshapes"] = eb
+    if return_intermediates:
+        out["_y"] = y
+        out["_z"] = z
+        out["_bs"] = bs
+    return out
+
+
+def core_forward_np(params, mel, short, emo, **kw) -> Dict[str, np.ndarray]:
+    """numpy-in / numpy-out convenience wrapper."""
+    with torch.no_grad():
+        o = core_forward(params, mel, short, emo, **kw)
+    return {k: v.detach().cpu().numpy() for k, v in o.items()}
+
+
+def core_loss_and_grads(params, mel, short, emo, target, num_heads=8,
+                        mel_sequence_length=256, dtype=torch.float32):
+    """MSE(blendshapes, target) and d loss / d param for every state-dict tensor, through
+    torch.autograd on the restated forward (eval mode, dropout off) -- golden G7."""
+    P = {k: _t(v, dtype).clone().requires_grad_(True) for k, v in params.items()}
+    out = core_forward(P, mel, short, emo, num_heads=num_heads,
+                       mel_sequence_length=mel_sequence_length, dtype=dtype)
+    loss = F.mse_loss(out["blendshapes"], _t(target, dtype))
+    loss.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).detach().numpy()
+             for k, v in P.items()}
+    return float(loss.detach()), grads, out["blendshapes"].detach().numpy()

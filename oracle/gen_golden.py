@@ -1,0 +1,88 @@
+"""Generate tests/golden/core_*.npz from the REFERENCE's own DualStreamCrossAttention.
+
+Runs ONLY in the build container (it imports /root/reference, which does not exist on the
+GPU box).  Usage:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden
+
+For every case it
+  1. builds the state dict and inputs from koemorph_amd.synth (seeded, reproducible),
+  2. instantiates the reference module (src/model/dual_stream_attention.py:48), loads the
+     state dict, runs eval-mode forward(return_attention=True),
+  3. for the gradient cases also runs autograd of MSE(blendshapes, target) in eval mode,
+  4. stores config + seeds + the reference outputs (a fixture is data: no weights, no
+     reference source).
+The fixtures pin oracle/core.py (tests/test_oracle_core.py) and, on the GPU, the HIP path.
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+CASES = [
+    # name, d_model, T_seq, heads, batch, t_in, param style, input style, seed, grads
+    dict(name="core_d256_T256_H8_init", d=256, T=256, H=8, B=4, t_in=257, pstyle="init", istyle="mel01", seed=11, grads=False),
+    dict(name="core_d256_T256_H8_trained", d=256, T=256, H=8, B=4, t_in=257, pstyle="trained", istyle="mel01", seed=12, grads=False),
+    dict(name="core_d256_T256_H8_randn", d=256, T=256, H=8, B=3, t_in=256, pstyle="trained", istyle="randn", seed=13, grads=False),
+    dict(name="core_d256_pad_T100", d=256, T=256, H=8, B=2, t_in=100, pstyle="trained", istyle="mel01", seed=14, grads=False),
+    dict(name="core_d256_trunc_T300", d=256, T=256, H=8, B=2, t_in=300, pstyle="trained", istyle="mel01", seed=15, grads=False),
+    dict(name="core_d256_rt_T255", d=256, T=256, H=8, B=2, t_in=255, pstyle="init", istyle="mel01", seed=16, grads=False),
+    dict(name="core_d512_T512_H8", d=512, T=512, H=8, B=2, t_in=513, pstyle="trained", istyle="mel01", seed=21, grads=False),
+    dict(name="core_d512_T512_H16", d=512, T=512, H=16, B=2, t_in=513, pstyle="trained", istyle="mel01", seed=22, grads=False),
+    dict(name="core_d64_T32_H4_small", d=64, T=32, H=4, B=5, t_in=33, pstyle="trained", istyle="randn", seed=31, grads=True),
+    dict(name="core_d256_T256_H8_grads", d=256, T=256, H=8, B=8, t_in=257, pstyle="trained", istyle="mel01", seed=41, grads=True),
+]
+
+
+def main():
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    from src.model.dual_stream_attention import DualStreamCrossAttention  # reference, read-only
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from koemorph_amd import synth
+
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(4)
+    for c in CASES:
+        params = synth.make_core_params(c["seed"], c["d"], c["T"], 256, c["pstyle"])
+        mel, short, emo = synth.make_core_inputs(c["seed"], c["B"], c["t_in"], style=c["istyle"])
+        m = DualStreamCrossAttention(d_model=c["d"], num_heads=c["H"], mel_sequence_length=c["T"]).eval()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        with torch.no_grad():
+            o = m(torch.from_numpy(mel), torch.from_numpy(short), torch.from_numpy(emo), return_attention=True)
+        rec = {
+            "config": json.dumps({k: c[k] for k in ("d", "T", "H", "B", "t_in", "pstyle", "istyle", "seed")}),
+            "params_checksum": np.float64(synth.params_checksum(params)),
+            "blendshapes": o["blendshapes"].numpy(),
+            "mel_attention_weights": o["mel_attention_weights"].numpy(),
+            "emotion_attention_weights": o["emotion_attention_weights"].numpy(),
+            "mel_blendshapes": o["mel_blendshapes"].numpy(),
+            "emotion_blendshapes": o["emotion_blendshapes"].numpy(),
+        }
+        if c["grads"]:
+            target = synth.uniform(c["seed"] * 3 + 1, (c["B"], 52), 0.0, 1.0)
+            m.zero_grad()
+            out = m(torch.from_numpy(mel), torch.from_numpy(short), torch.from_numpy(emo))["blendshapes"]
+            loss = torch.nn.functional.mse_loss(out, torch.from_numpy(target))
+            loss.backward()
+            rec["loss"] = np.float64(loss.item())
+            for k, p in m.named_parameters():
+                g = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+                if g.size <= 20000:
+                    rec["grad/" + k] = g.astype(np.float32)
+                else:                                    # large tensors: norm + strided sample
+                    rec["gradnorm/" + k] = np.float64(np.sqrt(np.sum(g.astype(np.float64) ** 2)))
+                    rec["gradsample/" + k] = g.ravel()[::97].astype(np.float32).copy()
+        path = os.path.join(OUT, c["name"] + ".npz")
+        np.savez_compressed(path, **rec)
+        print(f"{c['name']}: bs[0,:3]={rec['blendshapes'][0,:3]}  ->  {os.path.getsize(path)/1024:.1f} KB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,54 @@
+"""pytest configuration: the `gpu` marker and shared helpers.
+
+`-m "not gpu"` covers the oracle against the golden fixtures, the host logic, and that the
+C-ABI library loads and exports every declared symbol.  `-m gpu` tests are the parity tests
+proper; they call the HIP path through the C-ABI and fail (not skip) if the library is
+missing on a machine that has a GPU.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    rec = {k: z[k] for k in z.files}
+    rec["config"] = json.loads(str(rec["config"]))
+    return rec
+
+
+def golden_case(name):
+    """(config, params, (mel, short, emo), golden record) regenerated from the seeds."""
+    from koemorph_amd import synth
+    g = load_golden(name)
+    c = g["config"]
+    params = synth.make_core_params(c["seed"], c["d"], c["T"], 256, c["pstyle"])
+    assert abs(synth.params_checksum(params) - float(g["params_checksum"])) <= 1e-6 * abs(float(g["params_checksum"])), \
+        "synthetic parameter generator drifted from the one the fixtures were made with"
+    inputs = synth.make_core_inputs(c["seed"], c["B"], c["t_in"], style=c["istyle"])
+    return c, params, inputs, g
+
+
+CORE_CASES_D256 = [
+    "core_d256_T256_H8_init", "core_d256_T256_H8_trained", "core_d256_T256_H8_randn",
+    "core_d256_pad_T100", "core_d256_trunc_T300", "core_d256_rt_T255",
+]
+CORE_CASES_OTHER = ["core_d512_T512_H8", "core_d512_T512_H16", "core_d64_T32_H4_small"]
+
+
+@pytest.fixture(scope="session")
+def has_gpu():
+    import torch
+    return torch.cuda.is_available()
