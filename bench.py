@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- blendshape frames/s of the KoeMorph hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): per GPU a batch of 256 synthetic 8.5 s windows
+(136 448 samples @16 kHz) -> 1024-pt STFT / 80-bin log-mel (257 frames) -> dual-stream
+cross-attention (d_model 256, 8 heads, window 256) -> decoder -> temporal smoothing ->
+256 x 52 fp32 coefficients.  One "step" = one pass of that path over the batch
+(km_forward_audio: emotion kernel, mel power kernel, mel log kernel, fused core kernel);
+inputs are resident in HBM before the timed region.  Windows shard embarrassingly across
+GPUs (weak scaling, no data-path collective).
+
+    python bench.py --gpus N --steps K --warmup W
+
+prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline      dominant kernel: algorithmic FLOPs (or bytes) per launch / measured launch time
+  cpu_baseline  the CPU oracle (numpy front end + torch-CPU core) timed on this host (N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic work per frame, SURVEY.md section 8(d) (d=256, T=256, H=8)
+FLOPS_PER_FRAME = 48.8e6          # dense FLOPs of the attention core, Q projection included
+BYTES_PER_FRAME_AUDIO = 136448 * 4  # fp32 audio in
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=256, help="windows per GPU per step")
+    ap.add_argument("--cpu-windows", type=int, default=256, help="windows in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from koemorph_amd import synth
+    from koemorph_amd.engine import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    else:
+        dist = None
+        torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    n_gpus = max(world, 1)
+
+    B, L = args.batch, 136448
+    params = synth.make_core_params(0, style="init")
+    eng = Engine()
+    eng.load_state_dict(params)
+    eng.finalize(dev)
+    eng.reserve(B, L)
+    audio_np = synth.make_audio(100 + rank, B, L, style="uniform")
+    emo_np = synth.normal(200 + rank, (B, 256))
+    audio = torch.from_numpy(audio_np).to(dev)
+    emo = torch.from_numpy(emo_np).to(dev)
+    state = torch.zeros(B, 52, device=dev)
+    out = torch.empty(B, 52, device=dev)
+
+    def step(first=False):
+        eng.forward_audio(audio, emo, state=state, first=first, out=out)
+
+    step(first=True)
+    for _ in range(args.warmup):
+        step()
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = B * n_gpus * args.steps / dt
+
+    # ---- per-stage timing with HIP events on the launch stream (torch's current stream) -----
+    def time_stage(fn, iters):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / iters * 1e-3     # seconds per launch
+
+    mel_long, mel_short = eng.mel_batch(audio)
+    zemo = eng.emotion_logit(emo)
+    iters = max(10, min(args.steps, 100))
+    t_core = time_stage(lambda: eng.core_forward_z(mel_long, mel_short, zemo, out=out), iters)
+    t_mel = time_stage(lambda: eng.mel_batch(audio), iters)
+    core_tflops = FLOPS_PER_FRAME * B / t_core / 1e12
+    mel_gbs = BYTES_PER_FRAME_AUDIO * B / t_mel / 1e9
+    pmc_traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc_traffic = json.load(open(pmc_path))
+        except Exception:
+            pmc_traffic = None
+    roof_core = {"kernel": "core_fused_kernel", "bound": "mfma", "achieved": round(core_tflops, 3),
+                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(core_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+                 "traffic": (pmc_traffic or {}).get("core_fused_kernel"), "launch_ms": round(t_core * 1e3, 4),
+                 "algorithmic_flops_per_launch": FLOPS_PER_FRAME * B}
+    roof_mel = {"kernel": "mel_power_kernel(+mel_log_kernel)", "bound": "hbm", "achieved": round(mel_gbs, 2),
+                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(mel_gbs / PEAK_HBM_GBS, 4),
+                "traffic": (pmc_traffic or {}).get("mel_power_kernel"), "launch_ms": round(t_mel * 1e3, 4),
+                "algorithmic_bytes_per_launch": BYTES_PER_FRAME_AUDIO * B}
+    roofline, other = (roof_core, roof_mel) if t_core >= t_mel else (roof_mel, roof_core)
+
+    # ---- CPU baseline: the oracle on this host's cores (rank 0, N=1 only) -------------------
+    cpu = None
+    if rank == 0 and n_gpus == 1 and args.cpu_windows > 0:
+        from oracle import models
+        nb = min(args.cpu_windows, B)
+        orc = models.SimplifiedOracle(params)
+        orc.forward(audio_np[:2], emo_np[:2])                      # warm-up (filterbank, BLAS threads)
+        orc.reset_temporal_state()
+        tc0 = time.perf_counter()
+        ref = orc.forward(audio_np[:nb], emo_np[:nb])["blendshapes"]
+        tc = time.perf_counter() - tc0
+        # same weights, same inputs: report the agreement as a sanity line
+        chk = eng.forward_audio(audio[:nb], emo[:nb]).cpu().numpy()
+        cpu = {"value": round(nb / tc, 2), "unit": "frames/s", "cores": int(torch.get_num_threads()),
+               "kind": "port", "sample": f"one pass over {nb} windows of 136448 samples "
+               f"(numpy float64 STFT + float32 mel/dB, torch-CPU fp32 core), {tc:.1f} s",
+               "max_abs_diff_vs_gpu": float(np.abs(chk - ref).max())}
+
+    if rank == 0:
+        line = {
+            "metric": "blendshape frames/sec (52-coef, 256-win, d_model=256)",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rtf_30fps": round(30.0 / (value / n_gpus), 8),
+            "config": {"workload": "C2: 256 windows/GPU x 136448 samples (8.5 s @16 kHz) -> 1024-pt STFT, hop 533, "
+                                   "80-bin log-mel (257 frames) -> dual-stream attention d_model=256, 8 heads, "
+                                   "window 256 -> 52 coefficients + EMA; from audio resident in HBM",
+                       "windows_per_gpu": B, "samples_per_window": L, "parallelism": f"window-sharded x{n_gpus}, no collective"},
+            "roofline": roofline, "roofline_other_stage": other, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

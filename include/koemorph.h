@@ -1,0 +1,194 @@
+/*
+ * koemorph.h -- C-ABI of libkoemorph_hip.so, the MI355X (gfx950) implementation of the
+ * KoeMorph hot path.
+ *
+ * The reference (atsuki-ichikawa/KoeMorph) is 100 % Python and has no FFI / plugin
+ * interface; its boundary for this path is a set of torch.nn.Module.forward methods
+ * (SURVEY.md section 8b).  This header is what a maintainer would bind from those methods
+ * (ctypes stub in INTEGRATION.md).  Every entry point cites the reference interface it
+ * replaces as path:line relative to the reference repository root.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, int status codes.  No torch / C++ types.
+ *   - every function returns KM_OK (0) or a negative km_status; km_last_error() gives a
+ *     thread-local message for the last failure on the calling thread.
+ *   - all `const float*` / `float*` arguments named *_dev are DEVICE pointers owned by the
+ *     caller (e.g. torch tensor.data_ptr()), fp32, contiguous, 16-byte aligned.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Launch functions
+ *     (everything taking a stream except km_finalize / km_reserve) neither allocate nor
+ *     synchronise, so they can be captured into a hipGraph.
+ *   - the library owns a packed copy of the weights and a workspace; km_reserve sizes the
+ *     workspace up front, launch functions fail with KM_ERR_WORKSPACE if it is too small.
+ *   - not re-entrant per handle (the reference modules are not either: stateful EMA,
+ *     src/model/simplified_dual_stream_model.py:164); use one handle per thread/stream.
+ */
+#ifndef KOEMORPH_H
+#define KOEMORPH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KM_ABI_VERSION 1
+
+typedef enum km_status {
+    KM_OK = 0,
+    KM_ERR_INVALID_ARG = -1,   /* bad shape / NULL / misaligned pointer (reference: ValueError, src/features/stft.py:115-116) */
+    KM_ERR_UNSUPPORTED = -2,   /* configuration has no kernel */
+    KM_ERR_NOT_FINALIZED = -3, /* forward before km_finalize, or a parameter is missing */
+    KM_ERR_WORKSPACE = -4,     /* km_reserve was not called with a large enough batch */
+    KM_ERR_HIP = -5,           /* HIP runtime error; message in km_last_error() */
+    KM_ERR_NOT_READY = -6      /* streaming: ring not full yet (reference returns None, src/features/mel_sliding_window.py:126-127) */
+} km_status;
+
+typedef struct km_context* km_handle;
+
+/* Mel front-end variants (the reference has three inconsistent ones). */
+typedef enum km_mel_scale { KM_MEL_SLANEY = 0, KM_MEL_HTK = 1 } km_mel_scale;
+typedef enum km_pad_mode { KM_PAD_CONSTANT = 0, KM_PAD_REFLECT = 1 } km_pad_mode;
+typedef enum km_log_mode {
+    KM_LOG_DB_MAX = 0, /* librosa.power_to_db(ref=np.max, amin, top_db) then (x + db_add) * db_scale */
+    KM_LOG_LN_EPS = 1  /* log(mel + log_eps)  (src/features/stft.py:123) */
+} km_log_mode;
+
+typedef struct km_mel_config {
+    int32_t sample_rate;   /* 16000 */
+    int32_t n_fft;         /* 512 or 1024 */
+    int32_t hop_length;    /* int(sample_rate / target_fps): 533 @30 fps, 266 @60 fps */
+    int32_t n_mels;        /* 80 */
+    float f_min;           /* 80 */
+    float f_max;           /* 8000 */
+    int32_t mel_scale;     /* km_mel_scale */
+    int32_t slaney_norm;   /* 1: area-normalised triangles (librosa norm='slaney') */
+    int32_t pad_mode;      /* km_pad_mode; frames are always centred (center=True) */
+    int32_t window_norm;   /* 1: divide the STFT by sqrt(sum(w^2)) (torchaudio normalized=True) */
+    int32_t log_mode;      /* km_log_mode */
+    float amin;            /* 1e-10 */
+    float top_db;          /* 80 */
+    float db_add;          /* 80  -> (x + 80) / 80, simplified_dual_stream_model.py:200; 0 for none */
+    float db_scale;        /* 1/80;  1 for none */
+    float log_eps;         /* 1e-8 */
+} km_mel_config;
+
+/* Mirrors DualStreamCrossAttention.__init__ (src/model/dual_stream_attention.py:57-70)
+ * plus the front end and smoothing of SimplifiedDualStreamModel
+ * (src/model/simplified_dual_stream_model.py:28-55,163). */
+typedef struct km_config {
+    int32_t abi_version;          /* KM_ABI_VERSION */
+    int32_t d_model;              /* 256 */
+    int32_t num_heads;            /* 8 */
+    int32_t num_mel_channels;     /* 80 */
+    int32_t mel_sequence_length;  /* 256 */
+    int32_t mel_temporal_frames;  /* 3 */
+    int32_t emotion_dim;          /* 256 */
+    int32_t num_blendshapes;      /* 52 */
+    float temperature;            /* 1.0 */
+    km_mel_config mel;            /* batch front end of the model */
+} km_config;
+
+/* ---- lifecycle ---------------------------------------------------------------------- */
+int km_abi_version(void);
+const char* km_last_error(void);
+
+/* Construct for the current HIP device.  Replaces DualStreamCrossAttention.__init__ /
+ * SimplifiedDualStreamModel.__init__.  Works without a GPU (host-side state only) so that
+ * parameter folding can be exercised on the CPU; device memory is touched from km_finalize on. */
+int km_create(const km_config* cfg, km_handle* out);
+int km_destroy(km_handle h);
+
+/* Replaces nn.Module.load_state_dict for one tensor.  `key` is the reference state-dict key
+ * relative to DualStreamCrossAttention (e.g. "mel_attention.in_proj_weight"; the full-model
+ * prefix "dual_stream_attention." is accepted and stripped) or "smoothing_alpha"
+ * (simplified_dual_stream_model.py:163).  `data` is a HOST pointer to fp32. */
+int km_load_param(km_handle h, const char* key, const float* data, const int64_t* shape, int32_t ndim);
+/* Copy a parameter back to the host (state_dict()); n = number of floats in `out`. */
+int km_get_param(km_handle h, const char* key, float* out, int64_t n);
+/* Number of parameters the configuration expects / has received so far. */
+int km_param_count(km_handle h, int32_t* expected, int32_t* loaded);
+
+/* Fold + pack the weights for the kernels (host, double precision) and upload them.
+ * Must follow the last km_load_param and precede any forward.  Allocates and synchronises. */
+int km_finalize(km_handle h, void* stream);
+/* Host half of km_finalize only (no GPU needed): used by the CPU tests. */
+int km_finalize_host(km_handle h);
+/* Size the workspace for batches up to max_windows windows of up to max_samples audio samples
+ * (0 = core only).  Allocates; call outside any graph capture. */
+int km_reserve(km_handle h, int64_t max_windows, int64_t max_samples);
+
+/* ---- forward path ---------------------------------------------------------------------- */
+
+/* Batch log-mel front end.  Replaces SimplifiedDualStreamModel.extract_mel_features
+ * (src/model/simplified_dual_stream_model.py:166-229) with the handle's km_config.mel:
+ * audio_dev (B, L) -> mel_long_dev (B, n_frames, n_mels), mel_short_dev (B, 3, n_mels) = the
+ * last three frames, n_frames = 1 + L / hop.  mel_short_dev may be NULL. */
+int km_mel_batch(km_handle h, const float* audio_dev, int64_t B, int64_t L,
+                 float* mel_long_dev, float* mel_short_dev, void* stream);
+int64_t km_mel_num_frames(km_handle h, int64_t L);
+
+/* Stand-alone front end with an explicit configuration and output frame policy.  Replaces
+ * MelSpectrogramExtractor.forward (src/features/stft.py:101-142) and
+ * MelSlidingWindowExtractor.process_audio_batch / the per-tick extraction
+ * (src/features/mel_sliding_window.py:280-307,326-365).  out_frames > 0 truncates, or pads by
+ * repeating the last frame, to exactly out_frames rows (stft.py:130-140). */
+int km_mel_extract(km_handle h, const km_mel_config* cfg, const float* audio_dev, int64_t B, int64_t L,
+                   int64_t out_frames, float* mel_dev, void* stream);
+
+/* Attention core.  Replaces DualStreamCrossAttention.forward
+ * (src/model/dual_stream_attention.py:162-280), eval mode:
+ *   mel_dev (B, T_in, 80)  zero-padded / truncated to mel_sequence_length (:193-202)
+ *   mel_short_dev (B, 3, 80), emotion_dev (B, emotion_dim)
+ *   out_dev (B, 52)                      'blendshapes'
+ *   raw_dev (B, 52) or NULL              sigmoid outputs before the stream weights; the host
+ *                                        derives 'mel_blendshapes' / 'emotion_blendshapes' (:257-262)
+ *   attn_mel_dev (B, 28, 80) or NULL     'mel_attention_weights' (head-averaged)
+ * ('emotion_attention_weights' is identically 1: softmax over a single key, :234-239.) */
+int km_core_forward(km_handle h, const float* mel_dev, int64_t B, int64_t T_in,
+                    const float* mel_short_dev, const float* emotion_dev,
+                    float* out_dev, float* raw_dev, float* attn_mel_dev, void* stream);
+
+/* The two halves of km_core_forward as separate launches (same arithmetic; bench.py times the
+ * dominant kernel alone through km_core_forward_z):
+ *   km_emotion_logit   emotion stream, z_dev (B) = the decoder logit shared by the 24 expression rows
+ *                      (src/model/dual_stream_attention.py:216-218, :234-240, :248)
+ *   km_core_forward_z  mel stream + decoder + stream weights with the logits supplied by the caller. */
+int km_emotion_logit(km_handle h, const float* emotion_dev, int64_t B, float* z_dev, void* stream);
+int km_core_forward_z(km_handle h, const float* mel_dev, int64_t B, int64_t T_in,
+                      const float* mel_short_dev, const float* z_dev,
+                      float* out_dev, float* raw_dev, float* attn_mel_dev, void* stream);
+
+/* Temporal smoothing.  Replaces SimplifiedDualStreamModel.apply_temporal_smoothing
+ * (src/model/simplified_dual_stream_model.py:341-368): alpha = sigmoid(smoothing_alpha);
+ * first != 0 stores x into state and leaves x unchanged, otherwise x = alpha*x + (1-alpha)*state
+ * and state = x.  x_dev, state_dev: (B, 52). */
+int km_smooth(km_handle h, float* x_dev, float* state_dev, int64_t B, int32_t first, void* stream);
+
+/* Whole-model forward.  Replaces SimplifiedDualStreamModel.forward
+ * (src/model/simplified_dual_stream_model.py:370-415) with the emotion vector supplied by the
+ * caller (openSMILE / emotion2vec are host-side providers, out of scope):
+ * audio_dev (B, L) -> out_dev (B, 52).  state_dev (B,52) or NULL disables smoothing. */
+int km_forward_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L,
+                     const float* emotion_dev, float* out_dev, float* state_dev, int32_t first,
+                     void* stream);
+
+/* Sequence forward.  Replaces SequentialDualStreamModel.forward
+ * (src/model/sequential_dual_stream_model.py:63-167): slides a mel_sequence_length-frame
+ * window with stride_frames over each clip, one output frame per position, EMA reset at the
+ * clip start.  audio_dev (B, L) -> out_dev (B, N, 52), N = km_sequence_num_outputs().
+ * The STFT of the clip is computed once; only the two zero-padded edge frames of every window
+ * are recomputed (the reference recomputes all 257). */
+int64_t km_sequence_num_outputs(km_handle h, int64_t L, int32_t stride_frames);
+int km_sequence_forward(km_handle h, const float* audio_dev, int64_t B, int64_t L,
+                        const float* emotion_dev, int32_t stride_frames, int32_t smooth,
+                        float* out_dev, void* stream);
+
+/* ---- introspection used by the tests ------------------------------------------------- */
+/* Copy a named host-side folded/packed buffer (after km_finalize_host) into out; returns its
+ * length in floats via *n when out == NULL. */
+int km_debug_buffer(km_handle h, const char* name, float* out, int64_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KOEMORPH_H */

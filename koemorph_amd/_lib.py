@@ -1,0 +1,109 @@
+"""ctypes binding of libkoemorph_hip.so (include/koemorph.h).
+
+There is NO fallback: if the library is missing or a call fails, a KoeMorphError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from . import build as _build
+
+KM_ABI_VERSION = 1
+
+
+class KoeMorphError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libkoemorph_hip: {msg} (status {code})")
+        self.code = code
+
+
+class KMMelConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_int32), ("n_fft", C.c_int32), ("hop_length", C.c_int32),
+                ("n_mels", C.c_int32), ("f_min", C.c_float), ("f_max", C.c_float),
+                ("mel_scale", C.c_int32), ("slaney_norm", C.c_int32), ("pad_mode", C.c_int32),
+                ("window_norm", C.c_int32), ("log_mode", C.c_int32), ("amin", C.c_float),
+                ("top_db", C.c_float), ("db_add", C.c_float), ("db_scale", C.c_float),
+                ("log_eps", C.c_float)]
+
+
+class KMConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("d_model", C.c_int32), ("num_heads", C.c_int32),
+                ("num_mel_channels", C.c_int32), ("mel_sequence_length", C.c_int32),
+                ("mel_temporal_frames", C.c_int32), ("emotion_dim", C.c_int32),
+                ("num_blendshapes", C.c_int32), ("temperature", C.c_float), ("mel", KMMelConfig)]
+
+
+KM_MEL_SLANEY, KM_MEL_HTK = 0, 1
+KM_PAD_CONSTANT, KM_PAD_REFLECT = 0, 1
+KM_LOG_DB_MAX, KM_LOG_LN_EPS = 0, 1
+
+KM_OK = 0
+KM_ERR_INVALID_ARG, KM_ERR_UNSUPPORTED, KM_ERR_NOT_FINALIZED = -1, -2, -3
+KM_ERR_WORKSPACE, KM_ERR_HIP, KM_ERR_NOT_READY = -4, -5, -6
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_i32 = C.c_int32
+_h = C.c_void_p
+
+# name -> (restype, argtypes); lists EVERY symbol include/koemorph.h declares
+# (tests/test_abi.py parses the header and compares).
+SIGNATURES = {
+    "km_abi_version": (C.c_int, []),
+    "km_last_error": (C.c_char_p, []),
+    "km_create": (C.c_int, [C.POINTER(KMConfig), C.POINTER(_h)]),
+    "km_destroy": (C.c_int, [_h]),
+    "km_load_param": (C.c_int, [_h, C.c_char_p, _p, C.POINTER(_i64), _i32]),
+    "km_get_param": (C.c_int, [_h, C.c_char_p, _p, _i64]),
+    "km_param_count": (C.c_int, [_h, C.POINTER(_i32), C.POINTER(_i32)]),
+    "km_finalize": (C.c_int, [_h, _p]),
+    "km_finalize_host": (C.c_int, [_h]),
+    "km_reserve": (C.c_int, [_h, _i64, _i64]),
+    "km_mel_batch": (C.c_int, [_h, _p, _i64, _i64, _p, _p, _p]),
+    "km_mel_num_frames": (_i64, [_h, _i64]),
+    "km_mel_extract": (C.c_int, [_h, C.POINTER(KMMelConfig), _p, _i64, _i64, _i64, _p, _p]),
+    "km_core_forward": (C.c_int, [_h, _p, _i64, _i64, _p, _p, _p, _p, _p, _p]),
+    "km_emotion_logit": (C.c_int, [_h, _p, _i64, _p, _p]),
+    "km_core_forward_z": (C.c_int, [_h, _p, _i64, _i64, _p, _p, _p, _p, _p, _p]),
+    "km_smooth": (C.c_int, [_h, _p, _p, _i64, _i32, _p]),
+    "km_forward_audio": (C.c_int, [_h, _p, _i64, _i64, _p, _p, _p, _i32, _p]),
+    "km_sequence_num_outputs": (_i64, [_h, _i64, _i32]),
+    "km_sequence_forward": (C.c_int, [_h, _p, _i64, _i64, _p, _i32, _i32, _p, _p]),
+    "km_debug_buffer": (C.c_int, [_h, C.c_char_p, _p, C.POINTER(_i64)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load the shared library (building it in-tree first if the sources are newer)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if build_if_missing and _build.is_stale():
+        try:
+            _build.build_library()
+        except Exception:
+            if not os.path.exists(path):
+                raise
+    if not os.path.exists(path):
+        raise KoeMorphError(KM_ERR_HIP, f"{path} is missing: run `python -m koemorph_amd.build` "
+                                        "(there is no CPU fallback)")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.km_abi_version() != KM_ABI_VERSION:
+        raise KoeMorphError(KM_ERR_INVALID_ARG, "ABI version mismatch between _lib.py and the shared library")
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code != KM_OK:
+        msg = load().km_last_error()
+        raise KoeMorphError(code, msg.decode("utf-8", "replace") if msg else "unknown error")

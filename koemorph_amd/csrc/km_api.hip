@@ -1,0 +1,201 @@
+// C-ABI entry points that touch the device (declared in include/koemorph.h).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "km_context.h"
+
+using namespace km;
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(KM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static int need_ready(Context* c) {
+    if (!c) return fail(KM_ERR_INVALID_ARG, "NULL handle");
+    if (!c->dev_finalized) return fail(KM_ERR_NOT_FINALIZED, "call km_finalize after loading the state dict");
+    return KM_OK;
+}
+
+extern "C" {
+
+int km_finalize(km_handle h, void* stream) {
+    if (!h) return fail(KM_ERR_INVALID_ARG, "NULL handle");
+    Context* c = h;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(KM_ERR_HIP, "no HIP device: libkoemorph_hip has no CPU fallback");
+    HIP_TRY(hipGetDevice(&c->device));
+    if (!c->host_finalized)
+        if (int rc = finalize_host(c)) return rc;
+    for (auto& kv : c->packed) {
+        Packed& p = kv.second;
+        if (!p.dev) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&p.dev), p.host.size() * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(p.dev, p.host.data(), p.host.size() * sizeof(float), hipMemcpyHostToDevice,
+                               (hipStream_t)stream));
+    }
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    for (MelPlan* p : c->mel_plans)
+        if (int rc = upload_mel_plan(p)) return rc;
+    c->dev_finalized = true;
+    return KM_OK;
+}
+
+static int free_ws(Context* c) {
+    if (c->ws_zemo) HIP_TRY(hipFree(c->ws_zemo));
+    if (c->ws_melpow) HIP_TRY(hipFree(c->ws_melpow));
+    if (c->ws_melmax) HIP_TRY(hipFree(c->ws_melmax));
+    if (c->ws_mel) HIP_TRY(hipFree(c->ws_mel));
+    if (c->ws_short) HIP_TRY(hipFree(c->ws_short));
+    c->ws_zemo = c->ws_melpow = c->ws_mel = c->ws_short = nullptr;
+    c->ws_melmax = nullptr;
+    c->ws_windows = c->ws_samples = c->ws_frames = 0;
+    return KM_OK;
+}
+
+int km_reserve(km_handle h, int64_t max_windows, int64_t max_samples) {
+    if (!h || max_windows <= 0 || max_samples < 0) return fail(KM_ERR_INVALID_ARG, "km_reserve: bad argument");
+    Context* c = h;
+    // frames for the smallest hop among the registered plans (upper bound for all of them)
+    int min_hop = c->cfg.mel.hop_length, max_mels = c->cfg.mel.n_mels;
+    for (MelPlan* p : c->mel_plans) {
+        if (p->cfg.hop_length < min_hop) min_hop = p->cfg.hop_length;
+        if (p->cfg.n_mels > max_mels) max_mels = p->cfg.n_mels;
+    }
+    const int64_t frames = max_samples > 0 ? 1 + max_samples / min_hop : 0;
+    if (max_windows <= c->ws_windows && frames <= c->ws_frames) return KM_OK;
+    const int64_t W = max_windows > c->ws_windows ? max_windows : c->ws_windows;
+    const int64_t F = frames > c->ws_frames ? frames : c->ws_frames;
+    const int64_t S = max_samples > c->ws_samples ? max_samples : c->ws_samples;
+    if (int rc = free_ws(c)) return rc;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_zemo), (size_t)W * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_melmax), (size_t)W * sizeof(unsigned)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_short), (size_t)W * 3 * max_mels * sizeof(float)));
+    if (F > 0) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_melpow), (size_t)W * F * max_mels * sizeof(float)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_mel), (size_t)W * F * max_mels * sizeof(float)));
+    }
+    c->ws_windows = W; c->ws_frames = F; c->ws_samples = S;
+    return KM_OK;
+}
+
+int km_destroy(km_handle h) {
+    if (!h) return KM_OK;
+    Context* c = h;
+    for (auto& kv : c->packed)
+        if (kv.second.dev) (void)hipFree(kv.second.dev);
+    (void)free_ws(c);
+    for (MelPlan* p : c->mel_plans) free_mel_plan(p);
+    delete h;
+    return KM_OK;
+}
+
+int64_t km_mel_num_frames(km_handle h, int64_t L) {
+    if (!h || L < 0) return -1;
+    return 1 + L / h->cfg.mel.hop_length;    // librosa center=True: 1 + len(y) // hop
+}
+
+int km_mel_batch(km_handle h, const float* audio_dev, int64_t B, int64_t L, float* mel_long_dev,
+                 float* mel_short_dev, void* stream) {
+    if (int rc = need_ready(h)) return rc;
+    if (!audio_dev || !mel_long_dev || B <= 0 || L <= 0) return fail(KM_ERR_INVALID_ARG, "km_mel_batch: bad argument");
+    return launch_mel(h, h->mel_plans[0], audio_dev, B, L, 0, mel_long_dev, mel_short_dev, stream);
+}
+
+int km_mel_extract(km_handle h, const km_mel_config* cfg, const float* audio_dev, int64_t B, int64_t L,
+                   int64_t out_frames, float* mel_dev, void* stream) {
+    if (int rc = need_ready(h)) return rc;
+    if (!cfg || !audio_dev || !mel_dev || B <= 0 || L <= 0 || out_frames < 0)
+        return fail(KM_ERR_INVALID_ARG, "km_mel_extract: bad argument");
+    if (cfg->n_fft != 512 && cfg->n_fft != 1024) return fail(KM_ERR_UNSUPPORTED, "n_fft must be 512 or 1024");
+    if (cfg->hop_length <= 0 || cfg->n_mels <= 0 || cfg->n_mels > 128) return fail(KM_ERR_INVALID_ARG, "bad hop_length / n_mels");
+    MelPlan* p = nullptr;
+    for (MelPlan* q : h->mel_plans)
+        if (std::memcmp(&q->cfg, cfg, sizeof(*cfg)) == 0) p = q;
+    if (!p) {   // first use of this configuration: build + upload (allocates; not capturable)
+        p = find_or_add_plan(h, *cfg);
+        if (int rc = upload_mel_plan(p)) return rc;
+    }
+    return launch_mel(h, p, audio_dev, B, L, out_frames, mel_dev, nullptr, stream);
+}
+
+int km_core_forward(km_handle h, const float* mel_dev, int64_t B, int64_t T_in, const float* mel_short_dev,
+                    const float* emotion_dev, float* out_dev, float* raw_dev, float* attn_mel_dev, void* stream) {
+    if (int rc = need_ready(h)) return rc;
+    Context* c = h;
+    if (!mel_dev || !mel_short_dev || !emotion_dev || !out_dev || B <= 0 || T_in <= 0)
+        return fail(KM_ERR_INVALID_ARG, "km_core_forward: bad argument");
+    if (!aligned16(mel_dev) || !aligned16(mel_short_dev))
+        return fail(KM_ERR_INVALID_ARG, "km_core_forward: mel pointers must be 16-byte aligned");
+    if (!c->fused_ok)
+        return fail(KM_ERR_UNSUPPORTED, "no kernel for d_model=%d, mel_sequence_length=%d, heads=%d", c->d, c->T, c->H);
+    if (B > c->ws_windows) return fail(KM_ERR_WORKSPACE, "workspace holds %lld windows, need %lld: call km_reserve",
+                                       (long long)c->ws_windows, (long long)B);
+    if (int rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, stream)) return rc;
+    return launch_core_fused(c, mel_dev, B, T_in, mel_short_dev, c->ws_zemo, out_dev, raw_dev, attn_mel_dev,
+                             nullptr, 1, stream);
+}
+
+int km_emotion_logit(km_handle h, const float* emotion_dev, int64_t B, float* z_dev, void* stream) {
+    if (int rc = need_ready(h)) return rc;
+    if (!emotion_dev || !z_dev || B <= 0) return fail(KM_ERR_INVALID_ARG, "km_emotion_logit: bad argument");
+    return launch_emotion(h, emotion_dev, B, z_dev, stream);
+}
+
+int km_core_forward_z(km_handle h, const float* mel_dev, int64_t B, int64_t T_in, const float* mel_short_dev,
+                      const float* z_dev, float* out_dev, float* raw_dev, float* attn_mel_dev, void* stream) {
+    if (int rc = need_ready(h)) return rc;
+    Context* c = h;
+    if (!mel_dev || !mel_short_dev || !z_dev || !out_dev || B <= 0 || T_in <= 0)
+        return fail(KM_ERR_INVALID_ARG, "km_core_forward_z: bad argument");
+    if (!aligned16(mel_dev) || !aligned16(mel_short_dev))
+        return fail(KM_ERR_INVALID_ARG, "km_core_forward_z: mel pointers must be 16-byte aligned");
+    if (!c->fused_ok)
+        return fail(KM_ERR_UNSUPPORTED, "no kernel for d_model=%d, mel_sequence_length=%d, heads=%d", c->d, c->T, c->H);
+    return launch_core_fused(c, mel_dev, B, T_in, mel_short_dev, z_dev, out_dev, raw_dev, attn_mel_dev, nullptr, 1, stream);
+}
+
+int km_smooth(km_handle h, float* x_dev, float* state_dev, int64_t B, int32_t first, void* stream) {
+    if (int rc = need_ready(h)) return rc;
+    if (!x_dev || !state_dev || B <= 0) return fail(KM_ERR_INVALID_ARG, "km_smooth: bad argument");
+    return launch_smooth(h, x_dev, state_dev, B, first, stream);
+}
+
+int km_forward_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L, const float* emotion_dev,
+                     float* out_dev, float* state_dev, int32_t first, void* stream) {
+    if (int rc = need_ready(h)) return rc;
+    Context* c = h;
+    if (!audio_dev || !emotion_dev || !out_dev || B <= 0 || L <= 0)
+        return fail(KM_ERR_INVALID_ARG, "km_forward_audio: bad argument");
+    if (!c->fused_ok)
+        return fail(KM_ERR_UNSUPPORTED, "no kernel for d_model=%d, mel_sequence_length=%d, heads=%d", c->d, c->T, c->H);
+    const int64_t n_frames = 1 + L / c->cfg.mel.hop_length;
+    if (B > c->ws_windows || n_frames > c->ws_frames)
+        return fail(KM_ERR_WORKSPACE, "workspace too small for %lld windows x %lld samples: call km_reserve",
+                    (long long)B, (long long)L);
+    if (int rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, stream)) return rc;
+    if (int rc = launch_mel(c, c->mel_plans[0], audio_dev, B, L, 0, c->ws_mel, c->ws_short, stream)) return rc;
+    return launch_core_fused(c, c->ws_mel, B, n_frames, c->ws_short, c->ws_zemo, out_dev, nullptr, nullptr,
+                             state_dev, first, stream);
+}
+
+int64_t km_sequence_num_outputs(km_handle h, int64_t L, int32_t stride_frames) {
+    if (!h || L < 0 || stride_frames <= 0) return -1;
+    const int64_t num_frames = L / h->cfg.mel.hop_length;                       // sequential_dual_stream_model.py:84
+    const int64_t n = (num_frames - h->T) / stride_frames + 1;                   // :96 (floor division)
+    const int64_t nn = (num_frames - h->T) >= 0 ? n : ((num_frames - h->T - (stride_frames - 1)) / stride_frames + 1);
+    return nn > 1 ? nn : 1;
+}
+
+int km_sequence_forward(km_handle h, const float* audio_dev, int64_t B, int64_t L, const float* emotion_dev,
+                        int32_t stride_frames, int32_t smooth, float* out_dev, void* stream) {
+    (void)audio_dev; (void)B; (void)L; (void)emotion_dev; (void)stride_frames; (void)smooth; (void)out_dev; (void)stream;
+    if (int rc = need_ready(h)) return rc;
+    return fail(KM_ERR_UNSUPPORTED, "km_sequence_forward: not built yet");
+}
+
+}  // extern "C"

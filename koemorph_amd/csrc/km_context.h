@@ -1,0 +1,99 @@
+// Internal definitions shared by the translation units of libkoemorph_hip.so.
+// Not part of the public ABI (that is include/koemorph.h).
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "koemorph.h"
+
+namespace km {
+
+constexpr int kNumMouth = 28;   // dual_stream_attention.py:14-45 (MOUTH_INDICES)
+constexpr int kNumExpr = 24;    // EXPRESSION_INDICES
+extern const int kMouthIdx[kNumMouth];
+extern const int kExprIdx[kNumExpr];
+
+struct HostParam {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    bool loaded = false;
+};
+
+// A named host buffer produced by folding/packing, mirrored 1:1 on the device.
+struct Packed {
+    std::vector<float> host;
+    float* dev = nullptr;
+};
+
+// Sparse triangular mel filterbank + window for one front-end configuration.
+struct MelPlan {
+    km_mel_config cfg{};
+    int n_freq = 0;                 // n_fft/2 + 1
+    std::vector<float> window;      // n_fft, periodic Hann (optionally / sqrt(sum w^2))
+    std::vector<float> twiddle;     // n_fft complex (cos, -sin) pairs: W_N^p
+    std::vector<int32_t> fb_start;  // n_mels: first FFT bin with non-zero weight
+    std::vector<int32_t> fb_count;  // n_mels: number of bins
+    std::vector<int32_t> fb_offset; // n_mels: offset into fb_weight
+    std::vector<float> fb_weight;   // concatenated non-zero weights
+    // device mirrors
+    float* d_window = nullptr;
+    float* d_twiddle = nullptr;
+    int32_t* d_fb_start = nullptr;
+    int32_t* d_fb_count = nullptr;
+    int32_t* d_fb_offset = nullptr;
+    float* d_fb_weight = nullptr;
+    bool uploaded = false;
+};
+
+struct Context {
+    km_config cfg{};
+    int d = 0, H = 0, hd = 0, T = 0, KT = 0, ED = 0, DH = 0, NB = 0, NK = 0;
+    std::map<std::string, HostParam> params;     // reference state-dict tensors (fp32 masters)
+    std::vector<std::string> param_order;
+    std::map<std::string, Packed> packed;        // folded / packed buffers
+    bool host_finalized = false;
+    bool dev_finalized = false;
+    bool fused_ok = false;                       // (d,T,H) has the fused gfx950 kernel
+    float alpha = 0.0f;                          // sigmoid(smoothing_alpha)
+    int device = -1;
+
+    std::vector<MelPlan*> mel_plans;             // [0] = cfg.mel
+
+    // workspace (device)
+    int64_t ws_windows = 0, ws_samples = 0;
+    float* ws_zemo = nullptr;      // (windows)             emotion-stream logit
+    float* ws_melpow = nullptr;    // (windows, frames, 80) power-mel
+    unsigned* ws_melmax = nullptr; // (windows)             max power (float bits)
+    float* ws_mel = nullptr;       // (windows, frames, 80) log-mel
+    float* ws_short = nullptr;     // (windows, 3, 80)
+    int64_t ws_frames = 0;
+};
+
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+// km_host.cpp
+int finalize_host(Context* c);
+MelPlan* build_mel_plan(const km_mel_config& cfg);
+MelPlan* find_or_add_plan(Context* c, const km_mel_config& cfg);
+
+// km_core.hip
+int launch_emotion(Context* c, const float* emo, int64_t B, float* zemo, void* stream);
+int launch_core_fused(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short,
+                      const float* zemo, float* out, float* raw, float* attn, float* state, int first,
+                      void* stream);
+int launch_smooth(Context* c, float* x, float* state, int64_t B, int first, void* stream);
+
+// km_mel.hip
+int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, int64_t out_frames,
+               float* mel_long, float* mel_short, void* stream);
+int upload_mel_plan(MelPlan* p);
+void free_mel_plan(MelPlan* p);
+
+}  // namespace km
+
+// the opaque handle type of the public header
+struct km_context : public km::Context {};

@@ -1,0 +1,495 @@
+// Attention core of the KoeMorph hot path for gfx950 (MI355X): one fused kernel per window.
+//
+// Replaces DualStreamCrossAttention.forward (reference src/model/dual_stream_attention.py:162-280)
+// in eval mode for the production configuration d_model=256, mel_sequence_length=256, 8 heads.
+//
+// One 512-thread workgroup (8 waves, 2 per SIMD) owns one window and keeps every intermediate
+// on chip; all contractions run on the exact-fp32 matrix instruction v_mfma_f32_16x16x4_f32
+// (bitwise a k-ordered fmaf chain), so the result differs from the PyTorch CPU forward only by
+// summation order.
+//
+//   phase 0  X (264 x 80, [t][c]) <- mel rows, zero pad / truncate to T, + 3 short-term rows (:189-208)
+//   phase 1  Y = X^T Wce^T + b   (80 x 256, K = 259)            wave w owns output columns 32w..32w+31
+//            LayerNorm(eps 1e-5) two-pass, cross-wave row statistics through LDS (:211-212)
+//            Y -> LDS [80][264] (aliases X)
+//   phase 2  per head h = wave:  S^T = Y Qk_h^T  (80 keys x 32 query slots, K = 256), softmax over keys
+//   phase 3                      V_h = Y Wv_h^T  (80 x 32, K = 256)       -- same sweep over Y as phase 2
+//   phase 4                      O_h^T = V_h^T P_h^T  (32 x 32, K = 80)   -- both operands ARE the phase 2/3
+//            accumulators: the C/D layout of the 16x16x4 MFMA (col = lane&15, row = 4*(lane>>4)+reg)
+//            is its own A/B operand layout when the contraction runs over the row index, so the
+//            attention weights never leave registers.
+//   phase 5  O -> LDS [32 q][256], hidden^T = Wf^T O^T (128 x 32, K = 256), ReLU, dot w2, sigmoid,
+//            stream weights, clamp, optional EMA (:231-270 folded on the host, km_host.cpp)
+//
+// LDS operand images: X rows are 80 floats (320 B = 16 banks mod 32, so two consecutive rows fill the
+// 32 banks of a ds_read_b32 half-wave); Y / O rows are 264 floats (stride = 8 mod 64 dwords) which makes
+// every 16-lane group of the ds_read_b128 A-fragment reads hit 16 distinct 16-byte slots.
+// The contraction index inside a 16-wide k block is permuted (lane group g reads k = 16kb+4g..+3 as one
+// b128) -- legal because the weights are packed on the host with the same permutation.
+#include <hip/hip_runtime.h>
+
+#include "km_context.h"
+
+namespace km {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define KM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(KM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace fused {
+constexpr int D = 256, T = 256, NK = 80, NQ = 28, DH = 128;
+constexpr int KT = 259, KTP = 264, YS = 264, NW = 8, NT = 512;
+constexpr int KP = 33;               // k-step pairs of the encoder GEMM (66 steps of 4 >= 259)
+constexpr int KB = 16;               // 16-wide k blocks of the d=256 contractions
+constexpr int R1_FLOATS = KTP * NK;  // 21120: X [264][80]  ==  Y [80][264]
+constexpr int R2_FLOATS = NW * NK;   // 640: cross-wave reduction scratch
+constexpr int LDS_BYTES = (R1_FLOATS + R2_FLOATS) * 4;
+}  // namespace fused
+
+struct CoreArgs {
+    const float* mel;        // (B, t_in, 80)
+    const float* mel_short;  // (B, 3, 80)
+    const float* zemo;       // (B) emotion-stream logit
+    int t_in;
+    const float *wce_p, *bce, *ln_g, *ln_b, *qk_p, *wv_p, *wf_p, *bf, *w2, *b2, *wsum;
+    float* out;    // (B, 52)
+    float* raw;    // (B, 52) or null
+    float* attn;   // (B, 28, 80) or null (ATTN variant only)
+    float* state;  // (B, 52) EMA state or null
+    int first;
+    float alpha;
+};
+
+// blendshape index -> mouth query slot (MOUTH_INDICES = 14..40, 51; dual_stream_attention.py:14-45)
+// or -1 for the 24 expression rows
+__device__ __forceinline__ int mouth_slot_of(int i) { return (i >= 14 && i <= 40) ? i - 14 : (i == 51 ? 27 : -1); }
+
+template <bool ATTN>
+__global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
+    using namespace fused;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* R1 = smem;
+    float* R2 = smem + R1_FLOATS;
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+
+    // ---- phase 0: X -> LDS, [t][c] exactly as the caller's (t_in, 80) rows --------------------
+    {
+        const int tv = a.t_in < T ? a.t_in : T;   // rows beyond T are truncated (:200-202)
+        const float4* src = reinterpret_cast<const float4*>(a.mel + (int64_t)b * a.t_in * NK);
+        float4* dst = reinterpret_cast<float4*>(R1);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < tv * 20; i += NT) dst[i] = src[i];
+        for (int i = tv * 20 + tid; i < T * 20; i += NT) dst[i] = z4;                       // zero pad (:193-199)
+        const float4* s4 = reinterpret_cast<const float4*>(a.mel_short + (int64_t)b * 3 * NK);
+        if (tid < 60) dst[T * 20 + tid] = s4[tid];                                           // 3 short rows (:205-208)
+        if (tid >= 64 && tid < 64 + (KTP - KT) * 20) dst[KT * 20 + tid - 64] = z4;          // k padding rows
+    }
+    __syncthreads();
+
+    // ---- phase 1: channel encoder GEMM -----------------------------------------------------
+    f32x4 acc[5][2];
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt) { acc[mt][0] = f32x4{0, 0, 0, 0}; acc[mt][1] = f32x4{0, 0, 0, 0}; }
+    {
+        const float4* wp = reinterpret_cast<const float4*>(a.wce_p) + (size_t)wave * KP * 64 + lane;
+        float4 bw = wp[0];
+        for (int kp = 0; kp < KP; ++kp) {
+            const float4 bn = wp[(size_t)(kp + 1 < KP ? kp + 1 : kp) * 64];   // prefetch next pair
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) {
+                const float* xr = R1 + (4 * (2 * kp + ds) + g) * NK + j;
+                const float b0 = ds ? bw.z : bw.x, b1 = ds ? bw.w : bw.y;
+                float av[5];
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt) av[mt] = xr[16 * mt];
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt) {
+                    acc[mt][0] = KM_MFMA(av[mt], b0, acc[mt][0]);
+                    acc[mt][1] = KM_MFMA(av[mt], b1, acc[mt][1]);
+                }
+            }
+            bw = bn;
+        }
+    }
+    // bias; this lane's two columns are n0 = 32*wave + j and n0 + 16
+    const int n0 = 32 * wave + j;
+    {
+        const float bb0 = a.bce[n0], bb1 = a.bce[n0 + 16];
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc[mt][0][r] += bb0; acc[mt][1][r] += bb1; }
+    }
+    // LayerNorm over the 256 columns of each of the 80 rows: two-pass (mean, then centred squares)
+    float mean[5][4], rstd[5][4];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float part[5][4];
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v;
+                if (pass == 0) {
+                    v = acc[mt][0][r] + acc[mt][1][r];
+                } else {
+                    const float d0 = acc[mt][0][r] - mean[mt][r], d1 = acc[mt][1][r] - mean[mt][r];
+                    v = d0 * d0 + d1 * d1;
+                }
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                part[mt][r] = v;
+            }
+        if (j == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) R2[wave * NK + 16 * mt + 4 * g + r] = part[mt][r];
+        }
+        __syncthreads();   // pass 0: also fences every wave's last read of X
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * mt + 4 * g + r;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) s += R2[w * NK + row];
+                if (pass == 0) mean[mt][r] = s * (1.0f / D);
+                else rstd[mt][r] = 1.0f / sqrtf(s * (1.0f / D) + 1e-5f);
+            }
+        __syncthreads();   // R2 is rewritten by the next pass / later phases
+    }
+    {
+        const float g0 = a.ln_g[n0], g1 = a.ln_g[n0 + 16], be0 = a.ln_b[n0], be1 = a.ln_b[n0 + 16];
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* yr = R1 + (16 * mt + 4 * g + r) * YS + n0;
+                yr[0] = (acc[mt][0][r] - mean[mt][r]) * rstd[mt][r] * g0 + be0;
+                yr[16] = (acc[mt][1][r] - mean[mt][r]) * rstd[mt][r] * g1 + be1;
+            }
+    }
+    __syncthreads();
+
+    // ---- phases 2+3: S^T = Y Qk_h^T and V_h = Y Wv_h^T in one sweep over Y -------------------
+    f32x4 S[5][2], V[5][2];
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt) {
+        S[mt][0] = f32x4{0, 0, 0, 0}; S[mt][1] = f32x4{0, 0, 0, 0};
+        V[mt][0] = f32x4{0, 0, 0, 0}; V[mt][1] = f32x4{0, 0, 0, 0};
+    }
+    {
+        const f32x4* qp = reinterpret_cast<const f32x4*>(a.qk_p) + (size_t)wave * KB * 2 * 64 + lane;
+        const f32x4* vp = reinterpret_cast<const f32x4*>(a.wv_p) + (size_t)wave * KB * 2 * 64 + lane;
+        f32x4 q0 = qp[0], q1 = qp[64], v0 = vp[0], v1 = vp[64];
+        for (int kb = 0; kb < KB; ++kb) {
+            const int kn = kb + 1 < KB ? kb + 1 : kb;
+            const f32x4 q0n = qp[(size_t)kn * 128], q1n = qp[(size_t)kn * 128 + 64];
+            const f32x4 v0n = vp[(size_t)kn * 128], v1n = vp[(size_t)kn * 128 + 64];
+            f32x4 ya[5];
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt)
+                ya[mt] = *reinterpret_cast<const f32x4*>(R1 + (16 * mt + j) * YS + 16 * kb + 4 * g);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt) {
+                    const float av = ya[mt][s];
+                    S[mt][0] = KM_MFMA(av, q0[s], S[mt][0]);
+                    S[mt][1] = KM_MFMA(av, q1[s], S[mt][1]);
+                    V[mt][0] = KM_MFMA(av, v0[s], V[mt][0]);
+                    V[mt][1] = KM_MFMA(av, v1[s], V[mt][1]);
+                }
+            q0 = q0n; q1 = q1n; v0 = v0n; v1 = v1n;
+        }
+    }
+    // softmax over the 80 keys of each query column: 20 values in-lane, then across the 4 lane groups
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float m = S[0][qt][0];
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, S[mt][qt][r]);
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = expf(S[mt][qt][r] - m);
+                S[mt][qt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[mt][qt][r] *= inv;
+    }
+
+    // ---- phase 4: O_h^T (32 d x 32 q) = V_h^T P_h^T, operands straight from the accumulators ----
+    f32x4 O[2][2];
+    O[0][0] = f32x4{0, 0, 0, 0}; O[0][1] = f32x4{0, 0, 0, 0};
+    O[1][0] = f32x4{0, 0, 0, 0}; O[1][1] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            O[0][0] = KM_MFMA(V[mt][0][r], S[mt][0][r], O[0][0]);
+            O[0][1] = KM_MFMA(V[mt][0][r], S[mt][1][r], O[0][1]);
+            O[1][0] = KM_MFMA(V[mt][1][r], S[mt][0][r], O[1][0]);
+            O[1][1] = KM_MFMA(V[mt][1][r], S[mt][1][r], O[1][1]);
+        }
+
+    __syncthreads();   // every wave is done reading Y; R1 becomes O [32 q][264]
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+            *reinterpret_cast<f32x4*>(R1 + (16 * qt + j) * YS + 32 * wave + 16 * dt + 4 * g) = O[dt][qt];
+
+    if constexpr (ATTN) {
+        // head-averaged attention weights (:225-230, average_attn_weights=True), summed in head order
+        float* Pa = R1 + 32 * YS;   // [28][80] behind the O image
+        for (int h = 0; h < NW; ++h) {
+            if (wave == h) {
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    const int q = 16 * qt + j;
+                    if (q < NQ) {
+#pragma unroll
+                        for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float* p = Pa + q * NK + 16 * mt + 4 * g + r;
+                                *p = (h == 0 ? 0.f : *p) + S[mt][qt][r];
+                            }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        float* ao = a.attn + (int64_t)b * NQ * NK;
+        for (int i = tid; i < NQ * NK; i += NT) ao[i] = Pa[i] * (1.0f / NW);
+    } else {
+        __syncthreads();
+    }
+
+    // ---- phase 5: hidden^T (128 x 32 q) = Wf^T O^T, wave w owns hidden units 16w..16w+15 -------
+    f32x4 Z[2];
+    Z[0] = f32x4{0, 0, 0, 0}; Z[1] = f32x4{0, 0, 0, 0};
+    {
+        const f32x4* fp = reinterpret_cast<const f32x4*>(a.wf_p) + (size_t)wave * KB * 64 + lane;
+#pragma unroll 4
+        for (int kb = 0; kb < KB; ++kb) {
+            const f32x4 wa = fp[(size_t)kb * 64];
+            const f32x4 o0 = *reinterpret_cast<const f32x4*>(R1 + j * YS + 16 * kb + 4 * g);
+            const f32x4 o1 = *reinterpret_cast<const f32x4*>(R1 + (16 + j) * YS + 16 * kb + 4 * g);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                Z[0] = KM_MFMA(wa[s], o0[s], Z[0]);
+                Z[1] = KM_MFMA(wa[s], o1[s], Z[1]);
+            }
+        }
+    }
+    {
+        float zp[2] = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int hid = 16 * wave + 4 * g + r;
+            const float bfv = a.bf[hid], w2v = a.w2[hid];
+            zp[0] += fmaxf(Z[0][r] + bfv, 0.f) * w2v;
+            zp[1] += fmaxf(Z[1][r] + bfv, 0.f) * w2v;
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            zp[qt] += __shfl_xor(zp[qt], 16);
+            zp[qt] += __shfl_xor(zp[qt], 32);
+        }
+        if (g == 0) { R2[wave * 32 + j] = zp[0]; R2[wave * 32 + 16 + j] = zp[1]; }
+    }
+    __syncthreads();
+    if (tid < 52) {
+        const int slot = mouth_slot_of(tid);
+        float z;
+        if (slot >= 0) {
+            z = a.b2[0];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) z += R2[w * 32 + slot];
+        } else {
+            z = a.zemo[b];
+        }
+        const float bs = 1.0f / (1.0f + expf(-z));                      // nn.Sigmoid (:155)
+        float val = fminf(fmaxf(a.wsum[tid] * bs, 0.f), 1.f);           // stream weights + clamp (:264-270)
+        if (a.raw) a.raw[(int64_t)b * 52 + tid] = bs;
+        if (a.state) {                                                  // EMA (simplified_dual_stream_model.py:357-366)
+            float* st = a.state + (int64_t)b * 52 + tid;
+            if (!a.first) val = a.alpha * val + (1.0f - a.alpha) * (*st);
+            *st = val;
+        }
+        a.out[(int64_t)b * 52 + tid] = val;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Emotion stream: z_e[b] = w2 . relu(LN(Wee emo + bee) We2 + be2) + b2   (one scalar per window: the
+// 24 expression queries all attend to the single eGeMAPS token, dual_stream_attention.py:234-240).
+// 0.5 MFLOP / window, plain VALU; 8 windows per workgroup so the two weight matrices are read once
+// per 8 windows from L2.  Generic in (ED, d, DH).
+// ---------------------------------------------------------------------------------------------
+constexpr int EWPB = 8;
+
+__global__ __launch_bounds__(256) void emotion_kernel(const float* __restrict__ emo, int64_t B, int ED, int d, int DH,
+                                                      const float* __restrict__ wee_t, const float* __restrict__ bee,
+                                                      const float* __restrict__ lg, const float* __restrict__ lb,
+                                                      const float* __restrict__ we2, const float* __restrict__ be2,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      float* __restrict__ zemo) {
+    extern __shared__ __attribute__((aligned(16))) float es[];
+    float* emo_s = es;                   // [EWPB][ED]
+    float* e1 = emo_s + EWPB * ED;       // [EWPB][d]
+    float* hp = e1 + EWPB * d;           // [EWPB][DH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t b0 = (int64_t)blockIdx.x * EWPB;
+    const int nb = (int)((B - b0) < EWPB ? (B - b0) : EWPB);
+    for (int i = tid; i < EWPB * ED; i += 256) {
+        const int w = i / ED;
+        emo_s[i] = w < nb ? emo[b0 * ED + i] : 0.f;
+    }
+    __syncthreads();
+    for (int n = tid; n < d; n += 256) {
+        float acc[EWPB];
+        const float bv = bee[n];
+#pragma unroll
+        for (int w = 0; w < EWPB; ++w) acc[w] = bv;
+        for (int k = 0; k < ED; ++k) {
+            const float wv = wee_t[(size_t)k * d + n];
+#pragma unroll
+            for (int w = 0; w < EWPB; ++w) acc[w] = fmaf(emo_s[w * ED + k], wv, acc[w]);
+        }
+#pragma unroll
+        for (int w = 0; w < EWPB; ++w) e1[w * d + n] = acc[w];
+    }
+    __syncthreads();
+    // LayerNorm per window, wave `wave` handles windows wave and wave+4
+    for (int w = wave; w < EWPB; w += 4) {
+        float s = 0.f;
+        for (int n = lane; n < d; n += 64) s += e1[w * d + n];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / d;
+        float v = 0.f;
+        for (int n = lane; n < d; n += 64) { const float t = e1[w * d + n] - mean; v += t * t; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        const float rstd = 1.0f / sqrtf(v / d + 1e-5f);
+        for (int n = lane; n < d; n += 64) e1[w * d + n] = (e1[w * d + n] - mean) * rstd * lg[n] + lb[n];
+    }
+    __syncthreads();
+    for (int m = tid; m < DH; m += 256) {
+        float acc[EWPB];
+        const float bv = be2[m];
+#pragma unroll
+        for (int w = 0; w < EWPB; ++w) acc[w] = bv;
+        for (int n = 0; n < d; ++n) {
+            const float wv = we2[(size_t)n * DH + m];
+#pragma unroll
+            for (int w = 0; w < EWPB; ++w) acc[w] = fmaf(e1[w * d + n], wv, acc[w]);
+        }
+        const float w2v = w2[m];
+#pragma unroll
+        for (int w = 0; w < EWPB; ++w) hp[w * DH + m] = fmaxf(acc[w], 0.f) * w2v;
+    }
+    __syncthreads();
+    for (int w = wave; w < EWPB; w += 4) {
+        float s = 0.f;
+        for (int m = lane; m < DH; m += 64) s += hp[w * DH + m];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0 && w < nb) zemo[b0 + w] = s + b2[0];
+    }
+}
+
+__global__ void smooth_kernel(float* __restrict__ x, float* __restrict__ state, int64_t n, int first, float alpha) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = x[i];
+    if (!first) v = alpha * v + (1.0f - alpha) * state[i];
+    state[i] = v;
+    x[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+static const float* dv(Context* c, const char* name) { return c->packed.at(name).dev; }
+
+int launch_emotion(Context* c, const float* emo, int64_t B, float* zemo, void* stream) {
+    const size_t lds = (size_t)EWPB * (c->ED + c->d + c->DH) * sizeof(float);
+    if (lds > 160 * 1024) return fail(KM_ERR_UNSUPPORTED, "emotion_dim/d_model too large for the emotion kernel");
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&emotion_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)((B + EWPB - 1) / EWPB);
+    hipLaunchKernelGGL(emotion_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, emo, B, c->ED, c->d, c->DH,
+                       dv(c, "wee_t"), dv(c, "bee"), dv(c, "eln_g"), dv(c, "eln_b"), dv(c, "we2"), dv(c, "be2"),
+                       dv(c, "w2"), dv(c, "b2"), zemo);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+int launch_core_fused(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short,
+                      const float* zemo, float* out, float* raw, float* attn, float* state, int first,
+                      void* stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&core_fused_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, fused::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&core_fused_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, fused::LDS_BYTES));
+        attr_set = true;
+    }
+    CoreArgs a;
+    a.mel = mel; a.mel_short = mel_short; a.zemo = zemo; a.t_in = (int)T_in;
+    a.wce_p = dv(c, "wce_p"); a.bce = dv(c, "bce"); a.ln_g = dv(c, "ln_g"); a.ln_b = dv(c, "ln_b");
+    a.qk_p = dv(c, "qk_p"); a.wv_p = dv(c, "wv_p"); a.wf_p = dv(c, "wf_p"); a.bf = dv(c, "bf");
+    a.w2 = dv(c, "w2"); a.b2 = dv(c, "b2"); a.wsum = dv(c, "wsum");
+    a.out = out; a.raw = raw; a.attn = attn; a.state = state; a.first = first; a.alpha = c->alpha;
+    if (attn)
+        hipLaunchKernelGGL(core_fused_kernel<true>, dim3((unsigned)B), dim3(fused::NT), fused::LDS_BYTES, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(core_fused_kernel<false>, dim3((unsigned)B), dim3(fused::NT), fused::LDS_BYTES, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+int launch_smooth(Context* c, float* x, float* state, int64_t B, int first, void* stream) {
+    const int64_t n = B * c->NB;
+    hipLaunchKernelGGL(smooth_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, state, n,
+                       first, c->alpha);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+}  // namespace km

@@ -1,0 +1,445 @@
+// Host side of libkoemorph_hip.so: parameter store, weight folding and packing, mel plans.
+// No HIP calls in this file, so it also runs on a machine without a GPU (CPU tests).
+//
+// Folding (eval mode, done once in double precision):
+//   * the mouth queries are input independent (dual_stream_attention.py:221), so
+//     Q = mouth_queries Wq^T + bq is precomputed, scaled by 1/sqrt(hd) and multiplied into the key
+//     projection:  scores_h = (Q_h Wk_h) Y^T + Q_h bk_h.  The second term is constant along the
+//     key axis and cancels in the softmax (:225-230), so it is dropped.
+//   * out_proj -> mel_output_proj -> decoder[0] (:231, :248, :150-151) are consecutive affine maps
+//     with no non-linearity in between: folded into one (d x d/2) matrix.  The value bias bv rides
+//     through because softmax rows sum to one.
+//   * the emotion stream attends over ONE key (:234-239): softmax == 1, so its output is
+//     out_proj(Wv e + bv) for every query; everything after the emotion LayerNorm folds into one
+//     (d x d/2) matrix.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "km_context.h"
+
+namespace km {
+
+const int kMouthIdx[kNumMouth] = {14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27,
+                                  28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 51};
+const int kExprIdx[kNumExpr] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13,
+                                41, 42, 43, 44, 45, 46, 47, 48, 49, 50};
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+const char* last_error() { return g_err; }
+
+using dvec = std::vector<double>;
+
+static dvec to_d(const std::vector<float>& v) { return dvec(v.begin(), v.end()); }
+
+// C[M x N] = A[M x K] * B[K x N]
+static dvec mm(const dvec& A, const dvec& B, int M, int K, int N) {
+    dvec C((size_t)M * N, 0.0);
+    for (int i = 0; i < M; ++i)
+        for (int k = 0; k < K; ++k) {
+            const double a = A[(size_t)i * K + k];
+            const double* b = &B[(size_t)k * N];
+            double* c = &C[(size_t)i * N];
+            for (int j = 0; j < N; ++j) c[j] += a * b[j];
+        }
+    return C;
+}
+
+static dvec transpose(const dvec& A, int R, int Cn) {
+    dvec T((size_t)R * Cn);
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < Cn; ++j) T[(size_t)j * R + i] = A[(size_t)i * Cn + j];
+    return T;
+}
+
+static std::vector<float> to_f(const dvec& v) { return std::vector<float>(v.begin(), v.end()); }
+
+static const std::vector<float>& P(Context* c, const char* k) { return c->params.at(k).data; }
+
+static void put(Context* c, const char* name, std::vector<float>&& v) {
+    c->packed[name].host = std::move(v);
+}
+
+static dvec softmax_d(const std::vector<float>& w, double temp) {
+    dvec r(w.size());
+    double m = -1e300;
+    for (float x : w) m = std::fmax(m, x / temp);
+    double s = 0;
+    for (size_t i = 0; i < w.size(); ++i) { r[i] = std::exp(w[i] / temp - m); s += r[i]; }
+    for (double& x : r) x /= s;
+    return r;
+}
+
+// Chain y = ((x Wa^T + ba) Wb^T + bb) W1^T + b1 folded into x F + f, with an input bias bin that
+// is pushed through as well (x -> x + bin first).  Wa, Wb are (d x d) [out][in], W1 is (DH x d).
+static void fold_chain(const dvec& bin, const dvec& Wa, const dvec& ba, const dvec& Wb, const dvec& bb,
+                       const dvec& W1, const dvec& b1, int d, int DH, dvec& F, dvec& f) {
+    dvec WaT = transpose(Wa, d, d), WbT = transpose(Wb, d, d), W1T = transpose(W1, DH, d);  // [in][out]
+    dvec M2 = mm(WaT, WbT, d, d, d);
+    F = mm(M2, W1T, d, d, DH);                                                               // d x DH
+    dvec t1 = mm(bin, WaT, 1, d, d);
+    for (int i = 0; i < d; ++i) t1[i] += ba[i];
+    dvec t2 = mm(t1, WbT, 1, d, d);
+    for (int i = 0; i < d; ++i) t2[i] += bb[i];
+    f = mm(t2, W1T, 1, d, DH);
+    for (int i = 0; i < DH; ++i) f[i] += b1[i];
+}
+
+int finalize_host(Context* c) {
+    for (const auto& k : c->param_order)
+        if (!c->params[k].loaded) return fail(KM_ERR_NOT_FINALIZED, "parameter '%s' was never loaded", k.c_str());
+    const int d = c->d, H = c->H, hd = c->hd, KT = c->KT, ED = c->ED, DH = c->DH, NB = c->NB;
+    const int NQ = kNumMouth;
+
+    const dvec inw = to_d(P(c, "mel_attention.in_proj_weight")), inb = to_d(P(c, "mel_attention.in_proj_bias"));
+    dvec Wq(inw.begin(), inw.begin() + (size_t)d * d), Wk(inw.begin() + (size_t)d * d, inw.begin() + (size_t)2 * d * d),
+        Wv(inw.begin() + (size_t)2 * d * d, inw.end());
+    dvec bq(inb.begin(), inb.begin() + d), bv(inb.begin() + 2 * d, inb.end());
+
+    // Q = mouth_queries Wq^T + bq ; Qk[h][q][k] = 1/sqrt(hd) * sum_e Q[q][h*hd+e] Wk[h*hd+e][k]
+    dvec Q = mm(to_d(P(c, "mouth_queries")), transpose(Wq, d, d), NQ, d, d);
+    for (int q = 0; q < NQ; ++q)
+        for (int i = 0; i < d; ++i) Q[(size_t)q * d + i] += bq[i];
+    const double scale = 1.0 / std::sqrt((double)hd);
+    dvec Qk((size_t)H * NQ * d, 0.0);
+    for (int h = 0; h < H; ++h)
+        for (int q = 0; q < NQ; ++q)
+            for (int e = 0; e < hd; ++e) {
+                const double qv = Q[(size_t)q * d + h * hd + e] * scale;
+                const double* wk = &Wk[(size_t)(h * hd + e) * d];
+                double* o = &Qk[((size_t)h * NQ + q) * d];
+                for (int k = 0; k < d; ++k) o[k] += qv * wk[k];
+            }
+
+    // mouth chain: out_proj -> mel_output_proj -> decoder[0], value bias pushed through
+    dvec Wf, bf;
+    fold_chain(bv, to_d(P(c, "mel_attention.out_proj.weight")), to_d(P(c, "mel_attention.out_proj.bias")),
+               to_d(P(c, "mel_output_proj.weight")), to_d(P(c, "mel_output_proj.bias")),
+               to_d(P(c, "blendshape_decoder.0.weight")), to_d(P(c, "blendshape_decoder.0.bias")), d, DH, Wf, bf);
+
+    // emotion chain: Wv_e -> out_proj -> emotion_output_proj -> decoder[0]
+    const dvec einw = to_d(P(c, "emotion_attention.in_proj_weight")), einb = to_d(P(c, "emotion_attention.in_proj_bias"));
+    dvec Wve(einw.begin() + (size_t)2 * d * d, einw.end()), bve(einb.begin() + 2 * d, einb.end());
+    dvec WfE, bfE;
+    fold_chain(bve, to_d(P(c, "emotion_attention.out_proj.weight")), to_d(P(c, "emotion_attention.out_proj.bias")),
+               to_d(P(c, "emotion_output_proj.weight")), to_d(P(c, "emotion_output_proj.bias")),
+               to_d(P(c, "blendshape_decoder.0.weight")), to_d(P(c, "blendshape_decoder.0.bias")), d, DH, WfE, bfE);
+    dvec We2 = mm(transpose(Wve, d, d), WfE, d, d, DH);   // [n][hid] = sum_i Wve[i][n] WfE[i][hid]
+
+    // stream weights: 0.5 * (softmax(mel_w / tau) + softmax(emo_w / tau))   (:252-253, :264-267)
+    dvec wm = softmax_d(P(c, "mel_weights"), c->cfg.temperature), we = softmax_d(P(c, "emotion_weights"), c->cfg.temperature);
+    std::vector<float> wsum(NB);
+    for (int i = 0; i < NB; ++i) {
+        // the reference evaluates w_m*bs*0.5 + w_e*bs*0.5 in fp32; the folded form differs by <= 1 ulp
+        wsum[i] = (float)(0.5 * wm[i] + 0.5 * we[i]);
+    }
+    c->alpha = (float)(1.0 / (1.0 + std::exp(-(double)P(c, "smoothing_alpha")[0])));
+
+    // ---- plain (unpacked) folded buffers: used by the generic kernels and by the tests ----
+    put(c, "qk", to_f(Qk));                                        // (H, 28, d)
+    put(c, "wf", to_f(Wf));                                        // (d, DH)
+    put(c, "bf", to_f(bf));                                        // (DH)
+    put(c, "we2", to_f(We2));                                      // (d, DH)
+    put(c, "be2", to_f(bfE));                                      // (DH)
+    put(c, "wee_t", to_f(transpose(to_d(P(c, "emotion_encoder.weight")), d, ED)));   // (ED, d)
+    put(c, "bee", std::vector<float>(P(c, "emotion_encoder.bias")));
+    put(c, "eln_g", std::vector<float>(P(c, "emotion_norm.weight")));
+    put(c, "eln_b", std::vector<float>(P(c, "emotion_norm.bias")));
+    put(c, "bce", std::vector<float>(P(c, "mel_channel_encoder.bias")));
+    put(c, "ln_g", std::vector<float>(P(c, "mel_norm.weight")));
+    put(c, "ln_b", std::vector<float>(P(c, "mel_norm.bias")));
+    put(c, "w2", std::vector<float>(P(c, "blendshape_decoder.3.weight")));
+    put(c, "b2", std::vector<float>(P(c, "blendshape_decoder.3.bias")));
+    put(c, "wsum", std::move(wsum));
+
+    // ---- packed MFMA operand images for the fused gfx950 kernel -------------------------
+    // v_mfma_f32_16x16x4_f32 operand maps: lane l = 16*g + j supplies A[i=j][k=g] and B[k=g][n=j].
+    c->fused_ok = (d == 256 && H == 8 && c->T == 256 && c->NK == 80 && NB == 52 && c->cfg.mel_temporal_frames == 3);
+    if (c->fused_ok) {
+        const std::vector<float>& Wce = P(c, "mel_channel_encoder.weight");   // (d, KT)
+        const int NW = 8, KP = 33;                                            // 66 k-steps of 4 >= KT=259
+        std::vector<float> wce_p((size_t)NW * KP * 64 * 4);
+        for (int w = 0; w < NW; ++w)
+            for (int kp = 0; kp < KP; ++kp)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 4; ++e) {
+                        const int g = l >> 4, j = l & 15, ds = e >> 1, t = e & 1;
+                        const int k = 4 * (2 * kp + ds) + g, n = 16 * (2 * w + t) + j;
+                        wce_p[(((size_t)w * KP + kp) * 64 + l) * 4 + e] = k < KT ? Wce[(size_t)n * KT + k] : 0.0f;
+                    }
+        put(c, "wce_p", std::move(wce_p));
+
+        const int KB = d / 16;
+        std::vector<float> qk_p((size_t)H * KB * 2 * 64 * 4), wv_p((size_t)H * KB * 2 * 64 * 4), wf_p((size_t)8 * KB * 64 * 4);
+        for (int h = 0; h < H; ++h)
+            for (int kb = 0; kb < KB; ++kb)
+                for (int t = 0; t < 2; ++t)
+                    for (int l = 0; l < 64; ++l)
+                        for (int s = 0; s < 4; ++s) {
+                            const int g = l >> 4, j = l & 15, k = 16 * kb + 4 * g + s;
+                            const size_t o = ((((size_t)h * KB + kb) * 2 + t) * 64 + l) * 4 + s;
+                            const int q = 16 * t + j;
+                            qk_p[o] = q < NQ ? (float)Qk[((size_t)h * NQ + q) * d + k] : 0.0f;
+                            wv_p[o] = (float)Wv[(size_t)(h * hd + 16 * t + j) * d + k];
+                        }
+        for (int w = 0; w < 8; ++w)
+            for (int kb = 0; kb < KB; ++kb)
+                for (int l = 0; l < 64; ++l)
+                    for (int s = 0; s < 4; ++s) {
+                        const int g = l >> 4, j = l & 15, k = 16 * kb + 4 * g + s;
+                        wf_p[(((size_t)w * KB + kb) * 64 + l) * 4 + s] = (float)Wf[(size_t)k * DH + 16 * w + j];
+                    }
+        put(c, "qk_p", std::move(qk_p));
+        put(c, "wv_p", std::move(wv_p));
+        put(c, "wf_p", std::move(wf_p));
+    }
+    c->host_finalized = true;
+    return KM_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// mel plans
+// ---------------------------------------------------------------------------------------
+static double hz_to_mel(double f, bool htk) {
+    if (htk) return 2595.0 * std::log10(1.0 + f / 700.0);
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+
+static double mel_to_hz(double m, bool htk) {
+    if (htk) return 700.0 * (std::pow(10.0, m / 2595.0) - 1.0);
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+MelPlan* build_mel_plan(const km_mel_config& cfg) {
+    MelPlan* p = new MelPlan();
+    p->cfg = cfg;
+    const int N = cfg.n_fft, nf = N / 2 + 1, nm = cfg.n_mels;
+    p->n_freq = nf;
+    const double PI = 3.14159265358979323846;
+    // periodic Hann (scipy get_window('hann', N, fftbins=True) == torch.hann_window(N, periodic=True))
+    std::vector<double> w(N);
+    double sw2 = 0;
+    for (int n = 0; n < N; ++n) { w[n] = 0.5 - 0.5 * std::cos(2.0 * PI * n / N); sw2 += w[n] * w[n]; }
+    const double wn = cfg.window_norm ? 1.0 / std::sqrt(sw2) : 1.0;
+    p->window.resize(N);
+    for (int n = 0; n < N; ++n) p->window[n] = (float)(w[n] * wn);
+    p->twiddle.resize((size_t)2 * N);
+    for (int q = 0; q < N; ++q) {
+        p->twiddle[2 * q] = (float)std::cos(2.0 * PI * q / N);
+        p->twiddle[2 * q + 1] = (float)(-std::sin(2.0 * PI * q / N));
+    }
+    // triangular filters: librosa.filters.mel (slaney/htk, norm) == torchaudio melscale_fbanks
+    const bool htk = cfg.mel_scale == KM_MEL_HTK;
+    std::vector<double> mel_f(nm + 2);
+    const double m0 = hz_to_mel(cfg.f_min, htk), m1 = hz_to_mel(cfg.f_max, htk);
+    for (int i = 0; i < nm + 2; ++i) mel_f[i] = mel_to_hz(m0 + (m1 - m0) * i / (nm + 1), htk);
+    p->fb_start.assign(nm, 0);
+    p->fb_count.assign(nm, 0);
+    p->fb_offset.assign(nm, 0);
+    for (int i = 0; i < nm; ++i) {
+        const double fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
+        const double enorm = cfg.slaney_norm ? 2.0 / (mel_f[i + 2] - mel_f[i]) : 1.0;
+        int first = -1, last = -1;
+        std::vector<float> row(nf, 0.0f);
+        for (int k = 0; k < nf; ++k) {
+            const double fk = (double)k * cfg.sample_rate / N;
+            const double lower = (fk - mel_f[i]) / fd0, upper = (mel_f[i + 2] - fk) / fd1;
+            const double v = std::fmax(0.0, std::fmin(lower, upper));
+            const float v32 = (float)v;                      // librosa stores the triangle in float32 ...
+            const float wv = (float)((double)v32 * enorm);   // ... and scales it in place
+            row[k] = wv;
+            if (wv != 0.0f) { if (first < 0) first = k; last = k; }
+        }
+        p->fb_offset[i] = (int32_t)p->fb_weight.size();
+        if (first >= 0) {
+            p->fb_start[i] = first;
+            p->fb_count[i] = last - first + 1;
+            for (int k = first; k <= last; ++k) p->fb_weight.push_back(row[k]);
+        }
+    }
+    if (p->fb_weight.empty()) p->fb_weight.push_back(0.0f);
+    return p;
+}
+
+static bool same_cfg(const km_mel_config& a, const km_mel_config& b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
+
+MelPlan* find_or_add_plan(Context* c, const km_mel_config& cfg) {
+    for (MelPlan* p : c->mel_plans)
+        if (same_cfg(p->cfg, cfg)) return p;
+    MelPlan* p = build_mel_plan(cfg);
+    c->mel_plans.push_back(p);
+    return p;
+}
+
+}  // namespace km
+
+// ---------------------------------------------------------------------------------------
+// C-ABI: host-only entry points
+// ---------------------------------------------------------------------------------------
+using namespace km;
+
+namespace km { const char* last_error(); }
+
+extern "C" {
+
+int km_abi_version(void) { return KM_ABI_VERSION; }
+const char* km_last_error(void) { return km::last_error(); }
+
+static void expect(Context* c, const char* key, std::vector<int64_t> shape) {
+    HostParam hp;
+    hp.shape = std::move(shape);
+    size_t n = 1;
+    for (int64_t s : hp.shape) n *= (size_t)s;
+    hp.data.assign(n, 0.0f);
+    c->params[key] = std::move(hp);
+    c->param_order.push_back(key);
+}
+
+static int check_mel_cfg(const km_mel_config& m) {
+    if (m.n_fft != 512 && m.n_fft != 1024) return fail(KM_ERR_UNSUPPORTED, "n_fft must be 512 or 1024 (got %d)", m.n_fft);
+    if (m.hop_length <= 0) return fail(KM_ERR_INVALID_ARG, "invalid hop_length %d", m.hop_length);   // stft.py:78-81
+    if (m.n_mels <= 0 || m.n_mels > 128) return fail(KM_ERR_UNSUPPORTED, "n_mels must be in 1..128 (got %d)", m.n_mels);
+    if (!(m.f_max > m.f_min) || m.f_min < 0 || m.f_max > m.sample_rate / 2.0f + 1e-3f)
+        return fail(KM_ERR_INVALID_ARG, "need 0 <= f_min < f_max <= sr/2");
+    return KM_OK;
+}
+
+int km_create(const km_config* cfg, km_handle* out) {
+    if (!cfg || !out) return fail(KM_ERR_INVALID_ARG, "km_create: NULL argument");
+    if (cfg->abi_version != KM_ABI_VERSION) return fail(KM_ERR_INVALID_ARG, "km_config.abi_version %d != %d", cfg->abi_version, KM_ABI_VERSION);
+    if (cfg->d_model <= 0 || cfg->num_heads <= 0 || cfg->d_model % cfg->num_heads != 0)
+        return fail(KM_ERR_INVALID_ARG, "embed_dim %d must be divisible by num_heads %d", cfg->d_model, cfg->num_heads);
+    if (cfg->d_model % 2 != 0 || cfg->mel_sequence_length <= 0 || cfg->emotion_dim <= 0)
+        return fail(KM_ERR_INVALID_ARG, "bad d_model / mel_sequence_length / emotion_dim");
+    if (cfg->num_blendshapes != 52 || cfg->num_mel_channels <= 0 || cfg->mel_temporal_frames != 3)
+        return fail(KM_ERR_UNSUPPORTED, "num_blendshapes must be 52 and mel_temporal_frames 3 (ARKit grouping, dual_stream_attention.py:14-45)");
+    if (cfg->num_mel_channels != cfg->mel.n_mels) return fail(KM_ERR_INVALID_ARG, "num_mel_channels != mel.n_mels");
+    if (int rc = check_mel_cfg(cfg->mel)) return rc;
+    km_context* c = new km_context();
+    c->cfg = *cfg;
+    c->d = cfg->d_model; c->H = cfg->num_heads; c->hd = c->d / c->H; c->T = cfg->mel_sequence_length;
+    c->KT = c->T + cfg->mel_temporal_frames; c->ED = cfg->emotion_dim; c->DH = c->d / 2;
+    c->NB = cfg->num_blendshapes; c->NK = cfg->num_mel_channels;
+    const int64_t d = c->d;
+    // state-dict layout of DualStreamCrossAttention (dual_stream_attention.py:102-159)
+    expect(c, "mouth_queries", {kNumMouth, d});
+    expect(c, "expression_queries", {kNumExpr, d});
+    expect(c, "mel_weights", {c->NB});
+    expect(c, "emotion_weights", {c->NB});
+    expect(c, "mel_channel_encoder.weight", {d, c->KT});
+    expect(c, "mel_channel_encoder.bias", {d});
+    expect(c, "mel_attention.in_proj_weight", {3 * d, d});
+    expect(c, "mel_attention.in_proj_bias", {3 * d});
+    expect(c, "mel_attention.out_proj.weight", {d, d});
+    expect(c, "mel_attention.out_proj.bias", {d});
+    expect(c, "emotion_encoder.weight", {d, c->ED});
+    expect(c, "emotion_encoder.bias", {d});
+    expect(c, "emotion_attention.in_proj_weight", {3 * d, d});
+    expect(c, "emotion_attention.in_proj_bias", {3 * d});
+    expect(c, "emotion_attention.out_proj.weight", {d, d});
+    expect(c, "emotion_attention.out_proj.bias", {d});
+    expect(c, "mel_output_proj.weight", {d, d});
+    expect(c, "mel_output_proj.bias", {d});
+    expect(c, "emotion_output_proj.weight", {d, d});
+    expect(c, "emotion_output_proj.bias", {d});
+    expect(c, "blendshape_decoder.0.weight", {d / 2, d});
+    expect(c, "blendshape_decoder.0.bias", {d / 2});
+    expect(c, "blendshape_decoder.3.weight", {1, d / 2});
+    expect(c, "blendshape_decoder.3.bias", {1});
+    expect(c, "mel_norm.weight", {d});
+    expect(c, "mel_norm.bias", {d});
+    expect(c, "emotion_norm.weight", {d});
+    expect(c, "emotion_norm.bias", {d});
+    // SimplifiedDualStreamModel.smoothing_alpha (simplified_dual_stream_model.py:163); optional, default 0.8
+    expect(c, "smoothing_alpha", {});
+    c->params["smoothing_alpha"].data[0] = 0.8f;
+    c->params["smoothing_alpha"].loaded = true;
+    c->mel_plans.push_back(build_mel_plan(cfg->mel));
+    *out = c;
+    return KM_OK;
+}
+
+static const char* strip_prefix(const char* key) {
+    static const char pre[] = "dual_stream_attention.";
+    return std::strncmp(key, pre, sizeof(pre) - 1) == 0 ? key + sizeof(pre) - 1 : key;
+}
+
+int km_load_param(km_handle h, const char* key, const float* data, const int64_t* shape, int32_t ndim) {
+    if (!h || !key || !data) return fail(KM_ERR_INVALID_ARG, "km_load_param: NULL argument");
+    Context* c = h;
+    key = strip_prefix(key);
+    auto it = c->params.find(key);
+    if (it == c->params.end()) return fail(KM_ERR_INVALID_ARG, "unexpected key '%s' in state dict", key);
+    HostParam& hp = it->second;
+    size_t n = 1;
+    bool ok = (size_t)ndim == hp.shape.size();
+    for (int i = 0; ok && i < ndim; ++i) ok = shape[i] == hp.shape[i];
+    if (!ok) {
+        // torch also reports the two shapes on a size mismatch
+        char want[64] = "", got[64] = "";
+        for (int64_t s : hp.shape) snprintf(want + strlen(want), sizeof(want) - strlen(want), "%lld,", (long long)s);
+        for (int i = 0; i < ndim; ++i) snprintf(got + strlen(got), sizeof(got) - strlen(got), "%lld,", (long long)shape[i]);
+        return fail(KM_ERR_INVALID_ARG, "size mismatch for %s: expected (%s) got (%s)", key, want, got);
+    }
+    for (int64_t s : hp.shape) n *= (size_t)s;
+    std::memcpy(hp.data.data(), data, n * sizeof(float));
+    hp.loaded = true;
+    c->host_finalized = false;
+    c->dev_finalized = false;
+    return KM_OK;
+}
+
+int km_get_param(km_handle h, const char* key, float* out, int64_t n) {
+    if (!h || !key || !out) return fail(KM_ERR_INVALID_ARG, "km_get_param: NULL argument");
+    auto it = h->params.find(strip_prefix(key));
+    if (it == h->params.end()) return fail(KM_ERR_INVALID_ARG, "unknown key '%s'", key);
+    if ((size_t)n != it->second.data.size()) return fail(KM_ERR_INVALID_ARG, "km_get_param: size mismatch for %s", key);
+    std::memcpy(out, it->second.data.data(), (size_t)n * sizeof(float));
+    return KM_OK;
+}
+
+int km_param_count(km_handle h, int32_t* expected, int32_t* loaded) {
+    if (!h) return fail(KM_ERR_INVALID_ARG, "NULL handle");
+    int e = 0, l = 0;
+    for (auto& kv : h->params) { ++e; l += kv.second.loaded ? 1 : 0; }
+    if (expected) *expected = e;
+    if (loaded) *loaded = l;
+    return KM_OK;
+}
+
+int km_finalize_host(km_handle h) {
+    if (!h) return fail(KM_ERR_INVALID_ARG, "NULL handle");
+    return finalize_host(h);
+}
+
+int km_debug_buffer(km_handle h, const char* name, float* out, int64_t* n) {
+    if (!h || !name || !n) return fail(KM_ERR_INVALID_ARG, "km_debug_buffer: NULL argument");
+    if (!h->host_finalized) return fail(KM_ERR_NOT_FINALIZED, "km_debug_buffer before km_finalize_host");
+    auto it = h->packed.find(name);
+    if (it == h->packed.end()) return fail(KM_ERR_INVALID_ARG, "no buffer named '%s'", name);
+    if (!out) { *n = (int64_t)it->second.host.size(); return KM_OK; }
+    if (*n != (int64_t)it->second.host.size()) return fail(KM_ERR_INVALID_ARG, "km_debug_buffer: size mismatch");
+    std::memcpy(out, it->second.host.data(), it->second.host.size() * sizeof(float));
+    return KM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,369 @@
+// Log-mel front end of the KoeMorph hot path for gfx950 (MI355X).
+//
+// Replaces the reference's three CPU front ends:
+//   librosa.feature.melspectrogram + power_to_db   src/model/simplified_dual_stream_model.py:188-200
+//                                                  src/features/mel_sliding_window.py:280-307
+//   torchaudio.transforms.MelSpectrogram + log     src/features/stft.py:84-140
+//
+// Kernel 1  mel_power_kernel<NFFT>: grid (frame chunks, windows).  A 256-thread workgroup owns 16
+//   consecutive frames of one window.  Each wave transforms TWO real frames at once as one complex
+//   NFFT-point FFT (z = frame_a + i frame_b), fully wave-private:
+//     pass 1  radix-R0 (R0 = NFFT/64: 16 or 8) butterflies in registers on samples n = lane + 64 i
+//             (global loads are unit-stride across lanes whatever the hop / alignment),
+//     pass 2  radix-8, pass 3 radix-8, with two transposes through a wave-private LDS buffer
+//             (row strides 72 / 9 complex keep the ds_read_b64 / ds_write_b64 half-waves on distinct banks),
+//   the two spectra are separated with the conjugate-symmetry identities, |.|^2 goes to an LDS
+//   [frame][bin] image with an odd row stride, and the sparse triangular mel filters (<= 2 filters per
+//   bin, stored CSR per filter) are applied with lanes = frames so every LDS read is conflict free.
+//   Output: power-mel (B, F, n_mels) + per-window max via atomicMax on the float bits (values >= 0).
+// Kernel 2  mel_log_kernel: dB against the per-window max, top_db clip and affine (librosa
+//   power_to_db(ref=np.max) is a whole-window reduction, so it cannot be fused into kernel 1), or
+//   log(x + eps); applies the truncate / repeat-last-frame output policy; emits the last 3 frames.
+//
+// Everything is fp32.  librosa runs the rFFT in float64 and rounds to complex64; the fp32 FFT here
+// differs by ~1e-7 of the frame's peak amplitude, visible only in bins > 60 dB below the peak.
+#include <hip/hip_runtime.h>
+
+#include "km_context.h"
+
+namespace km {
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(KM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace mel {
+constexpr int FPB = 16;          // frames per workgroup
+constexpr int WAVES = 4;
+constexpr int FFT_BUF = 1152;    // complex elements per wave-private LDS buffer (16*72 = 128*9)
+}  // namespace mel
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// multiply by W_R^idx = exp(-2 pi i idx / R) for the constant indices of an unrolled radix-R DIF
+template <int R>
+__device__ __forceinline__ float2 twiddle_const(float2 d, int idx) {
+    // idx * 16 / R in sixteenths of a turn; after full unrolling every branch folds away
+    const int s = idx * (16 / R);
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, C2 = 0.70710678118654752f;
+    switch (s) {
+        case 0: return d;
+        case 1: return make_float2(d.x * C1 + d.y * S1, d.y * C1 - d.x * S1);
+        case 2: return make_float2((d.x + d.y) * C2, (d.y - d.x) * C2);
+        case 3: return make_float2(d.x * S1 + d.y * C1, d.y * S1 - d.x * C1);
+        case 4: return make_float2(d.y, -d.x);
+        case 5: return make_float2(d.y * C1 - d.x * S1, -d.x * C1 - d.y * S1);
+        case 6: return make_float2((d.y - d.x) * C2, -(d.x + d.y) * C2);
+        default: return make_float2(-d.x * C1 + d.y * S1, -d.y * C1 - d.x * S1);   // 7
+    }
+}
+
+__host__ __device__ constexpr int bitrev(int i, int bits) {
+    int r = 0;
+    for (int b = 0; b < bits; ++b) r |= ((i >> b) & 1) << (bits - 1 - b);
+    return r;
+}
+
+// In-register radix-2 DIF FFT of R points (R = 8 or 16).  Output X[bitrev(i)] is left in v[i].
+template <int R>
+__device__ __forceinline__ void dif_fft(float2 (&v)[R]) {
+#pragma unroll
+    for (int h = R / 2; h >= 1; h >>= 1) {
+#pragma unroll
+        for (int base = 0; base < R; base += 2 * h) {
+#pragma unroll
+            for (int i = 0; i < h; ++i) {
+                const float2 a = v[base + i], b = v[base + i + h];
+                v[base + i] = cadd(a, b);
+                v[base + i + h] = twiddle_const<R>(csub(a, b), i * (R / (2 * h)));
+            }
+        }
+    }
+}
+
+struct MelArgs {
+    const float* audio;   // (B, L)
+    int64_t L;
+    int n_frames;         // frames computed per window = 1 + L / hop
+    int hop;
+    int pad_mode;
+    int n_mels;
+    const float* window;  // NFFT
+    const float2* twiddle;  // NFFT: W_N^q
+    const int* fb_start;
+    const int* fb_count;
+    const int* fb_offset;
+    const float* fb_weight;
+    float* melpow;        // (B, n_frames, n_mels)
+    unsigned* melmax;     // (B) float bits, zero-initialised
+};
+
+template <int NFFT>
+__global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
+    using namespace mel;
+    constexpr int R0 = NFFT / 64;          // 16 or 8
+    constexpr int G = R0 / 8;              // radix-8 groups per lane in passes 2 and 3
+    constexpr int LOG_R0 = R0 == 16 ? 4 : 3;
+    constexpr int NF = NFFT / 2 + 1;       // bins; odd => conflict-free [frame][bin] image for lanes = frames
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float2* fbuf = reinterpret_cast<float2*>(smem);                     // [WAVES][FFT_BUF]
+    float* pw = smem + WAVES * FFT_BUF * 2;                              // [FPB][NF]
+    float* outs = pw + FPB * NF;                                         // [FPB][n_mels]
+    float* redmax = outs + FPB * 128;                                    // [WAVES]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int f0 = blockIdx.x * FPB;
+    const float* x = a.audio + (int64_t)b * a.L;
+    float2* buf = fbuf + wave * FFT_BUF;
+
+    // lane-constant operands, hoisted out of the frame loop
+    float win[R0];
+    float2 tw1[R0];                        // pass-1 twiddles W_N^(lane * k0), k0 = bitrev(i)
+#pragma unroll
+    for (int i = 0; i < R0; ++i) {
+        win[i] = a.window[lane + 64 * i];
+        tw1[i] = a.twiddle[(lane * bitrev(i, LOG_R0)) & (NFFT - 1)];
+    }
+    const int n2 = lane & 7, k0l = lane >> 3;
+    float2 tw2[8];                         // pass-2 twiddles W_64^(n2 * k1) = W_N^(R0 * n2 * k1), k1 = bitrev(i)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tw2[i] = a.twiddle[(R0 * n2 * bitrev(i, 3)) & (NFFT - 1)];
+
+    for (int p = wave; p < FPB / 2; p += WAVES) {
+        const int fa = f0 + 2 * p, fb = fa + 1;
+        if (fa < a.n_frames) {   // wave-uniform
+            float2 z[R0];
+            // ---- load + window: z = frame_a + i frame_b, sample n = lane + 64 i --------------------
+            const int64_t pa = (int64_t)fa * a.hop - NFFT / 2 + lane;
+            const int64_t pb = pa + a.hop;
+            const bool have_b = fb < a.n_frames;
+#pragma unroll
+            for (int i = 0; i < R0; ++i) {
+                int64_t qa = pa + 64 * i, qb = pb + 64 * i;
+                float va, vb;
+                if (a.pad_mode == KM_PAD_REFLECT) {                    // np.pad(mode='reflect')
+                    qa = qa < 0 ? -qa : (qa >= a.L ? 2 * (a.L - 1) - qa : qa);
+                    qb = qb < 0 ? -qb : (qb >= a.L ? 2 * (a.L - 1) - qb : qb);
+                    va = x[qa];
+                    vb = have_b ? x[qb] : 0.f;
+                } else {                                               // zero padding
+                    va = (qa >= 0 && qa < a.L) ? x[qa] : 0.f;
+                    vb = (have_b && qb >= 0 && qb < a.L) ? x[qb] : 0.f;
+                }
+                z[i] = make_float2(va * win[i], vb * win[i]);
+            }
+            // ---- pass 1: radix-R0 over n0 (n = 64 n0 + m, m = lane) ---------------------------------
+            dif_fft<R0>(z);
+#pragma unroll
+            for (int i = 0; i < R0; ++i) {
+                const int k0 = bitrev(i, LOG_R0);
+                buf[k0 * 72 + lane] = k0 == 0 ? z[i] : cmul(z[i], tw1[i]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- pass 2: radix-8 over n1 (m = 8 n1 + n2); this lane: n2 = lane&7, k0 = (lane>>3) + 8u ----
+            float2 y[G][8];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+#pragma unroll
+                for (int n1 = 0; n1 < 8; ++n1) y[u][n1] = buf[(k0l + 8 * u) * 72 + 8 * n1 + n2];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                dif_fft<8>(y[u]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k1 = bitrev(i, 3);
+                    // transposed image indexed by c = k0 + R0 k1 (row stride 9)
+                    buf[(k0l + 8 * u + R0 * k1) * 9 + n2] = k1 == 0 ? y[u][i] : cmul(y[u][i], tw2[i]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- pass 3: radix-8 over n2; this lane: c = lane + 64 v; output k = c + 8 R0 k2 ---------
+#pragma unroll
+            for (int v = 0; v < G; ++v) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) y[v][q] = buf[(lane + 64 * v) * 9 + q];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int v = 0; v < G; ++v) {
+                dif_fft<8>(y[v]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) buf[lane + 64 * v + 8 * R0 * bitrev(i, 3)] = y[v][i];
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- separate the two real spectra, |.|^2 ----------------------------------------------
+            // A[k] = (Z[k] + conj Z[N-k]) / 2,  B[k] = (Z[k] - conj Z[N-k]) / 2i
+            float* pwa = pw + (2 * p) * NF;
+            float* pwb = pwa + NF;
+#pragma unroll
+            for (int i = 0; i <= NFFT / 128; ++i) {
+                const int k = lane + 64 * i;
+                if (k <= NFFT / 2) {
+                    const float2 zk = buf[k], zn = buf[(NFFT - k) & (NFFT - 1)];
+                    const float ar = zk.x + zn.x, ai = zk.y - zn.y, br = zk.y + zn.y, bi = zk.x - zn.x;
+                    pwa[k] = 0.25f * (ar * ar + ai * ai);
+                    pwb[k] = 0.25f * (br * br + bi * bi);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- sparse triangular mel filters: lanes = frames (16 per filter), conflict-free reads --------
+    float vmax = 0.f;
+    const int fl = tid & 15;
+    const bool fvalid = f0 + fl < a.n_frames;
+    for (int m = tid >> 4; m < a.n_mels; m += 16) {
+        const int st = a.fb_start[m], cnt = a.fb_count[m];
+        const float* wt = a.fb_weight + a.fb_offset[m];
+        const float* pr = pw + fl * NF + st;
+        float acc = 0.f;
+        if (fvalid)
+            for (int i = 0; i < cnt; ++i) acc = fmaf(pr[i], wt[i], acc);
+        outs[fl * a.n_mels + m] = acc;
+        vmax = fmaxf(vmax, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if (lane == 0) redmax[wave] = vmax;
+    __syncthreads();
+    const int nf_here = (a.n_frames - f0) < FPB ? (a.n_frames - f0) : FPB;
+    float* dst = a.melpow + ((int64_t)b * a.n_frames + f0) * a.n_mels;
+    for (int i = tid; i < nf_here * a.n_mels; i += 256) dst[i] = outs[i];
+    if (tid == 0) {
+        const float mx = fmaxf(fmaxf(redmax[0], redmax[1]), fmaxf(redmax[2], redmax[3]));
+        atomicMax(a.melmax + b, __float_as_uint(mx));
+    }
+}
+
+struct LogArgs {
+    const float* melpow;     // (B, n_frames, n_mels)
+    const unsigned* melmax;  // (B)
+    int n_frames, out_frames, n_mels;
+    int log_mode;
+    float amin, top_db, db_add, db_scale, log_eps;
+    float* mel_long;         // (B, out_frames, n_mels)
+    float* mel_short;        // (B, 3, n_mels) or null: last three COMPUTED frames
+};
+
+__device__ __forceinline__ float log_one(const LogArgs& a, float s, float ref_db, float floor_db) {
+    if (a.log_mode == KM_LOG_LN_EPS) return logf(s + a.log_eps);
+    float v = 10.0f * log10f(fmaxf(a.amin, s)) - ref_db;   // librosa.power_to_db
+    v = fmaxf(v, floor_db);
+    return (v + a.db_add) * a.db_scale;
+}
+
+__global__ __launch_bounds__(256) void mel_log_kernel(LogArgs a) {
+    const int b = blockIdx.y;
+    const float ref = __uint_as_float(a.melmax[b]);
+    const float ref_db = 10.0f * log10f(fmaxf(a.amin, ref));
+    // log_spec.max() - top_db: the maximum of the window is its reference, so max_db = f(ref) - ref_db
+    const float floor_db = (10.0f * log10f(fmaxf(a.amin, ref)) - ref_db) - a.top_db;
+    const float* src = a.melpow + (int64_t)b * a.n_frames * a.n_mels;
+    const int total = a.out_frames * a.n_mels;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < total) {
+        int f = i / a.n_mels;
+        const int m = i - f * a.n_mels;
+        if (f >= a.n_frames) f = a.n_frames - 1;            // repeat the last frame (stft.py:136-140)
+        a.mel_long[(int64_t)b * total + i] = log_one(a, src[f * a.n_mels + m], ref_db, floor_db);
+    }
+    if (a.mel_short && blockIdx.x == 0) {
+        for (int s = threadIdx.x; s < 3 * a.n_mels; s += 256) {
+            const int r = s / a.n_mels, m = s - r * a.n_mels;
+            float v = 0.f;
+            // simplified_dual_stream_model.py:206-214: last 3 frames; fewer than 3 -> first rows, zero rest
+            if (a.n_frames >= 3) v = log_one(a, src[(a.n_frames - 3 + r) * a.n_mels + m], ref_db, floor_db);
+            else if (r < a.n_frames) v = log_one(a, src[r * a.n_mels + m], ref_db, floor_db);
+            a.mel_short[(int64_t)b * 3 * a.n_mels + s] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename Tv>
+static int upload(Tv** dst, const std::vector<Tv>& src) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), src.size() * sizeof(Tv)));
+    HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(Tv), hipMemcpyHostToDevice));
+    return KM_OK;
+}
+
+int upload_mel_plan(MelPlan* p) {
+    if (p->uploaded) return KM_OK;
+    if (int rc = upload(&p->d_window, p->window)) return rc;
+    if (int rc = upload(&p->d_twiddle, p->twiddle)) return rc;
+    if (int rc = upload(&p->d_fb_start, p->fb_start)) return rc;
+    if (int rc = upload(&p->d_fb_count, p->fb_count)) return rc;
+    if (int rc = upload(&p->d_fb_offset, p->fb_offset)) return rc;
+    if (int rc = upload(&p->d_fb_weight, p->fb_weight)) return rc;
+    p->uploaded = true;
+    return KM_OK;
+}
+
+void free_mel_plan(MelPlan* p) {
+    if (p->uploaded) {
+        (void)hipFree(p->d_window); (void)hipFree(p->d_twiddle); (void)hipFree(p->d_fb_start);
+        (void)hipFree(p->d_fb_count); (void)hipFree(p->d_fb_offset); (void)hipFree(p->d_fb_weight);
+    }
+    delete p;
+}
+
+static size_t mel_lds_bytes(int nfft) {
+    return (size_t)(mel::WAVES * mel::FFT_BUF * 2 + mel::FPB * (nfft / 2 + 1) + mel::FPB * 128 + mel::WAVES) * sizeof(float);
+}
+
+int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, int64_t out_frames,
+               float* mel_long, float* mel_short, void* stream) {
+    const km_mel_config& m = p->cfg;
+    const int64_t n_frames = 1 + L / m.hop_length;
+    if (m.pad_mode == KM_PAD_REFLECT && L <= m.n_fft / 2)
+        return fail(KM_ERR_INVALID_ARG, "reflect padding needs more than n_fft/2 = %d samples (got %lld)", m.n_fft / 2, (long long)L);
+    if (B > c->ws_windows || n_frames > c->ws_frames)
+        return fail(KM_ERR_WORKSPACE, "workspace holds %lld windows x %lld frames, need %lld x %lld: call km_reserve",
+                    (long long)c->ws_windows, (long long)c->ws_frames, (long long)B, (long long)n_frames);
+    if (!p->uploaded) return fail(KM_ERR_NOT_FINALIZED, "mel plan not uploaded (km_finalize / km_reserve first)");
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_kernel<1024>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)mel_lds_bytes(1024)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_kernel<512>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)mel_lds_bytes(512)));
+        attr_set = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(c->ws_melmax, 0, (size_t)B * sizeof(unsigned), st));
+    MelArgs a;
+    a.audio = audio; a.L = L; a.n_frames = (int)n_frames; a.hop = m.hop_length; a.pad_mode = m.pad_mode;
+    a.n_mels = m.n_mels; a.window = p->d_window; a.twiddle = reinterpret_cast<const float2*>(p->d_twiddle);
+    a.fb_start = p->d_fb_start; a.fb_count = p->d_fb_count; a.fb_offset = p->d_fb_offset; a.fb_weight = p->d_fb_weight;
+    a.melpow = c->ws_melpow; a.melmax = c->ws_melmax;
+    const dim3 grid((unsigned)((n_frames + mel::FPB - 1) / mel::FPB), (unsigned)B);
+    if (m.n_fft == 1024)
+        hipLaunchKernelGGL(mel_power_kernel<1024>, grid, dim3(256), mel_lds_bytes(1024), st, a);
+    else
+        hipLaunchKernelGGL(mel_power_kernel<512>, grid, dim3(256), mel_lds_bytes(512), st, a);
+    HIP_TRY(hipGetLastError());
+    LogArgs g;
+    g.melpow = c->ws_melpow; g.melmax = c->ws_melmax; g.n_frames = (int)n_frames;
+    g.out_frames = (int)(out_frames > 0 ? out_frames : n_frames); g.n_mels = m.n_mels; g.log_mode = m.log_mode;
+    g.amin = m.amin; g.top_db = m.top_db; g.db_add = m.db_add; g.db_scale = m.db_scale; g.log_eps = m.log_eps;
+    g.mel_long = mel_long; g.mel_short = mel_short;
+    const dim3 grid2((unsigned)((g.out_frames * m.n_mels + 255) / 256), (unsigned)B);
+    if (grid2.x > 0) {
+        hipLaunchKernelGGL(mel_log_kernel, grid2, dim3(256), 0, st, g);
+        HIP_TRY(hipGetLastError());
+    }
+    return KM_OK;
+}
+
+}  // namespace km

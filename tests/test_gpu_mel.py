@@ -1,0 +1,111 @@
+"""GPU parity of the log-mel front ends (HIP through the C-ABI) against oracle/mel.py.
+
+oracle/mel.py is PARITY UNPINNED by the reference (librosa / torchaudio are not installed and the
+reference holds no mel fixtures); it restates the published librosa / torchaudio algorithms and
+is cross-checked against transformers.audio_utils in tests/test_oracle_mel.py.
+
+Tolerances (normalised (dB+80)/80 units, range [0,1]): librosa runs the FFT in float64 and
+rounds to complex64, the kernel runs an fp32 FFT, so bins far below the frame peak carry a
+relative error that grows as the bin falls; in dB that is < 0.02 dB at -60 dB.  We assert
+max |err| < 5e-4 (0.04 dB) and mean |err| < 2e-5, and -- the contractual figure -- that the 52
+coefficients computed from GPU mel vs oracle mel agree within 1e-4 (observed ~1e-6).
+"""
+import numpy as np
+import pytest
+import torch
+
+from koemorph_amd import synth
+from koemorph_amd.engine import Engine, MelConfig
+from oracle import core, mel as omel, models
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = Engine()
+    e.load_state_dict(synth.make_core_params(7, style="trained"))
+    e.finalize()
+    return e
+
+
+@pytest.mark.parametrize("style,L", [("speech", 136448), ("uniform", 136448), ("speech", 136000), ("speech", 5000),
+                                      ("uniform", 533)])
+def test_batch_front_end(eng, style, L):
+    audio = synth.make_audio(3, 3, L, style)
+    long, short = eng.mel_batch(dev(audio))
+    rl, rs = omel.mel_batch(audio)
+    assert tuple(long.shape) == rl.shape and tuple(short.shape) == rs.shape
+    d = np.abs(long.cpu().numpy() - rl)
+    assert d.max() < 5e-4 and d.mean() < 2e-5, (d.max(), d.mean())
+    assert np.abs(short.cpu().numpy() - rs).max() < 5e-4
+
+
+def test_batch_front_end_edge_cases(eng):
+    # silence: power 0 everywhere -> amin floor -> dB 0 -> 1.0 after (x+80)/80
+    z = np.zeros((2, 136448), np.float32)
+    long, short = eng.mel_batch(dev(z))
+    rl, _ = omel.mel_batch(z)
+    np.testing.assert_allclose(long.cpu().numpy(), rl, atol=1e-6)
+    # one loud click: everything else is clipped at top_db below the peak
+    z[0, 70000] = 1.0
+    long, _ = eng.mel_batch(dev(z))
+    rl, _ = omel.mel_batch(z)
+    assert np.abs(long.cpu().numpy() - rl).max() < 5e-4
+    # windows are independent
+    a = synth.make_audio(5, 4, 136448)
+    l1, _ = eng.mel_batch(dev(a))
+    l2, _ = eng.mel_batch(dev(a[::-1].copy()))
+    assert torch.equal(l1, l2.flip(0))
+
+
+def test_sliding_window_front_end(eng):
+    audio = synth.make_audio(11, 2, 136000)
+    cfg = MelConfig.sliding_window()                      # n_fft 512, hop 532, reflect, dB without affine
+    got = eng.mel_extract(cfg, dev(audio), out_frames=255).cpu().numpy()
+    want = np.stack([omel.mel_sliding_window(a) for a in audio])
+    assert got.shape == want.shape == (2, 255, 80)
+    d = np.abs(got - want)
+    assert d.max() < 0.04 and d.mean() < 2e-3, (d.max(), d.mean())      # dB units
+
+
+def test_sliding_window_front_end_model_config(eng):
+    # as built by the model: n_fft 1024, hop 533 (simplified_dual_stream_model.py:122-131)
+    audio = synth.make_audio(12, 2, 136000)
+    cfg = MelConfig.sliding_window(n_fft=1024, hop_length=533)
+    got = eng.mel_extract(cfg, dev(audio), out_frames=255).cpu().numpy()
+    want = np.stack([omel.mel_sliding_window(a, n_fft=1024, hop=533) for a in audio])
+    d = np.abs(got - want)
+    assert d.max() < 0.04 and d.mean() < 2e-3, (d.max(), d.mean())
+
+
+def test_torchaudio_front_end(eng):
+    audio = synth.make_audio(13, 2, 136000)
+    cfg = MelConfig.torchaudio()
+    got = eng.mel_extract(cfg, dev(audio), out_frames=255).cpu().numpy()
+    want = omel.mel_torchaudio(audio)
+    assert got.shape == want.shape == (2, 255, 80)
+    # natural-log units; the eps=1e-8 floor makes the very quiet bins ill-conditioned, so compare exp()
+    np.testing.assert_allclose(np.exp(got), np.exp(want), rtol=2e-3, atol=2e-8)
+    # pad-with-last-frame policy (stft.py:136-140): ask for more rows than the STFT produces
+    got2 = eng.mel_extract(cfg, dev(audio), out_frames=260).cpu().numpy()
+    assert np.array_equal(got2[:, 256:], np.repeat(got2[:, 255:256], 4, axis=1))
+
+
+def test_end_to_end_from_audio(eng):
+    """audio -> 52 coefficients, three consecutive calls with the EMA state (contract: 1e-4 abs)."""
+    params = synth.make_core_params(7, style="trained")
+    orc = models.SimplifiedOracle(params)
+    state = torch.zeros(4, 52, device="cuda")
+    for i in range(3):
+        audio = synth.make_audio(20 + i, 4, 136448)
+        emo = synth.normal(30 + i, (4, 256))
+        want = orc.forward(audio, emo)["blendshapes"]
+        got = eng.forward_audio(dev(audio), dev(emo), state=state, first=(i == 0)).cpu().numpy()
+        err = np.abs(got - want).max()
+        assert err < 1e-4, err
+        assert err < 5e-6, err
