@@ -80,6 +80,7 @@ int km_reserve(km_handle h, int64_t max_windows, int64_t max_samples) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_mel), (size_t)W * F * max_mels * sizeof(float)));
     }
     c->ws_windows = W; c->ws_frames = F; c->ws_samples = S;
+    c->melmax_dirty = true;
     return KM_OK;
 }
 
@@ -178,9 +179,9 @@ int km_forward_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L, 
         return fail(KM_ERR_WORKSPACE, "workspace too small for %lld windows x %lld samples: call km_reserve",
                     (long long)B, (long long)L);
     if (int rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, stream)) return rc;
-    if (int rc = launch_mel(c, c->mel_plans[0], audio_dev, B, L, 0, c->ws_mel, c->ws_short, stream)) return rc;
-    return launch_core_fused(c, c->ws_mel, B, n_frames, c->ws_short, c->ws_zemo, out_dev, nullptr, nullptr,
-                             state_dev, first, stream);
+    // three launches: emotion logits, power-mel + window maxima, fused core (dB conversion on load)
+    if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, L, stream)) return rc;
+    return launch_core_fused_db(c, c->mel_plans[0], B, n_frames, c->ws_zemo, out_dev, state_dev, first, stream);
 }
 
 int64_t km_sequence_num_outputs(km_handle h, int64_t L, int32_t stride_frames) {

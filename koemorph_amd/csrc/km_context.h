@@ -70,6 +70,7 @@ struct Context {
     float* ws_mel = nullptr;       // (windows, frames, 80) log-mel
     float* ws_short = nullptr;     // (windows, 3, 80)
     int64_t ws_frames = 0;
+    bool melmax_dirty = true;      // ws_melmax may hold stale maxima (see launch_mel_power)
 };
 
 void set_error(const char* fmt, ...);
@@ -85,9 +86,13 @@ int launch_emotion(Context* c, const float* emo, int64_t B, float* zemo, void* s
 int launch_core_fused(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short,
                       const float* zemo, float* out, float* raw, float* attn, float* state, int first,
                       void* stream);
+// fused variant: reads the workspace power-mel + window maxima, applies the log/dB conversion on load
+int launch_core_fused_db(Context* c, MelPlan* p, int64_t B, int64_t n_frames, const float* zemo, float* out,
+                         float* state, int first, void* stream);
 int launch_smooth(Context* c, float* x, float* state, int64_t B, int first, void* stream);
 
 // km_mel.hip
+int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, void* stream);
 int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, int64_t out_frames,
                float* mel_long, float* mel_short, void* stream);
 int upload_mel_plan(MelPlan* p);

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include "km_context.h"
+#include "km_device.h"
 
 namespace km {
 
@@ -63,13 +64,18 @@ struct CoreArgs {
     float* state;  // (B, 52) EMA state or null
     int first;
     float alpha;
+    // FUSE_DB variant: the front end's power-mel is converted to log-mel while it is staged into LDS
+    const float* melpow;  // (B, n_frames, 80) power-mel
+    unsigned* melmax;     // (B) window maxima (float bits); the entry is re-zeroed for the next call
+    int n_frames;
+    LogParams lp;
 };
 
 // blendshape index -> mouth query slot (MOUTH_INDICES = 14..40, 51; dual_stream_attention.py:14-45)
 // or -1 for the 24 expression rows
 __device__ __forceinline__ int mouth_slot_of(int i) { return (i >= 14 && i <= 40) ? i - 14 : (i == 51 ? 27 : -1); }
 
-template <bool ATTN>
+template <bool ATTN, bool FUSE_DB>
 __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
     using namespace fused;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -83,7 +89,37 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
     const int g = lane >> 4, j = lane & 15;
 
     // ---- phase 0: X -> LDS, [t][c] exactly as the caller's (t_in, 80) rows --------------------
-    {
+    if constexpr (FUSE_DB) {
+        // rows come from the power-mel workspace; dB / log conversion on the fly (bit-identical to
+        // mel_log_kernel: same log_one()), long rows = first min(F, T) frames, short rows = last 3 frames
+        // (simplified_dual_stream_model.py:199-214)
+        float ref_db, floor_db;
+        log_window_consts(a.lp, __uint_as_float(a.melmax[b]), ref_db, floor_db);
+        const int F = a.n_frames;
+        const int tv = F < T ? F : T;
+        const float4* src = reinterpret_cast<const float4*>(a.melpow + (int64_t)b * F * NK);
+        float4* dst = reinterpret_cast<float4*>(R1);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < tv * 20; i += NT) {
+            const float4 v = src[i];
+            dst[i] = make_float4(log_one(a.lp, v.x, ref_db, floor_db), log_one(a.lp, v.y, ref_db, floor_db),
+                                 log_one(a.lp, v.z, ref_db, floor_db), log_one(a.lp, v.w, ref_db, floor_db));
+        }
+        for (int i = tv * 20 + tid; i < T * 20; i += NT) dst[i] = z4;
+        if (tid < 60) {
+            const int r = tid / 20;
+            float4 v = z4;
+            int fr = -1;
+            if (F >= 3) fr = F - 3 + r; else if (r < F) fr = r;
+            if (fr >= 0) {
+                const float4 u = src[fr * 20 + (tid - r * 20)];
+                v = make_float4(log_one(a.lp, u.x, ref_db, floor_db), log_one(a.lp, u.y, ref_db, floor_db),
+                                log_one(a.lp, u.z, ref_db, floor_db), log_one(a.lp, u.w, ref_db, floor_db));
+            }
+            dst[T * 20 + tid] = v;
+        }
+        if (tid >= 64 && tid < 64 + (KTP - KT) * 20) dst[KT * 20 + tid - 64] = z4;
+    } else {
         const int tv = a.t_in < T ? a.t_in : T;   // rows beyond T are truncated (:200-202)
         const float4* src = reinterpret_cast<const float4*>(a.mel + (int64_t)b * a.t_in * NK);
         float4* dst = reinterpret_cast<float4*>(R1);
@@ -95,6 +131,9 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
         if (tid >= 64 && tid < 64 + (KTP - KT) * 20) dst[KT * 20 + tid - 64] = z4;          // k padding rows
     }
     __syncthreads();
+    if constexpr (FUSE_DB) {
+        if (tid == 0) a.melmax[b] = 0u;     // every thread has read it: hand a clean slot to the next front-end launch
+    }
 
     // ---- phase 1: channel encoder GEMM -----------------------------------------------------
     f32x4 acc[5][2];
@@ -352,45 +391,72 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Emotion stream: z_e[b] = w2 . relu(LN(Wee emo + bee) We2 + be2) + b2   (one scalar per window: the
 // 24 expression queries all attend to the single eGeMAPS token, dual_stream_attention.py:234-240).
-// 0.5 MFLOP / window, plain VALU; 8 windows per workgroup so the two weight matrices are read once
-// per 8 windows from L2.  Generic in (ED, d, DH).
+// 0.2 MFLOP / window after folding; the kernel is LATENCY bound (two dependent weight sweeps), so it
+// is built for memory-level parallelism: 1024 threads per 4 windows, the contraction index split 4-way
+// (layer 1) / 8-way (layer 2) across thread groups with 16 independent coalesced loads in flight per
+// thread, partial sums combined through LDS in a fixed order (deterministic).  Generic in (ED, d, DH).
 // ---------------------------------------------------------------------------------------------
-constexpr int EWPB = 8;
+constexpr int EWPB = 4;      // windows per workgroup
+constexpr int ENT = 1024;    // threads per workgroup
+constexpr int EKQ1 = 4;      // k-split of layer 1 (256 output columns x 4)
+constexpr int EKQ2 = 8;      // k-split of layer 2 (128 output columns x 8)
 
-__global__ __launch_bounds__(256) void emotion_kernel(const float* __restrict__ emo, int64_t B, int ED, int d, int DH,
-                                                      const float* __restrict__ wee_t, const float* __restrict__ bee,
-                                                      const float* __restrict__ lg, const float* __restrict__ lb,
-                                                      const float* __restrict__ we2, const float* __restrict__ be2,
-                                                      const float* __restrict__ w2, const float* __restrict__ b2,
-                                                      float* __restrict__ zemo) {
+__global__ __launch_bounds__(1024) void emotion_kernel(const float* __restrict__ emo, int64_t B, int ED, int d, int DH,
+                                                       const float* __restrict__ wee_t, const float* __restrict__ bee,
+                                                       const float* __restrict__ lg, const float* __restrict__ lb,
+                                                       const float* __restrict__ we2, const float* __restrict__ be2,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       float* __restrict__ zemo) {
     extern __shared__ __attribute__((aligned(16))) float es[];
-    float* emo_s = es;                   // [EWPB][ED]
-    float* e1 = emo_s + EWPB * ED;       // [EWPB][d]
-    float* hp = e1 + EWPB * d;           // [EWPB][DH]
+    float* emo_s = es;                        // [EWPB][ED]
+    float* e1 = emo_s + EWPB * ED;            // [EWPB][d]
+    float* part = e1 + EWPB * d;              // [max(EKQ1*EWPB*d, EKQ2*EWPB*DH)]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t b0 = (int64_t)blockIdx.x * EWPB;
     const int nb = (int)((B - b0) < EWPB ? (B - b0) : EWPB);
-    for (int i = tid; i < EWPB * ED; i += 256) {
+    for (int i = tid; i < EWPB * ED; i += ENT) {
         const int w = i / ED;
         emo_s[i] = w < nb ? emo[b0 * ED + i] : 0.f;
     }
     __syncthreads();
-    for (int n = tid; n < d; n += 256) {
-        float acc[EWPB];
-        const float bv = bee[n];
+    {   // layer 1 partial sums: thread (column n, k-quarter kq)
+        const int kq = tid >> 8, kchunk = (ED + EKQ1 - 1) / EKQ1;
+        const int k0 = kq * kchunk, k1 = (k0 + kchunk) < ED ? (k0 + kchunk) : ED;
+        for (int n = tid & 255; n < d; n += 256) {
+            float acc[EWPB];
 #pragma unroll
-        for (int w = 0; w < EWPB; ++w) acc[w] = bv;
-        for (int k = 0; k < ED; ++k) {
-            const float wv = wee_t[(size_t)k * d + n];
+            for (int w = 0; w < EWPB; ++w) acc[w] = 0.f;
+            const float* wp = wee_t + n;
+            int k = k0;
+            for (; k + 16 <= k1; k += 16) {       // 16 independent coalesced loads in flight, then the FMAs
+                float wv[16];
 #pragma unroll
-            for (int w = 0; w < EWPB; ++w) acc[w] = fmaf(emo_s[w * ED + k], wv, acc[w]);
+                for (int u = 0; u < 16; ++u) wv[u] = wp[(size_t)(k + u) * d];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+#pragma unroll
+                    for (int w = 0; w < EWPB; ++w) acc[w] = fmaf(emo_s[w * ED + k + u], wv[u], acc[w]);
+            }
+            for (; k < k1; ++k) {
+                const float wv = wp[(size_t)k * d];
+#pragma unroll
+                for (int w = 0; w < EWPB; ++w) acc[w] = fmaf(emo_s[w * ED + k], wv, acc[w]);
+            }
+#pragma unroll
+            for (int w = 0; w < EWPB; ++w) part[(kq * EWPB + w) * d + n] = acc[w];
         }
-#pragma unroll
-        for (int w = 0; w < EWPB; ++w) e1[w * d + n] = acc[w];
     }
     __syncthreads();
-    // LayerNorm per window, wave `wave` handles windows wave and wave+4
-    for (int w = wave; w < EWPB; w += 4) {
+    for (int i = tid; i < EWPB * d; i += ENT) {
+        const int w = i / d, n = i - w * d;
+        float s = bee[n];
+#pragma unroll
+        for (int kq = 0; kq < EKQ1; ++kq) s += part[(kq * EWPB + w) * d + n];
+        e1[i] = s;
+    }
+    __syncthreads();
+    if (wave < EWPB) {   // LayerNorm (eps 1e-5), one wave per window, two-pass
+        const int w = wave;
         float s = 0.f;
         for (int n = lane; n < d; n += 64) s += e1[w * d + n];
 #pragma unroll
@@ -404,24 +470,43 @@ __global__ __launch_bounds__(256) void emotion_kernel(const float* __restrict__ 
         for (int n = lane; n < d; n += 64) e1[w * d + n] = (e1[w * d + n] - mean) * rstd * lg[n] + lb[n];
     }
     __syncthreads();
-    for (int m = tid; m < DH; m += 256) {
-        float acc[EWPB];
-        const float bv = be2[m];
+    {   // layer 2 partial sums: thread (hidden unit m, k-eighth kq)
+        const int kq = tid >> 7, kchunk = (d + EKQ2 - 1) / EKQ2;
+        const int k0 = kq * kchunk, k1 = (k0 + kchunk) < d ? (k0 + kchunk) : d;
+        for (int m = tid & 127; m < DH; m += 128) {
+            float acc[EWPB];
 #pragma unroll
-        for (int w = 0; w < EWPB; ++w) acc[w] = bv;
-        for (int n = 0; n < d; ++n) {
-            const float wv = we2[(size_t)n * DH + m];
+            for (int w = 0; w < EWPB; ++w) acc[w] = 0.f;
+            const float* wp = we2 + m;
+            int n = k0;
+            for (; n + 16 <= k1; n += 16) {
+                float wv[16];
 #pragma unroll
-            for (int w = 0; w < EWPB; ++w) acc[w] = fmaf(e1[w * d + n], wv, acc[w]);
+                for (int u = 0; u < 16; ++u) wv[u] = wp[(size_t)(n + u) * DH];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+#pragma unroll
+                    for (int w = 0; w < EWPB; ++w) acc[w] = fmaf(e1[w * d + n + u], wv[u], acc[w]);
+            }
+            for (; n < k1; ++n) {
+                const float wv = wp[(size_t)n * DH];
+#pragma unroll
+                for (int w = 0; w < EWPB; ++w) acc[w] = fmaf(e1[w * d + n], wv, acc[w]);
+            }
+#pragma unroll
+            for (int w = 0; w < EWPB; ++w) part[(kq * EWPB + w) * DH + m] = acc[w];
         }
-        const float w2v = w2[m];
-#pragma unroll
-        for (int w = 0; w < EWPB; ++w) hp[w * DH + m] = fmaxf(acc[w], 0.f) * w2v;
     }
     __syncthreads();
-    for (int w = wave; w < EWPB; w += 4) {
+    if (wave < EWPB) {   // ReLU, dot with w2, one wave per window
+        const int w = wave;
         float s = 0.f;
-        for (int m = lane; m < DH; m += 64) s += hp[w * DH + m];
+        for (int m = lane; m < DH; m += 64) {
+            float h = be2[m];
+#pragma unroll
+            for (int kq = 0; kq < EKQ2; ++kq) h += part[(kq * EWPB + w) * DH + m];
+            s += fmaxf(h, 0.f) * w2[m];
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0 && w < nb) zemo[b0 + w] = s + b2[0];
@@ -443,7 +528,8 @@ __global__ void smooth_kernel(float* __restrict__ x, float* __restrict__ state, 
 static const float* dv(Context* c, const char* name) { return c->packed.at(name).dev; }
 
 int launch_emotion(Context* c, const float* emo, int64_t B, float* zemo, void* stream) {
-    const size_t lds = (size_t)EWPB * (c->ED + c->d + c->DH) * sizeof(float);
+    const size_t p1 = (size_t)EKQ1 * EWPB * c->d, p2 = (size_t)EKQ2 * EWPB * c->DH;
+    const size_t lds = ((size_t)EWPB * (c->ED + c->d) + (p1 > p2 ? p1 : p2)) * sizeof(float);
     if (lds > 160 * 1024) return fail(KM_ERR_UNSUPPORTED, "emotion_dim/d_model too large for the emotion kernel");
     static bool attr_set = false;
     if (!attr_set) {
@@ -452,34 +538,61 @@ int launch_emotion(Context* c, const float* emo, int64_t B, float* zemo, void* s
         attr_set = true;
     }
     const unsigned grid = (unsigned)((B + EWPB - 1) / EWPB);
-    hipLaunchKernelGGL(emotion_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, emo, B, c->ED, c->d, c->DH,
+    hipLaunchKernelGGL(emotion_kernel, dim3(grid), dim3(ENT), lds, (hipStream_t)stream, emo, B, c->ED, c->d, c->DH,
                        dv(c, "wee_t"), dv(c, "bee"), dv(c, "eln_g"), dv(c, "eln_b"), dv(c, "we2"), dv(c, "be2"),
                        dv(c, "w2"), dv(c, "b2"), zemo);
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }
 
-int launch_core_fused(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short,
-                      const float* zemo, float* out, float* raw, float* attn, float* state, int first,
-                      void* stream) {
+static int core_attrs() {
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&core_fused_kernel<false>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&core_fused_kernel<false, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, fused::LDS_BYTES));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&core_fused_kernel<true>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&core_fused_kernel<true, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, fused::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&core_fused_kernel<false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, fused::LDS_BYTES));
         attr_set = true;
     }
-    CoreArgs a;
-    a.mel = mel; a.mel_short = mel_short; a.zemo = zemo; a.t_in = (int)T_in;
+    return KM_OK;
+}
+
+static void core_weights(Context* c, CoreArgs& a) {
     a.wce_p = dv(c, "wce_p"); a.bce = dv(c, "bce"); a.ln_g = dv(c, "ln_g"); a.ln_b = dv(c, "ln_b");
     a.qk_p = dv(c, "qk_p"); a.wv_p = dv(c, "wv_p"); a.wf_p = dv(c, "wf_p"); a.bf = dv(c, "bf");
     a.w2 = dv(c, "w2"); a.b2 = dv(c, "b2"); a.wsum = dv(c, "wsum");
-    a.out = out; a.raw = raw; a.attn = attn; a.state = state; a.first = first; a.alpha = c->alpha;
+    a.alpha = c->alpha;
+}
+
+int launch_core_fused(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short,
+                      const float* zemo, float* out, float* raw, float* attn, float* state, int first,
+                      void* stream) {
+    if (int rc = core_attrs()) return rc;
+    CoreArgs a{};
+    core_weights(c, a);
+    a.mel = mel; a.mel_short = mel_short; a.zemo = zemo; a.t_in = (int)T_in;
+    a.out = out; a.raw = raw; a.attn = attn; a.state = state; a.first = first;
     if (attn)
-        hipLaunchKernelGGL(core_fused_kernel<true>, dim3((unsigned)B), dim3(fused::NT), fused::LDS_BYTES, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((core_fused_kernel<true, false>), dim3((unsigned)B), dim3(fused::NT), fused::LDS_BYTES, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(core_fused_kernel<false>, dim3((unsigned)B), dim3(fused::NT), fused::LDS_BYTES, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((core_fused_kernel<false, false>), dim3((unsigned)B), dim3(fused::NT), fused::LDS_BYTES, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+LogParams plan_log_params(MelPlan* p);
+
+int launch_core_fused_db(Context* c, MelPlan* p, int64_t B, int64_t n_frames, const float* zemo, float* out,
+                         float* state, int first, void* stream) {
+    if (int rc = core_attrs()) return rc;
+    CoreArgs a{};
+    core_weights(c, a);
+    a.zemo = zemo; a.t_in = (int)n_frames;
+    a.out = out; a.state = state; a.first = first;
+    a.melpow = c->ws_melpow; a.melmax = c->ws_melmax; a.n_frames = (int)n_frames; a.lp = plan_log_params(p);
+    hipLaunchKernelGGL((core_fused_kernel<false, true>), dim3((unsigned)B), dim3(fused::NT), fused::LDS_BYTES, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }

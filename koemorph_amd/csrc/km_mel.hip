@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include "km_context.h"
+#include "km_device.h"
 
 namespace km {
 
@@ -100,9 +101,46 @@ struct MelArgs {
     const int* fb_count;
     const int* fb_offset;
     const float* fb_weight;
+    int fb_nnz;           // number of stored filter weights
     float* melpow;        // (B, n_frames, n_mels)
     unsigned* melmax;     // (B) float bits, zero-initialised
 };
+
+// raw samples of the frame pair (fa, fa+1) into z[i] = (x_a[lane + 64 i], x_b[lane + 64 i]); wave-uniform fa
+template <int NFFT>
+__device__ __forceinline__ void load_pair(const MelArgs& a, const float* __restrict__ x, int fa, int lane,
+                                          float2 (&z)[NFFT / 64]) {
+    constexpr int R0 = NFFT / 64;
+    if (fa >= a.n_frames) {
+#pragma unroll
+        for (int i = 0; i < R0; ++i) z[i] = make_float2(0.f, 0.f);
+        return;
+    }
+    const int64_t p0 = (int64_t)fa * a.hop - NFFT / 2;
+    const bool have_b = fa + 1 < a.n_frames;
+    if (p0 >= 0 && p0 + a.hop + NFFT <= a.L && have_b) {      // interior pair: no padding, 32-bit offsets
+        const float* xa = x + p0 + lane;
+        const float* xb = xa + a.hop;
+#pragma unroll
+        for (int i = 0; i < R0; ++i) z[i] = make_float2(xa[64 * i], xb[64 * i]);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < R0; ++i) {
+        int64_t qa = p0 + lane + 64 * i, qb = qa + a.hop;
+        float va, vb;
+        if (a.pad_mode == KM_PAD_REFLECT) {                    // np.pad(mode='reflect')
+            qa = qa < 0 ? -qa : (qa >= a.L ? 2 * (a.L - 1) - qa : qa);
+            qb = qb < 0 ? -qb : (qb >= a.L ? 2 * (a.L - 1) - qb : qb);
+            va = x[qa];
+            vb = have_b ? x[qb] : 0.f;
+        } else {                                               // zero padding
+            va = (qa >= 0 && qa < a.L) ? x[qa] : 0.f;
+            vb = (have_b && qb >= 0 && qb < a.L) ? x[qb] : 0.f;
+        }
+        z[i] = make_float2(va, vb);
+    }
+}
 
 template <int NFFT>
 __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
@@ -110,19 +148,28 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
     constexpr int R0 = NFFT / 64;          // 16 or 8
     constexpr int G = R0 / 8;              // radix-8 groups per lane in passes 2 and 3
     constexpr int LOG_R0 = R0 == 16 ? 4 : 3;
-    constexpr int NF = NFFT / 2 + 1;       // bins; odd => conflict-free [frame][bin] image for lanes = frames
+    constexpr int NFS = NFFT / 2 + 2;      // power row stride: 2 mod 32 dwords (see the mel stage)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float2* fbuf = reinterpret_cast<float2*>(smem);                     // [WAVES][FFT_BUF]
-    float* pw = smem + WAVES * FFT_BUF * 2;                              // [FPB][NF]
-    float* outs = pw + FPB * NF;                                         // [FPB][n_mels]
-    float* redmax = outs + FPB * 128;                                    // [WAVES]
+    float* pw = smem + WAVES * FFT_BUF * 2;                              // [FPB][NFS]
+    float* outs = pw + FPB * NFS;                                        // [FPB][n_mels]
+    float* redmax = outs + FPB * a.n_mels;                               // [WAVES]
+    int* fbs = reinterpret_cast<int*>(redmax + WAVES);                   // [n_mels] first bin
+    int* fbc = fbs + a.n_mels;                                           // [n_mels] tap count
+    int* fbo = fbc + a.n_mels;                                           // [n_mels] offset into fbw
+    float* fbw = reinterpret_cast<float*>(fbo + a.n_mels);               // [fb_nnz] triangle weights
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
-    const int f0 = blockIdx.x * FPB;
     const float* x = a.audio + (int64_t)b * a.L;
     float2* buf = fbuf + wave * FFT_BUF;
+    const int n_chunks = (a.n_frames + FPB - 1) / FPB;
+
+    // the sparse filterbank lives in LDS for the lifetime of the (persistent) workgroup; first use is
+    // behind the chunk loop's first __syncthreads()
+    for (int i = tid; i < a.n_mels; i += 256) { fbs[i] = a.fb_start[i]; fbc[i] = a.fb_count[i]; fbo[i] = a.fb_offset[i]; }
+    for (int i = tid; i < a.fb_nnz; i += 256) fbw[i] = a.fb_weight[i];
 
     // lane-constant operands, hoisted out of the frame loop
     float win[R0];
@@ -137,109 +184,114 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) tw2[i] = a.twiddle[(R0 * n2 * bitrev(i, 3)) & (NFFT - 1)];
 
-    for (int p = wave; p < FPB / 2; p += WAVES) {
-        const int fa = f0 + 2 * p, fb = fa + 1;
-        if (fa < a.n_frames) {   // wave-uniform
+    float vmax = 0.f;
+    float2 zn[R0];                          // software prefetch: raw samples of the NEXT pair of this wave
+    int chunk = blockIdx.x;
+    load_pair<NFFT>(a, x, chunk * FPB + 2 * wave, lane, zn);
+    for (; chunk < n_chunks; chunk += gridDim.x) {
+        const int f0 = chunk * FPB;
+#pragma unroll 1
+        for (int pi = 0; pi < FPB / 2 / WAVES; ++pi) {
+            const int p = wave + WAVES * pi;
+            const int fa = f0 + 2 * p;
             float2 z[R0];
-            // ---- load + window: z = frame_a + i frame_b, sample n = lane + 64 i --------------------
-            const int64_t pa = (int64_t)fa * a.hop - NFFT / 2 + lane;
-            const int64_t pb = pa + a.hop;
-            const bool have_b = fb < a.n_frames;
 #pragma unroll
-            for (int i = 0; i < R0; ++i) {
-                int64_t qa = pa + 64 * i, qb = pb + 64 * i;
-                float va, vb;
-                if (a.pad_mode == KM_PAD_REFLECT) {                    // np.pad(mode='reflect')
-                    qa = qa < 0 ? -qa : (qa >= a.L ? 2 * (a.L - 1) - qa : qa);
-                    qb = qb < 0 ? -qb : (qb >= a.L ? 2 * (a.L - 1) - qb : qb);
-                    va = x[qa];
-                    vb = have_b ? x[qb] : 0.f;
-                } else {                                               // zero padding
-                    va = (qa >= 0 && qa < a.L) ? x[qa] : 0.f;
-                    vb = (have_b && qb >= 0 && qb < a.L) ? x[qb] : 0.f;
+            for (int i = 0; i < R0; ++i) z[i] = make_float2(zn[i].x * win[i], zn[i].y * win[i]);
+            {   // issue the next pair's loads now; they complete under this pair's FFT
+                const int fn = (pi + 1 < FPB / 2 / WAVES) ? fa + 2 * WAVES
+                                                          : (chunk + (int)gridDim.x) * FPB + 2 * wave;
+                load_pair<NFFT>(a, x, (pi + 1 < FPB / 2 / WAVES || chunk + (int)gridDim.x < n_chunks) ? fn : a.n_frames,
+                                lane, zn);
+            }
+            if (fa < a.n_frames) {   // wave-uniform
+                // ---- pass 1: radix-R0 over n0 (n = 64 n0 + m, m = lane) ---------------------------------
+                dif_fft<R0>(z);
+#pragma unroll
+                for (int i = 0; i < R0; ++i) {
+                    const int k0 = bitrev(i, LOG_R0);
+                    buf[k0 * 72 + lane] = k0 == 0 ? z[i] : cmul(z[i], tw1[i]);
                 }
-                z[i] = make_float2(va * win[i], vb * win[i]);
-            }
-            // ---- pass 1: radix-R0 over n0 (n = 64 n0 + m, m = lane) ---------------------------------
-            dif_fft<R0>(z);
+                __builtin_amdgcn_wave_barrier();
+                // ---- pass 2: radix-8 over n1 (m = 8 n1 + n2); this lane: n2 = lane&7, k0 = (lane>>3) + 8u ----
+                float2 y[G][8];
 #pragma unroll
-            for (int i = 0; i < R0; ++i) {
-                const int k0 = bitrev(i, LOG_R0);
-                buf[k0 * 72 + lane] = k0 == 0 ? z[i] : cmul(z[i], tw1[i]);
-            }
-            __builtin_amdgcn_wave_barrier();
-            // ---- pass 2: radix-8 over n1 (m = 8 n1 + n2); this lane: n2 = lane&7, k0 = (lane>>3) + 8u ----
-            float2 y[G][8];
+                for (int u = 0; u < G; ++u) {
 #pragma unroll
-            for (int u = 0; u < G; ++u) {
-#pragma unroll
-                for (int n1 = 0; n1 < 8; ++n1) y[u][n1] = buf[(k0l + 8 * u) * 72 + 8 * n1 + n2];
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int u = 0; u < G; ++u) {
-                dif_fft<8>(y[u]);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int k1 = bitrev(i, 3);
-                    // transposed image indexed by c = k0 + R0 k1 (row stride 9)
-                    buf[(k0l + 8 * u + R0 * k1) * 9 + n2] = k1 == 0 ? y[u][i] : cmul(y[u][i], tw2[i]);
+                    for (int n1 = 0; n1 < 8; ++n1) y[u][n1] = buf[(k0l + 8 * u) * 72 + 8 * n1 + n2];
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // ---- pass 3: radix-8 over n2; this lane: c = lane + 64 v; output k = c + 8 R0 k2 ---------
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int v = 0; v < G; ++v) {
+                for (int u = 0; u < G; ++u) {
+                    dif_fft<8>(y[u]);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) y[v][q] = buf[(lane + 64 * v) * 9 + q];
-            }
-            __builtin_amdgcn_wave_barrier();
+                    for (int i = 0; i < 8; ++i) {
+                        const int k1 = bitrev(i, 3);
+                        // transposed image indexed by c = k0 + R0 k1 (row stride 9)
+                        buf[(k0l + 8 * u + R0 * k1) * 9 + n2] = k1 == 0 ? y[u][i] : cmul(y[u][i], tw2[i]);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---- pass 3: radix-8 over n2; this lane: c = lane + 64 v; output k = c + 8 R0 k2 ---------
 #pragma unroll
-            for (int v = 0; v < G; ++v) {
-                dif_fft<8>(y[v]);
+                for (int v = 0; v < G; ++v) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) buf[lane + 64 * v + 8 * R0 * bitrev(i, 3)] = y[v][i];
-            }
-            __builtin_amdgcn_wave_barrier();
-            // ---- separate the two real spectra, |.|^2 ----------------------------------------------
-            // A[k] = (Z[k] + conj Z[N-k]) / 2,  B[k] = (Z[k] - conj Z[N-k]) / 2i
-            float* pwa = pw + (2 * p) * NF;
-            float* pwb = pwa + NF;
+                    for (int q = 0; q < 8; ++q) y[v][q] = buf[(lane + 64 * v) * 9 + q];
+                }
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int i = 0; i <= NFFT / 128; ++i) {
-                const int k = lane + 64 * i;
-                if (k <= NFFT / 2) {
-                    const float2 zk = buf[k], zn = buf[(NFFT - k) & (NFFT - 1)];
-                    const float ar = zk.x + zn.x, ai = zk.y - zn.y, br = zk.y + zn.y, bi = zk.x - zn.x;
-                    pwa[k] = 0.25f * (ar * ar + ai * ai);
-                    pwb[k] = 0.25f * (br * br + bi * bi);
+                for (int v = 0; v < G; ++v) {
+                    dif_fft<8>(y[v]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) buf[lane + 64 * v + 8 * R0 * bitrev(i, 3)] = y[v][i];
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---- separate the two real spectra, |.|^2 ----------------------------------------------
+                // A[k] = (Z[k] + conj Z[N-k]) / 2,  B[k] = (Z[k] - conj Z[N-k]) / 2i
+                float* pwa = pw + (2 * p) * NFS;
+                float* pwb = pwa + NFS;
+#pragma unroll
+                for (int i = 0; i <= NFFT / 128; ++i) {
+                    const int k = lane + 64 * i;
+                    if (k <= NFFT / 2) {
+                        const float2 zk = buf[k], zc = buf[(NFFT - k) & (NFFT - 1)];
+                        const float ar = zk.x + zc.x, ai = zk.y - zc.y, br = zk.y + zc.y, bi = zk.x - zc.x;
+                        pwa[k] = 0.25f * (ar * ar + ai * ai);
+                        pwb[k] = 0.25f * (br * br + bi * bi);
+                    }
                 }
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // ---- sparse triangular mel filters: lanes = frames (16 per filter), conflict-free reads --------
-    float vmax = 0.f;
-    const int fl = tid & 15;
-    const bool fvalid = f0 + fl < a.n_frames;
-    for (int m = tid >> 4; m < a.n_mels; m += 16) {
-        const int st = a.fb_start[m], cnt = a.fb_count[m];
-        const float* wt = a.fb_weight + a.fb_offset[m];
-        const float* pr = pw + fl * NF + st;
-        float acc = 0.f;
-        if (fvalid)
-            for (int i = 0; i < cnt; ++i) acc = fmaf(pr[i], wt[i], acc);
-        outs[fl * a.n_mels + m] = acc;
-        vmax = fmaxf(vmax, acc);
+        // ---- sparse triangular mel filters: 16 lanes = 16 frames of one filter, the two 16-lane groups of
+        // a half-wave take the even / odd taps of the SAME filter; with a row stride of 2 (mod 32) dwords the
+        // 32 lanes of every ds_read_b32 hit 32 distinct banks.
+        {
+            const int fl = tid & 15, par = (tid >> 4) & 1;
+            const bool fvalid = f0 + fl < a.n_frames;
+            for (int m = tid >> 5; m < a.n_mels; m += 8) {
+                const int st = fbs[m], cnt = fbc[m];
+                const float* wt = fbw + fbo[m];
+                const float* pr = pw + fl * NFS + st;
+                float acc = 0.f;
+                if (fvalid) {
+#pragma unroll 4
+                    for (int i = par; i < cnt; i += 2) acc = fmaf(pr[i], wt[i], acc);
+                }
+                acc += __shfl_xor(acc, 16);
+                if (par == 0) outs[fl * a.n_mels + m] = acc;
+                vmax = fmaxf(vmax, acc);
+            }
+        }
+        __syncthreads();
+        const int nf_here = (a.n_frames - f0) < FPB ? (a.n_frames - f0) : FPB;
+        float* dst = a.melpow + ((int64_t)b * a.n_frames + f0) * a.n_mels;
+        for (int i = tid; i < nf_here * a.n_mels; i += 256) dst[i] = outs[i];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
     if (lane == 0) redmax[wave] = vmax;
     __syncthreads();
-    const int nf_here = (a.n_frames - f0) < FPB ? (a.n_frames - f0) : FPB;
-    float* dst = a.melpow + ((int64_t)b * a.n_frames + f0) * a.n_mels;
-    for (int i = tid; i < nf_here * a.n_mels; i += 256) dst[i] = outs[i];
     if (tid == 0) {
         const float mx = fmaxf(fmaxf(redmax[0], redmax[1]), fmaxf(redmax[2], redmax[3]));
         atomicMax(a.melmax + b, __float_as_uint(mx));
@@ -250,25 +302,15 @@ struct LogArgs {
     const float* melpow;     // (B, n_frames, n_mels)
     const unsigned* melmax;  // (B)
     int n_frames, out_frames, n_mels;
-    int log_mode;
-    float amin, top_db, db_add, db_scale, log_eps;
+    LogParams lp;
     float* mel_long;         // (B, out_frames, n_mels)
     float* mel_short;        // (B, 3, n_mels) or null: last three COMPUTED frames
 };
 
-__device__ __forceinline__ float log_one(const LogArgs& a, float s, float ref_db, float floor_db) {
-    if (a.log_mode == KM_LOG_LN_EPS) return logf(s + a.log_eps);
-    float v = 10.0f * log10f(fmaxf(a.amin, s)) - ref_db;   // librosa.power_to_db
-    v = fmaxf(v, floor_db);
-    return (v + a.db_add) * a.db_scale;
-}
-
 __global__ __launch_bounds__(256) void mel_log_kernel(LogArgs a) {
     const int b = blockIdx.y;
-    const float ref = __uint_as_float(a.melmax[b]);
-    const float ref_db = 10.0f * log10f(fmaxf(a.amin, ref));
-    // log_spec.max() - top_db: the maximum of the window is its reference, so max_db = f(ref) - ref_db
-    const float floor_db = (10.0f * log10f(fmaxf(a.amin, ref)) - ref_db) - a.top_db;
+    float ref_db, floor_db;
+    log_window_consts(a.lp, __uint_as_float(a.melmax[b]), ref_db, floor_db);
     const float* src = a.melpow + (int64_t)b * a.n_frames * a.n_mels;
     const int total = a.out_frames * a.n_mels;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -276,15 +318,15 @@ __global__ __launch_bounds__(256) void mel_log_kernel(LogArgs a) {
         int f = i / a.n_mels;
         const int m = i - f * a.n_mels;
         if (f >= a.n_frames) f = a.n_frames - 1;            // repeat the last frame (stft.py:136-140)
-        a.mel_long[(int64_t)b * total + i] = log_one(a, src[f * a.n_mels + m], ref_db, floor_db);
+        a.mel_long[(int64_t)b * total + i] = log_one(a.lp, src[f * a.n_mels + m], ref_db, floor_db);
     }
     if (a.mel_short && blockIdx.x == 0) {
         for (int s = threadIdx.x; s < 3 * a.n_mels; s += 256) {
             const int r = s / a.n_mels, m = s - r * a.n_mels;
             float v = 0.f;
             // simplified_dual_stream_model.py:206-214: last 3 frames; fewer than 3 -> first rows, zero rest
-            if (a.n_frames >= 3) v = log_one(a, src[(a.n_frames - 3 + r) * a.n_mels + m], ref_db, floor_db);
-            else if (r < a.n_frames) v = log_one(a, src[r * a.n_mels + m], ref_db, floor_db);
+            if (a.n_frames >= 3) v = log_one(a.lp, src[(a.n_frames - 3 + r) * a.n_mels + m], ref_db, floor_db);
+            else if (r < a.n_frames) v = log_one(a.lp, src[r * a.n_mels + m], ref_db, floor_db);
             a.mel_short[(int64_t)b * 3 * a.n_mels + s] = v;
         }
     }
@@ -318,12 +360,21 @@ void free_mel_plan(MelPlan* p) {
     delete p;
 }
 
-static size_t mel_lds_bytes(int nfft) {
-    return (size_t)(mel::WAVES * mel::FFT_BUF * 2 + mel::FPB * (nfft / 2 + 1) + mel::FPB * 128 + mel::WAVES) * sizeof(float);
+static size_t mel_lds_bytes(int nfft, int n_mels = 128, int nnz = 0) {
+    if (nnz == 0) nnz = 2 * (nfft / 2 + 1) + 128;    // upper bound: every bin feeds at most two triangles
+    return (size_t)(mel::WAVES * mel::FFT_BUF * 2 + mel::FPB * (nfft / 2 + 2) + mel::FPB * n_mels + mel::WAVES +
+                    3 * n_mels + nnz) * sizeof(float);
 }
 
-int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, int64_t out_frames,
-               float* mel_long, float* mel_short, void* stream) {
+static LogParams log_params(const km_mel_config& m) {
+    LogParams lp;
+    lp.log_mode = m.log_mode; lp.amin = m.amin; lp.top_db = m.top_db; lp.db_add = m.db_add;
+    lp.db_scale = m.db_scale; lp.log_eps = m.log_eps;
+    return lp;
+}
+
+// power-mel (B, n_frames, n_mels) + per-window max into the workspace
+int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, void* stream) {
     const km_mel_config& m = p->cfg;
     const int64_t n_frames = 1 + L / m.hop_length;
     if (m.pad_mode == KM_PAD_REFLECT && L <= m.n_fft / 2)
@@ -341,29 +392,51 @@ int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L,
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(c->ws_melmax, 0, (size_t)B * sizeof(unsigned), st));
+    // ws_melmax is all-zero on entry unless a previous non-fused call left its maxima behind
+    // (the fused core kernel re-zeroes the entry it consumes)
+    if (c->melmax_dirty) {
+        HIP_TRY(hipMemsetAsync(c->ws_melmax, 0, (size_t)c->ws_windows * sizeof(unsigned), st));
+        c->melmax_dirty = false;
+    }
     MelArgs a;
     a.audio = audio; a.L = L; a.n_frames = (int)n_frames; a.hop = m.hop_length; a.pad_mode = m.pad_mode;
     a.n_mels = m.n_mels; a.window = p->d_window; a.twiddle = reinterpret_cast<const float2*>(p->d_twiddle);
     a.fb_start = p->d_fb_start; a.fb_count = p->d_fb_count; a.fb_offset = p->d_fb_offset; a.fb_weight = p->d_fb_weight;
+    a.fb_nnz = (int)p->fb_weight.size();
     a.melpow = c->ws_melpow; a.melmax = c->ws_melmax;
-    const dim3 grid((unsigned)((n_frames + mel::FPB - 1) / mel::FPB), (unsigned)B);
+    // persistent over frame chunks: each workgroup walks chunks blockIdx.x, +gridDim.x, ... of its window with the
+    // next pair's samples prefetched; two workgroups are resident per CU (LDS), so aim at 512 in total
+    const int n_chunks = (int)((n_frames + mel::FPB - 1) / mel::FPB);
+    int per_window = (int)((512 + B / 2) / B);
+    if (per_window > n_chunks) per_window = n_chunks;
+    if (per_window < 1) per_window = 1;
+    const dim3 grid((unsigned)per_window, (unsigned)B);
     if (m.n_fft == 1024)
-        hipLaunchKernelGGL(mel_power_kernel<1024>, grid, dim3(256), mel_lds_bytes(1024), st, a);
+        hipLaunchKernelGGL(mel_power_kernel<1024>, grid, dim3(256), mel_lds_bytes(1024, m.n_mels, a.fb_nnz), st, a);
     else
-        hipLaunchKernelGGL(mel_power_kernel<512>, grid, dim3(256), mel_lds_bytes(512), st, a);
+        hipLaunchKernelGGL(mel_power_kernel<512>, grid, dim3(256), mel_lds_bytes(512, m.n_mels, a.fb_nnz), st, a);
     HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, int64_t out_frames,
+               float* mel_long, float* mel_short, void* stream) {
+    if (int rc = launch_mel_power(c, p, audio, B, L, stream)) return rc;
+    const km_mel_config& m = p->cfg;
+    const int64_t n_frames = 1 + L / m.hop_length;
+    c->melmax_dirty = true;     // mel_log_kernel leaves the maxima in place
     LogArgs g;
     g.melpow = c->ws_melpow; g.melmax = c->ws_melmax; g.n_frames = (int)n_frames;
-    g.out_frames = (int)(out_frames > 0 ? out_frames : n_frames); g.n_mels = m.n_mels; g.log_mode = m.log_mode;
-    g.amin = m.amin; g.top_db = m.top_db; g.db_add = m.db_add; g.db_scale = m.db_scale; g.log_eps = m.log_eps;
+    g.out_frames = (int)(out_frames > 0 ? out_frames : n_frames); g.n_mels = m.n_mels; g.lp = log_params(m);
     g.mel_long = mel_long; g.mel_short = mel_short;
     const dim3 grid2((unsigned)((g.out_frames * m.n_mels + 255) / 256), (unsigned)B);
     if (grid2.x > 0) {
-        hipLaunchKernelGGL(mel_log_kernel, grid2, dim3(256), 0, st, g);
+        hipLaunchKernelGGL(mel_log_kernel, grid2, dim3(256), 0, (hipStream_t)stream, g);
         HIP_TRY(hipGetLastError());
     }
     return KM_OK;
 }
+
+LogParams plan_log_params(MelPlan* p) { return log_params(p->cfg); }
 
 }  // namespace km

@@ -109,3 +109,23 @@ def test_end_to_end_from_audio(eng):
         err = np.abs(got - want).max()
         assert err < 1e-4, err
         assert err < 5e-6, err
+
+
+def test_fused_pipeline_is_bit_identical_to_staged_pipeline(eng):
+    """km_forward_audio (dB conversion fused into the core kernel's load, window maxima recycled in place)
+    must equal km_mel_batch -> km_core_forward bit for bit, also when the two are interleaved."""
+    audio = dev(synth.make_audio(41, 5, 136448))
+    emo = dev(synth.normal(42, (5, 256)))
+    for _ in range(2):
+        fused = eng.forward_audio(audio, emo)
+        long, short = eng.mel_batch(audio)                  # leaves the window maxima behind (dirty path)
+        staged = eng.core_forward(long, short, emo)["blendshapes"]
+        assert torch.equal(fused, staged)
+        fused2 = eng.forward_audio(audio, emo)              # must re-zero the maxima before reuse
+        assert torch.equal(fused2, fused)
+    # short clips (fewer than T frames, fewer than 3 frames)
+    for L in (5000, 700):
+        a = dev(synth.make_audio(43, 3, L))
+        e3 = dev(synth.normal(44, (3, 256)))
+        long, short = eng.mel_batch(a)
+        assert torch.equal(eng.forward_audio(a, e3), eng.core_forward(long, short, e3)["blendshapes"])
