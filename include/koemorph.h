@@ -176,8 +176,8 @@ int km_forward_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L,
  * (src/model/sequential_dual_stream_model.py:63-167): slides a mel_sequence_length-frame
  * window with stride_frames over each clip, one output frame per position, EMA reset at the
  * clip start.  audio_dev (B, L) -> out_dev (B, N, 52), N = km_sequence_num_outputs().
- * The STFT of the clip is computed once; only the two zero-padded edge frames of every window
- * are recomputed (the reference recomputes all 257). */
+ * Windows are addressed in place inside the clip (no (B*N, window) copy is materialised) and processed
+ * in tiles of the reserved workspace size; every window's STFT is recomputed, as the reference does. */
 int64_t km_sequence_num_outputs(km_handle h, int64_t L, int32_t stride_frames);
 int km_sequence_forward(km_handle h, const float* audio_dev, int64_t B, int64_t L,
                         const float* emotion_dev, int32_t stride_frames, int32_t smooth,

@@ -194,9 +194,32 @@ int64_t km_sequence_num_outputs(km_handle h, int64_t L, int32_t stride_frames) {
 
 int km_sequence_forward(km_handle h, const float* audio_dev, int64_t B, int64_t L, const float* emotion_dev,
                         int32_t stride_frames, int32_t smooth, float* out_dev, void* stream) {
-    (void)audio_dev; (void)B; (void)L; (void)emotion_dev; (void)stride_frames; (void)smooth; (void)out_dev; (void)stream;
     if (int rc = need_ready(h)) return rc;
-    return fail(KM_ERR_UNSUPPORTED, "km_sequence_forward: not built yet");
+    Context* c = h;
+    if (!audio_dev || !emotion_dev || !out_dev || B <= 0 || L <= 0 || stride_frames <= 0)
+        return fail(KM_ERR_INVALID_ARG, "km_sequence_forward: bad argument");
+    if (!c->fused_ok)
+        return fail(KM_ERR_UNSUPPORTED, "no kernel for d_model=%d, mel_sequence_length=%d, heads=%d", c->d, c->T, c->H);
+    const int hop = c->cfg.mel.hop_length;
+    const int64_t N = km_sequence_num_outputs(h, L, stride_frames);
+    const int64_t W = (int64_t)c->T * hop;                 // window_samples (sequential_dual_stream_model.py:54)
+    const int64_t step = (int64_t)stride_frames * hop;     // stride_samples (:55)
+    const int64_t n_frames = 1 + W / hop;
+    if (c->ws_windows < B || c->ws_windows < 1 || n_frames > c->ws_frames)
+        return fail(KM_ERR_WORKSPACE, "workspace too small for %lld clips / %lld-frame windows: call km_reserve",
+                    (long long)B, (long long)n_frames);
+    if (N > 0x7fffffff) return fail(KM_ERR_INVALID_ARG, "too many output frames");
+    // emotion features ONCE for the entire audio (:88): one logit per clip
+    if (int rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, stream)) return rc;
+    const int64_t total = B * N, tile = c->ws_windows;
+    for (int64_t w0 = 0; w0 < total; w0 += tile) {
+        const int64_t nw = (total - w0) < tile ? (total - w0) : tile;
+        if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, nw, W, stream, L, step, w0, (int)N)) return rc;
+        if (int rc = launch_core_fused_db(c, c->mel_plans[0], nw, n_frames, c->ws_zemo, out_dev + w0 * c->NB, nullptr, 1,
+                                          stream, w0, (int)N)) return rc;
+    }
+    if (smooth) return launch_ema_scan(c, out_dev, B, N, stream);
+    return KM_OK;
 }
 
 }  // extern "C"

@@ -88,11 +88,13 @@ int launch_core_fused(Context* c, const float* mel, int64_t B, int64_t T_in, con
                       void* stream);
 // fused variant: reads the workspace power-mel + window maxima, applies the log/dB conversion on load
 int launch_core_fused_db(Context* c, MelPlan* p, int64_t B, int64_t n_frames, const float* zemo, float* out,
-                         float* state, int first, void* stream);
+                         float* state, int first, void* stream, int64_t win0 = 0, int zemo_div = 1);
+int launch_ema_scan(Context* c, float* x, int64_t B, int64_t N, void* stream);
 int launch_smooth(Context* c, float* x, float* state, int64_t B, int first, void* stream);
 
 // km_mel.hip
-int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, void* stream);
+int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, void* stream,
+                     int64_t clip_len = 0, int64_t win_step = 0, int64_t win0 = 0, int wins_per_clip = 1);
 int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, int64_t out_frames,
                float* mel_long, float* mel_short, void* stream);
 int upload_mel_plan(MelPlan* p);

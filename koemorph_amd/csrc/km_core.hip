@@ -69,6 +69,9 @@ struct CoreArgs {
     unsigned* melmax;     // (B) window maxima (float bits); the entry is re-zeroed for the next call
     int n_frames;
     LogParams lp;
+    // sequence mode: one emotion logit per clip, shared by its windows: zemo[(win0 + b) / zemo_div]
+    int64_t win0;
+    int zemo_div;
 };
 
 // blendshape index -> mouth query slot (MOUTH_INDICES = 14..40, 51; dual_stream_attention.py:14-45)
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) z += R2[w * 32 + slot];
         } else {
-            z = a.zemo[b];
+            z = a.zemo[(a.win0 + b) / a.zemo_div];
         }
         const float bs = 1.0f / (1.0f + expf(-z));                      // nn.Sigmoid (:155)
         float val = fminf(fmaxf(a.wsum[tid] * bs, 0.f), 1.f);           // stream weights + clamp (:264-270)
@@ -513,6 +516,120 @@ __global__ __launch_bounds__(1024) void emotion_kernel(const float* __restrict__
     }
 }
 
+// Production shape (emotion_dim <= 256, d_model 256): every weight this thread will ever need is requested
+// before the first use -- 64 + 32 independent coalesced loads in flight per thread -- because the weights are
+// L2-cold on every step (the front end streams 140 MB through the L2s in between) and the kernel is pure
+// memory latency: one round trip instead of six dependent ones.
+__global__ __launch_bounds__(1024) void emotion_kernel_d256(const float* __restrict__ emo, int64_t B, int ED,
+                                                            const float* __restrict__ wee_t, const float* __restrict__ bee,
+                                                            const float* __restrict__ lg, const float* __restrict__ lb,
+                                                            const float* __restrict__ we2, const float* __restrict__ be2,
+                                                            const float* __restrict__ w2, const float* __restrict__ b2,
+                                                            float* __restrict__ zemo) {
+    constexpr int d = 256, DH = 128, EDP = 256;
+    __shared__ __attribute__((aligned(16))) float emo_s[EWPB * EDP];
+    __shared__ __attribute__((aligned(16))) float e1[EWPB * d];
+    __shared__ __attribute__((aligned(16))) float part[EKQ1 * EWPB * d];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t b0 = (int64_t)blockIdx.x * EWPB;
+    const int nb = (int)((B - b0) < EWPB ? (B - b0) : EWPB);
+    const int n = tid & 255, kq = tid >> 8;      // layer 1: column n, k in [64 kq, 64 kq + 64)
+    const int m = tid & 127, kq2 = tid >> 7;     // layer 2: hidden unit m, n in [32 kq2, 32 kq2 + 32)
+    float w1[64], w2r[32];
+#pragma unroll
+    for (int u = 0; u < 64; ++u) {
+        const int k = 64 * kq + u;
+        w1[u] = k < ED ? wee_t[(size_t)k * d + n] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) w2r[u] = we2[(size_t)(32 * kq2 + u) * DH + m];
+    for (int i = tid; i < EWPB * EDP; i += ENT) {
+        const int w = i >> 8, k = i & 255;
+        emo_s[i] = (w < nb && k < ED) ? emo[(b0 + w) * ED + k] : 0.f;
+    }
+    __syncthreads();
+    {
+        float acc[EWPB];
+#pragma unroll
+        for (int w = 0; w < EWPB; ++w) acc[w] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 64; u += 4)
+#pragma unroll
+            for (int w = 0; w < EWPB; ++w) {
+                const float4 e = *reinterpret_cast<const float4*>(emo_s + w * EDP + 64 * kq + u);
+                acc[w] = fmaf(e.x, w1[u], acc[w]);
+                acc[w] = fmaf(e.y, w1[u + 1], acc[w]);
+                acc[w] = fmaf(e.z, w1[u + 2], acc[w]);
+                acc[w] = fmaf(e.w, w1[u + 3], acc[w]);
+            }
+#pragma unroll
+        for (int w = 0; w < EWPB; ++w) part[(kq * EWPB + w) * d + n] = acc[w];
+    }
+    __syncthreads();
+    {
+        const int w = tid >> 8;                   // EWPB * d == ENT: one element per thread
+        float s = bee[n];
+#pragma unroll
+        for (int q = 0; q < EKQ1; ++q) s += part[(q * EWPB + w) * d + n];
+        e1[tid] = s;
+    }
+    __syncthreads();
+    if (wave < EWPB) {   // LayerNorm (eps 1e-5), one wave per window, two-pass
+        const int w = wave;
+        float x[4], s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = e1[w * d + lane + 64 * i]; s += x[i]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * (1.0f / d);
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float t = x[i] - mean; v += t * t; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        const float rstd = 1.0f / sqrtf(v * (1.0f / d) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            e1[w * d + c] = (x[i] - mean) * rstd * lg[c] + lb[c];
+        }
+    }
+    __syncthreads();
+    {
+        float acc[EWPB];
+#pragma unroll
+        for (int w = 0; w < EWPB; ++w) acc[w] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 32; u += 4)
+#pragma unroll
+            for (int w = 0; w < EWPB; ++w) {
+                const float4 e = *reinterpret_cast<const float4*>(e1 + w * d + 32 * kq2 + u);
+                acc[w] = fmaf(e.x, w2r[u], acc[w]);
+                acc[w] = fmaf(e.y, w2r[u + 1], acc[w]);
+                acc[w] = fmaf(e.z, w2r[u + 2], acc[w]);
+                acc[w] = fmaf(e.w, w2r[u + 3], acc[w]);
+            }
+#pragma unroll
+        for (int w = 0; w < EWPB; ++w) part[(kq2 * EWPB + w) * DH + m] = acc[w];
+    }
+    __syncthreads();
+    if (wave < EWPB) {   // ReLU, dot with w2, one wave per window
+        const int w = wave;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mm = lane + 64 * i;
+            float h = be2[mm];
+#pragma unroll
+            for (int q = 0; q < EKQ2; ++q) h += part[(q * EWPB + w) * DH + mm];
+            s += fmaxf(h, 0.f) * w2[mm];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0 && w < nb) zemo[b0 + w] = s + b2[0];
+    }
+}
+
 __global__ void smooth_kernel(float* __restrict__ x, float* __restrict__ state, int64_t n, int first, float alpha) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -538,6 +655,13 @@ int launch_emotion(Context* c, const float* emo, int64_t B, float* zemo, void* s
         attr_set = true;
     }
     const unsigned grid = (unsigned)((B + EWPB - 1) / EWPB);
+    if (c->d == 256 && c->DH == 128 && c->ED <= 256) {
+        hipLaunchKernelGGL(emotion_kernel_d256, dim3(grid), dim3(ENT), 0, (hipStream_t)stream, emo, B, c->ED,
+                           dv(c, "wee_t"), dv(c, "bee"), dv(c, "eln_g"), dv(c, "eln_b"), dv(c, "we2"), dv(c, "be2"),
+                           dv(c, "w2"), dv(c, "b2"), zemo);
+        HIP_TRY(hipGetLastError());
+        return KM_OK;
+    }
     hipLaunchKernelGGL(emotion_kernel, dim3(grid), dim3(ENT), lds, (hipStream_t)stream, emo, B, c->ED, c->d, c->DH,
                        dv(c, "wee_t"), dv(c, "bee"), dv(c, "eln_g"), dv(c, "eln_b"), dv(c, "we2"), dv(c, "be2"),
                        dv(c, "w2"), dv(c, "b2"), zemo);
@@ -573,7 +697,7 @@ int launch_core_fused(Context* c, const float* mel, int64_t B, int64_t T_in, con
     CoreArgs a{};
     core_weights(c, a);
     a.mel = mel; a.mel_short = mel_short; a.zemo = zemo; a.t_in = (int)T_in;
-    a.out = out; a.raw = raw; a.attn = attn; a.state = state; a.first = first;
+    a.out = out; a.raw = raw; a.attn = attn; a.state = state; a.first = first; a.win0 = 0; a.zemo_div = 1;
     if (attn)
         hipLaunchKernelGGL((core_fused_kernel<true, false>), dim3((unsigned)B), dim3(fused::NT), fused::LDS_BYTES, (hipStream_t)stream, a);
     else
@@ -585,14 +709,39 @@ int launch_core_fused(Context* c, const float* mel, int64_t B, int64_t T_in, con
 LogParams plan_log_params(MelPlan* p);
 
 int launch_core_fused_db(Context* c, MelPlan* p, int64_t B, int64_t n_frames, const float* zemo, float* out,
-                         float* state, int first, void* stream) {
+                         float* state, int first, void* stream, int64_t win0, int zemo_div) {
     if (int rc = core_attrs()) return rc;
     CoreArgs a{};
     core_weights(c, a);
     a.zemo = zemo; a.t_in = (int)n_frames;
-    a.out = out; a.state = state; a.first = first;
+    a.out = out; a.state = state; a.first = first; a.win0 = win0; a.zemo_div = zemo_div > 0 ? zemo_div : 1;
     a.melpow = c->ws_melpow; a.melmax = c->ws_melmax; a.n_frames = (int)n_frames; a.lp = plan_log_params(p);
     hipLaunchKernelGGL((core_fused_kernel<false, true>), dim3((unsigned)B), dim3(fused::NT), fused::LDS_BYTES, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+// EMA along the frame axis of (B, N, 52), state reset at the start of every clip
+// (sequential_dual_stream_model.py:99,136 + simplified_dual_stream_model.py:357-366).  First-order linear
+// recurrence: one thread per (clip, coefficient) walks the N frames.
+__global__ void ema_scan_kernel(float* __restrict__ x, int64_t B, int64_t N, int nb, float alpha) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * nb) return;
+    const int64_t b = i / nb;
+    const int cidx = (int)(i - b * nb);
+    float* p = x + b * N * nb + cidx;
+    float prev = p[0];                                   // first call returns its input unchanged
+    for (int64_t t = 1; t < N; ++t) {
+        const float v = alpha * p[t * nb] + (1.0f - alpha) * prev;
+        p[t * nb] = v;
+        prev = v;
+    }
+}
+
+int launch_ema_scan(Context* c, float* x, int64_t B, int64_t N, void* stream) {
+    const int64_t n = B * c->NB;
+    hipLaunchKernelGGL(ema_scan_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream, x, B, N,
+                       c->NB, c->alpha);
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }

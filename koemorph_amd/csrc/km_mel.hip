@@ -89,8 +89,14 @@ __device__ __forceinline__ void dif_fft(float2 (&v)[R]) {
 }
 
 struct MelArgs {
-    const float* audio;   // (B, L)
-    int64_t L;
+    const float* audio;   // (B, L)  -- or (clips, clip_len) in sequence mode
+    int64_t L;            // samples per window (zero padded past the end of the clip)
+    // sequence mode (SequentialDualStreamModel, sequential_dual_stream_model.py:101-117): window w of the launch
+    // is global window g = win0 + w, clip g / wins_per_clip, offset (g % wins_per_clip) * win_step in that clip;
+    // a plain batch is wins_per_clip = 1, clip_len = L, win_step = 0
+    int64_t clip_len, win_step;
+    int64_t win0;
+    int wins_per_clip;
     int n_frames;         // frames computed per window = 1 + L / hop
     int hop;
     int pad_mode;
@@ -108,7 +114,7 @@ struct MelArgs {
 
 // raw samples of the frame pair (fa, fa+1) into z[i] = (x_a[lane + 64 i], x_b[lane + 64 i]); wave-uniform fa
 template <int NFFT>
-__device__ __forceinline__ void load_pair(const MelArgs& a, const float* __restrict__ x, int fa, int lane,
+__device__ __forceinline__ void load_pair(const MelArgs& a, const float* __restrict__ x, int64_t Lv, int fa, int lane,
                                           float2 (&z)[NFFT / 64]) {
     constexpr int R0 = NFFT / 64;
     if (fa >= a.n_frames) {
@@ -118,7 +124,7 @@ __device__ __forceinline__ void load_pair(const MelArgs& a, const float* __restr
     }
     const int64_t p0 = (int64_t)fa * a.hop - NFFT / 2;
     const bool have_b = fa + 1 < a.n_frames;
-    if (p0 >= 0 && p0 + a.hop + NFFT <= a.L && have_b) {      // interior pair: no padding, 32-bit offsets
+    if (p0 >= 0 && p0 + a.hop + NFFT <= Lv && have_b) {      // interior pair: no padding, 32-bit offsets
         const float* xa = x + p0 + lane;
         const float* xb = xa + a.hop;
 #pragma unroll
@@ -130,13 +136,13 @@ __device__ __forceinline__ void load_pair(const MelArgs& a, const float* __restr
         int64_t qa = p0 + lane + 64 * i, qb = qa + a.hop;
         float va, vb;
         if (a.pad_mode == KM_PAD_REFLECT) {                    // np.pad(mode='reflect')
-            qa = qa < 0 ? -qa : (qa >= a.L ? 2 * (a.L - 1) - qa : qa);
-            qb = qb < 0 ? -qb : (qb >= a.L ? 2 * (a.L - 1) - qb : qb);
+            qa = qa < 0 ? -qa : (qa >= Lv ? 2 * (Lv - 1) - qa : qa);
+            qb = qb < 0 ? -qb : (qb >= Lv ? 2 * (Lv - 1) - qb : qb);
             va = x[qa];
             vb = have_b ? x[qb] : 0.f;
         } else {                                               // zero padding
-            va = (qa >= 0 && qa < a.L) ? x[qa] : 0.f;
-            vb = (have_b && qb >= 0 && qb < a.L) ? x[qb] : 0.f;
+            va = (qa >= 0 && qa < Lv) ? x[qa] : 0.f;
+            vb = (have_b && qb >= 0 && qb < Lv) ? x[qb] : 0.f;
         }
         z[i] = make_float2(va, vb);
     }
@@ -162,7 +168,10 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
-    const float* x = a.audio + (int64_t)b * a.L;
+    const int64_t gw = a.win0 + b;
+    const int64_t clip = gw / a.wins_per_clip, woff = (gw - clip * a.wins_per_clip) * a.win_step;
+    const float* x = a.audio + clip * a.clip_len + woff;
+    const int64_t Lv = (a.clip_len - woff) < a.L ? (a.clip_len - woff) : a.L;   // samples that exist; the rest reads as zero
     float2* buf = fbuf + wave * FFT_BUF;
     const int n_chunks = (a.n_frames + FPB - 1) / FPB;
 
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
     float vmax = 0.f;
     float2 zn[R0];                          // software prefetch: raw samples of the NEXT pair of this wave
     int chunk = blockIdx.x;
-    load_pair<NFFT>(a, x, chunk * FPB + 2 * wave, lane, zn);
+    load_pair<NFFT>(a, x, Lv, chunk * FPB + 2 * wave, lane, zn);
     for (; chunk < n_chunks; chunk += gridDim.x) {
         const int f0 = chunk * FPB;
 #pragma unroll 1
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
             {   // issue the next pair's loads now; they complete under this pair's FFT
                 const int fn = (pi + 1 < FPB / 2 / WAVES) ? fa + 2 * WAVES
                                                           : (chunk + (int)gridDim.x) * FPB + 2 * wave;
-                load_pair<NFFT>(a, x, (pi + 1 < FPB / 2 / WAVES || chunk + (int)gridDim.x < n_chunks) ? fn : a.n_frames,
+                load_pair<NFFT>(a, x, Lv, (pi + 1 < FPB / 2 / WAVES || chunk + (int)gridDim.x < n_chunks) ? fn : a.n_frames,
                                 lane, zn);
             }
             if (fa < a.n_frames) {   // wave-uniform
@@ -226,8 +235,10 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int k1 = bitrev(i, 3);
-                        // transposed image indexed by c = k0 + R0 k1 (row stride 9)
-                        buf[(k0l + 8 * u + R0 * k1) * 9 + n2] = k1 == 0 ? y[u][i] : cmul(y[u][i], tw2[i]);
+                        // transposed image indexed by c = k0 + R0 k1: row of 8, column XOR-swizzled by (c>>2)&7 so
+                        // that both this write (16-lane groups) and the pass-3 read (32-lane halves) are conflict free
+                        const int c = k0l + 8 * u + R0 * k1;
+                        buf[c * 8 + (n2 ^ ((c >> 2) & 7))] = k1 == 0 ? y[u][i] : cmul(y[u][i], tw2[i]);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -235,7 +246,10 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
 #pragma unroll
                 for (int v = 0; v < G; ++v) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) y[v][q] = buf[(lane + 64 * v) * 9 + q];
+                    for (int q = 0; q < 8; ++q) {
+                        const int c = lane + 64 * v;
+                        y[v][q] = buf[c * 8 + (q ^ ((c >> 2) & 7))];
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -374,7 +388,8 @@ static LogParams log_params(const km_mel_config& m) {
 }
 
 // power-mel (B, n_frames, n_mels) + per-window max into the workspace
-int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, void* stream) {
+int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, void* stream,
+                     int64_t clip_len, int64_t win_step, int64_t win0, int wins_per_clip) {
     const km_mel_config& m = p->cfg;
     const int64_t n_frames = 1 + L / m.hop_length;
     if (m.pad_mode == KM_PAD_REFLECT && L <= m.n_fft / 2)
@@ -399,7 +414,8 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
         c->melmax_dirty = false;
     }
     MelArgs a;
-    a.audio = audio; a.L = L; a.n_frames = (int)n_frames; a.hop = m.hop_length; a.pad_mode = m.pad_mode;
+    a.audio = audio; a.L = L; a.clip_len = clip_len > 0 ? clip_len : L; a.win_step = win_step; a.win0 = win0;
+    a.wins_per_clip = wins_per_clip > 0 ? wins_per_clip : 1; a.n_frames = (int)n_frames; a.hop = m.hop_length; a.pad_mode = m.pad_mode;
     a.n_mels = m.n_mels; a.window = p->d_window; a.twiddle = reinterpret_cast<const float2*>(p->d_twiddle);
     a.fb_start = p->d_fb_start; a.fb_count = p->d_fb_count; a.fb_offset = p->d_fb_offset; a.fb_weight = p->d_fb_weight;
     a.fb_nnz = (int)p->fb_weight.size();
@@ -421,7 +437,7 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
 
 int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, int64_t out_frames,
                float* mel_long, float* mel_short, void* stream) {
-    if (int rc = launch_mel_power(c, p, audio, B, L, stream)) return rc;
+    if (int rc = launch_mel_power(c, p, audio, B, L, stream, 0, 0, 0, 1)) return rc;
     const km_mel_config& m = p->cfg;
     const int64_t n_frames = 1 + L / m.hop_length;
     c->melmax_dirty = true;     // mel_log_kernel leaves the maxima in place

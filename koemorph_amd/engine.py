@@ -118,9 +118,11 @@ class Engine:
     def load_param(self, key: str, value) -> None:
         if hasattr(value, "detach"):
             value = value.detach().cpu().numpy()
-        a = np.ascontiguousarray(np.asarray(value), dtype=np.float32)
-        shape = (C.c_int64 * max(1, a.ndim))(*a.shape)
-        check(self._lib.km_load_param(self._h, key.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+        a = np.asarray(value, dtype=np.float32)
+        ndim, dims = a.ndim, a.shape                     # ascontiguousarray would promote a 0-d scalar to 1-d
+        a = np.ascontiguousarray(a)
+        shape = (C.c_int64 * max(1, ndim))(*dims)
+        check(self._lib.km_load_param(self._h, key.encode(), a.ctypes.data_as(C.c_void_p), shape, ndim))
 
     def load_state_dict(self, state: Mapping[str, object]) -> None:
         for k, v in state.items():
@@ -267,6 +269,21 @@ class Engine:
         with torch.cuda.device(audio.device):
             check(self._lib.km_forward_audio(self._h, _ptr(audio), B, L, _ptr(emotion), _ptr(out), _ptr(state),
                                              1 if first else 0, _stream_ptr(audio.device)))
+        return out
+
+    def sequence_forward(self, audio, emotion, stride_frames: int = 1, smooth: bool = True, max_tile: int = 2048):
+        """audio (B, L) -> (B, N, 52): one frame per window position (km_sequence_forward)."""
+        torch = _torch()
+        audio = self._chk(audio, "audio", 2)
+        emotion = self._chk(emotion, "emotion_features", 2)
+        B, L = audio.shape
+        N = self.sequence_num_outputs(L, stride_frames)
+        W = self.mel_sequence_length * self.mel.hop_length
+        self.reserve(max(B, min(B * N, max_tile)), W)
+        out = torch.empty(B, N, self.num_blendshapes, device=audio.device, dtype=torch.float32)
+        with torch.cuda.device(audio.device):
+            check(self._lib.km_sequence_forward(self._h, _ptr(audio), B, L, _ptr(emotion), stride_frames,
+                                                1 if smooth else 0, _ptr(out), _stream_ptr(audio.device)))
         return out
 
     def sequence_num_outputs(self, L: int, stride_frames: int = 1) -> int:

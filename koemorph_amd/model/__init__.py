@@ -1,0 +1,8 @@
+"""Host-side mirrors of the reference's ``src/model`` hot-path modules."""
+from .dual_stream_attention import (DualStreamCrossAttention, MOUTH_INDICES, EXPRESSION_INDICES,
+                                    ARKIT_BLENDSHAPES, MOUTH_BLENDSHAPES)
+from .simplified_dual_stream_model import SimplifiedDualStreamModel
+from .sequential_dual_stream_model import SequentialDualStreamModel
+
+__all__ = ["DualStreamCrossAttention", "SimplifiedDualStreamModel", "SequentialDualStreamModel",
+           "MOUTH_INDICES", "EXPRESSION_INDICES", "ARKIT_BLENDSHAPES", "MOUTH_BLENDSHAPES"]

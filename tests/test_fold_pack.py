@@ -219,3 +219,10 @@ def test_lane_level_model_of_fused_kernel():
     np.testing.assert_allclose(z, ref["_z"][b, MOUTH].numpy(), atol=2e-5)
     bs = 1 / (1 + np.exp(-z))
     np.testing.assert_allclose(np.clip(wsum[MOUTH] * bs, 0, 1), g["blendshapes"][b, MOUTH], atol=3e-7)
+
+
+def test_scalar_parameter_roundtrip():
+    e = Engine()
+    e.load_param("smoothing_alpha", np.float32(0.25))
+    e.load_param("smoothing_alpha", __import__("torch").tensor(0.5))
+    assert float(e.get_param("smoothing_alpha", ())) == 0.5

@@ -1,0 +1,179 @@
+"""GPU parity of the reference-interface mirrors (torch.nn.Module classes and the rt.py loop) against the
+oracle and the reference's golden outputs.  Everything computes through the C-ABI."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_case
+from koemorph_amd import synth
+from koemorph_amd.features import MelSlidingWindowExtractor, MelSpectrogramExtractor
+from koemorph_amd.model import (DualStreamCrossAttention, SequentialDualStreamModel, SimplifiedDualStreamModel,
+                                EXPRESSION_INDICES, MOUTH_INDICES)
+from koemorph_amd.scripts import rt
+from oracle import mel as omel, models
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def full_state(params, alpha=0.8):
+    sd = {"dual_stream_attention." + k: torch.from_numpy(v) for k, v in params.items()}
+    sd["smoothing_alpha"] = torch.tensor(alpha)
+    return sd
+
+
+def test_module_forward_matches_reference_golden():
+    c, params, (mel, short, emo), g = golden_case("core_d256_T256_H8_trained")
+    m = DualStreamCrossAttention().cuda().eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    o = m(dev(mel), dev(short), dev(emo), return_attention=True)
+    assert set(o) == {"blendshapes", "mel_attention_weights", "emotion_attention_weights", "mel_blendshapes",
+                      "emotion_blendshapes"}
+    for k in o:
+        np.testing.assert_allclose(o[k].cpu().numpy(), g[k], atol=2e-5 if "_blendshapes" in k else 2e-6)
+    # weights changed in place -> the engine re-folds them
+    with torch.no_grad():
+        m.mel_weights.add_(1.0)
+    o2 = m(dev(mel), dev(short), dev(emo))["blendshapes"]
+    assert not torch.equal(o2, o["blendshapes"])
+    with pytest.raises(RuntimeError, match="eval"):
+        m.train()(dev(mel), dev(short), dev(emo))
+
+
+def test_simplified_model_forward_and_smoothing():
+    params = synth.make_core_params(51, style="trained")
+    m = SimplifiedDualStreamModel().cuda().eval()
+    m.load_state_dict(full_state(params, 0.3))
+    orc = models.SimplifiedOracle(params, smoothing_alpha=0.3)
+    for i in range(3):
+        audio = synth.make_audio(60 + i, 3, 136448)
+        emo = synth.normal(70 + i, (3, 256))
+        want = orc.forward(audio, emo)["blendshapes"]
+        got = m(dev(audio), emotion_features=dev(emo))["blendshapes"].cpu().numpy()
+        assert np.abs(got - want).max() < 5e-6
+    # attention path goes through the staged kernels and the stand-alone smoothing kernel
+    m.reset_temporal_state(); orc.reset_temporal_state()
+    audio = synth.make_audio(80, 2, 136448); emo = synth.normal(81, (2, 256))
+    o = m(dev(audio), return_attention=True, emotion_features=dev(emo))
+    w = orc.forward(audio, emo, return_attention=True)
+    assert np.abs(o["blendshapes"].cpu().numpy() - w["blendshapes"]).max() < 5e-6
+    assert np.abs(o["mel_attention_weights"].cpu().numpy() - w["mel_attention_weights"]).max() < 5e-6
+    # provider hook, and the reference's dummy-feature fallback when there is none
+    m.emotion_provider = lambda a: dev(emo)
+    m.reset_temporal_state()
+    via_provider = m(dev(audio))["blendshapes"]
+    m.reset_temporal_state()
+    assert torch.equal(via_provider, m(dev(audio), emotion_features=dev(emo))["blendshapes"])
+    m.emotion_provider = None
+    assert m(dev(audio))["blendshapes"].shape == (2, 52)
+    long, short = m.extract_mel_features(dev(audio))
+    assert long.shape == (2, 257, 80) and short.shape == (2, 3, 80)
+
+
+@pytest.mark.parametrize("extra_hops,stride", [(5, 1), (9, 2), (-40, 1)])
+def test_sequential_model_matches_oracle(extra_hops, stride):
+    params = synth.make_core_params(52, style="trained")
+    L = 136448 + 533 * extra_hops + 100               # not a multiple of the hop: exercises the tail logic
+    audio = synth.make_audio(90, 2, L)
+    emo = synth.normal(91, (2, 256))
+    m = SequentialDualStreamModel(stride_frames=stride).cuda().eval()
+    m.load_state_dict(full_state(params))
+    orc = models.SequentialOracle(params, stride_frames=stride)
+    want = orc.forward(audio, emo)
+    got = m(dev(audio), emotion_features=dev(emo))
+    assert got["num_frames"] == want["num_frames"] == got["blendshapes"].shape[1]
+    assert got["fps"] == 30
+    assert np.abs(got["blendshapes"].cpu().numpy() - want["blendshapes"]).max() < 5e-6
+    if extra_hops == 5:
+        ga = m(dev(audio), return_attention=True, emotion_features=dev(emo))
+        assert torch.allclose(ga["blendshapes"], got["blendshapes"], atol=1e-6)
+        assert ga["mel_attention_weights"].shape == (2, want["num_frames"], 28, 80)
+
+
+def test_sequence_tiling_is_invisible():
+    """More windows than the workspace tile: results must not depend on the tile size."""
+    params = synth.make_core_params(53)
+    audio = dev(synth.make_audio(92, 3, 136448 + 533 * 20))
+    emo = dev(synth.normal(93, (3, 256)))
+    m = DualStreamCrossAttention().cuda().eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    eng = m.engine()
+    a = eng.sequence_forward(audio, emo, 1, True, max_tile=7)
+    m2 = DualStreamCrossAttention().cuda().eval()
+    m2.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    b = m2.engine().sequence_forward(audio, emo, 1, True, max_tile=4096)
+    assert a.shape == (3, 21, 52) and torch.equal(a, b)
+
+
+def test_mel_spectrogram_extractor_mirror():
+    ex = MelSpectrogramExtractor().cuda()
+    assert ex.hop_length == 533 and ex.get_output_length(16000) == 31
+    audio = synth.make_audio(94, 2, 32000)
+    got = ex(dev(audio)).cpu().numpy()
+    want = omel.mel_torchaudio(audio)
+    assert got.shape == want.shape == (2, 60, 80)
+    np.testing.assert_allclose(np.exp(got), np.exp(want), rtol=2e-3, atol=2e-8)
+    assert ex(dev(audio[0])).shape == (1, 60, 80)                       # 1-D input
+    assert ex(dev(audio[:, :533])).shape == (2, 0, 80)                  # rt.py's degenerate 533-sample call
+    with pytest.raises(ValueError):
+        ex(dev(audio)[None])
+
+
+def test_realtime_path_and_rt_loop(tmp_path):
+    params = synth.make_core_params(54, style="trained")
+    m = SimplifiedDualStreamModel(real_time_mode=True).cuda().eval()
+    m.load_state_dict(full_state(params))
+    clock = [0.0]
+    m.mel_extractor._clock = lambda: clock[0]
+    stream = synth.make_audio(95, 1, 533 * 262)[0]
+    emo = synth.normal(96, (1, 256))
+    from oracle import buffers, core, smoothing
+    ob = buffers.MelAudioBufferOracle()
+    sm = smoothing.TemporalSmootherOracle(0.8)
+    n_out = 0
+    for i in range(262):
+        frame = stream[i * 533:(i + 1) * 533]
+        clock[0] += 1.0 / 30
+        got = m.process_audio_frame_realtime(frame, emotion_features=dev(emo))
+        ob.add_audio_frame(frame)
+        win = ob.get_current_audio()
+        assert (got is None) == (win is None)
+        if got is None:
+            continue
+        n_out += 1
+        if i % 3 == 0 or i == 261:
+            feats = omel.mel_sliding_window(win, n_fft=1024, hop=533)                   # (255, 80) dB
+            want = core.core_forward_np(params, feats[None], feats[None, -3:], emo)["blendshapes"]
+            want = sm(want)
+            assert np.abs(got.cpu().numpy() - want[0]).max() < 2e-5
+        else:
+            feats = omel.mel_sliding_window(win, n_fft=1024, hop=533)
+            sm(core.core_forward_np(params, feats[None], feats[None, -3:], emo)["blendshapes"])
+    assert n_out == 262 - 255
+    # the rt.py loop end to end in --no_audio mode, JSONL out
+    out = tmp_path / "frames.jsonl"
+    m.reset_realtime_state()
+    m.mel_extractor._clock = lambda: clock.__setitem__(0, clock[0] + 1.0) or clock[0]
+    m.emotion_provider = lambda a: dev(emo)
+    inf = rt.RealTimeInference(None, model=m, device="cuda")
+    args = rt.build_parser().parse_args(["--model_path", "unused", "--no_audio", "--output_mode", "file",
+                                         "--output_file", str(out), "--duration", "1000", "--chunk_size", "533"])
+    streamer = rt.BlendshapeStreamer("file", output_file=str(out))
+    import queue
+    sent = 0
+    q = queue.Queue(maxsize=100)
+    for _ in range(270):                              # drive the loop body deterministically
+        inf.process_audio_chunk(np.random.randn(533).astype(np.float32) * 0.01)
+        bs = inf.inference_step()
+        if bs is not None:
+            streamer.send(bs, 0.0); sent += 1
+    streamer.close()
+    lines = out.read_text().splitlines()
+    assert sent == len(lines) == 270 - 255
+    rec = json.loads(lines[-1])
+    assert len(rec["blendshapes"]) == 52 and all(0.0 <= v <= 1.0 for v in rec["blendshapes"])

@@ -1,0 +1,106 @@
+"""Host-side mirrors of the reference interface (no GPU): ring buffers against the oracle, state-dict
+layout, wire format, CLI flags, and the no-CPU-fallback rule."""
+import json
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from koemorph_amd import synth
+from koemorph_amd.features.mel_sliding_window import MelAudioBuffer
+from koemorph_amd.model import DualStreamCrossAttention, SequentialDualStreamModel, SimplifiedDualStreamModel
+from koemorph_amd.scripts import rt
+from oracle import buffers
+
+
+def test_ringbuffer_matches_oracle_on_random_traffic():
+    rng = np.random.default_rng(0)
+    a, b = rt.RingBuffer(1000), buffers.RingBufferOracle(1000)
+    for _ in range(400):
+        if rng.random() < 0.55:
+            d = rng.standard_normal(int(rng.integers(1, 400))).astype(np.float32)
+            a.write(d); b.write(d)
+        else:
+            n = int(rng.integers(1, 600))
+            x, y = a.read(n), b.read(n)
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert np.array_equal(x, y)
+        assert (a.available, a.read_ptr, a.write_ptr) == (b.available, b.read_ptr, b.write_ptr)
+
+
+def test_mel_audio_buffer_matches_oracle():
+    rng = np.random.default_rng(1)
+    a, b = MelAudioBuffer(), buffers.MelAudioBufferOracle()
+    assert a.hop_length == b.hop_length == 532 and a.buffer_size == 136000
+    for i in range(300):
+        n = int(rng.choice([531, 532, 533, 533, 533, 500]))
+        f = rng.standard_normal(n).astype(np.float32)
+        assert a.add_audio_frame(f) == b.add_audio_frame(f)
+        x, y = a.get_current_audio(), b.get_current_audio()
+        assert (x is None) == (y is None)
+        if x is not None and i % 17 == 0:
+            assert np.array_equal(x, y)
+    assert a.get_stats()["total_frames_added"] == b.total_frames_added
+
+
+def test_state_dict_layout_matches_reference():
+    m = DualStreamCrossAttention()
+    want = synth.core_param_shapes()
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == dict(want)
+    assert sum(p.numel() for p in m.parameters()) == 837737
+    full = SimplifiedDualStreamModel()
+    keys = set(full.state_dict().keys())
+    assert keys == {"smoothing_alpha"} | {"dual_stream_attention." + k for k in want}
+    m512 = DualStreamCrossAttention(d_model=512, mel_sequence_length=512, num_heads=16)
+    assert sum(p.numel() for p in m512.parameters()) == 3182697
+    # a reference-layout checkpoint loads strictly
+    sd = {"dual_stream_attention." + k: torch.from_numpy(v) for k, v in synth.make_core_params(3).items()}
+    sd["smoothing_alpha"] = torch.tensor(0.5)
+    full.load_state_dict(sd, strict=True)
+    seq = SequentialDualStreamModel(stride_frames=2)
+    assert (seq.window_samples, seq.stride_samples, seq.hop_length) == (136448, 1066, 533)
+    assert SequentialDualStreamModel(target_fps=60, mel_sequence_length=512).hop_length == 266
+
+
+def test_no_cpu_fallback():
+    m = DualStreamCrossAttention().eval()
+    mel, short, emo = (torch.from_numpy(x) for x in synth.make_core_inputs(1, 2, 257))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(mel, short, emo)
+
+
+def test_streamer_wire_format(tmp_path):
+    bs = synth.uniform(5, (52,), 0, 1)
+    p = tmp_path / "out.jsonl"
+    s = rt.BlendshapeStreamer("file", output_file=str(p))
+    s.send(bs, 12.5); s.send(bs, 13.0); s.close()
+    lines = p.read_text().splitlines()
+    rec = json.loads(lines[0])
+    assert len(lines) == 2 and list(rec) == ["timestamp", "blendshapes"] and rec["timestamp"] == 12.5
+    assert len(rec["blendshapes"]) == 52 and rec["blendshapes"] == bs.tolist()
+    rx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    rx.bind(("127.0.0.1", 0)); rx.settimeout(2.0)
+    u = rt.BlendshapeStreamer("udp", port=rx.getsockname()[1])
+    u.send(bs, 1.0)
+    got = json.loads(rx.recv(65536).decode("utf-8"))
+    assert got == {"timestamp": 1.0, "blendshapes": bs.tolist()}
+    u.close(); rx.close()
+    with pytest.raises(ValueError):
+        rt.BlendshapeStreamer("file")
+    with pytest.raises(ValueError):
+        rt.BlendshapeStreamer("smoke-signals")
+
+
+def test_cli_flags_match_reference():
+    p = rt.build_parser()
+    a = p.parse_args(["--model_path", "x.pt"])
+    assert (a.sample_rate, a.target_fps, a.chunk_size, a.output_mode, a.host, a.port, a.device, a.no_audio) == \
+        (16000, 30.0, 1024, "udp", "127.0.0.1", 9001, "auto", False)
+    flags = {o for act in p._actions for o in act.option_strings}
+    assert {"--model_path", "--config_path", "--sample_rate", "--target_fps", "--chunk_size", "--output_mode",
+            "--host", "--port", "--output_file", "--device", "--duration", "--no_audio"} <= flags
+    with pytest.raises(SystemExit):
+        p.parse_args([])                                              # --model_path is required
