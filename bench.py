@@ -5,14 +5,15 @@ Workload (BASELINE.json configs[1], "C2"): per GPU a batch of 256 synthetic 8.5 
 (136 448 samples @16 kHz) -> 1024-pt STFT / 80-bin log-mel (257 frames) -> dual-stream
 cross-attention (d_model 256, 8 heads, window 256) -> decoder -> temporal smoothing ->
 256 x 52 fp32 coefficients.  One "step" = one pass of that path over the batch
-(km_forward_audio: emotion kernel, mel power kernel, mel log kernel, fused core kernel);
+(km_forward_audio: emotion kernel, mel power kernel, fused core kernel with dB conversion + EMA);
 inputs are resident in HBM before the timed region.  Windows shard embarrassingly across
 GPUs (weak scaling, no data-path collective).
 
     python bench.py --gpus N --steps K --warmup W
 
 prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline      dominant kernel: algorithmic FLOPs (or bytes) per launch / measured launch time
+  roofline      dominant kernel of the step: algorithmic bytes (or FLOPs) per launch / launch time measured
+                live with HIP events on the launch stream (km_enable_stage_timing)
   cpu_baseline  the CPU oracle (numpy front end + torch-CPU core) timed on this host (N=1 only)
 """
 from __future__ import annotations
@@ -30,6 +31,7 @@ if ROOT not in sys.path:
 # algorithmic work per frame, SURVEY.md section 8(d) (d=256, T=256, H=8)
 FLOPS_PER_FRAME = 48.8e6          # dense FLOPs of the attention core, Q projection included
 BYTES_PER_FRAME_AUDIO = 136448 * 4  # fp32 audio in
+EXECUTED_MFMA_FLOPS_PER_FRAME = 8 * 2148 * 2048  # 8 waves x 2148 v_mfma_f32_16x16x4 x 2048 FLOP = 35.2 M
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 
@@ -40,7 +42,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="windows per GPU per step")
-    ap.add_argument("--cpu-windows", type=int, default=256, help="windows in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-windows", type=int, default=256, help="windows per CPU-baseline pass (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget")
     args = ap.parse_args()
 
     import numpy as np
@@ -102,58 +105,59 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = B * n_gpus * args.steps / dt
 
-    # ---- per-stage timing with HIP events on the launch stream (torch's current stream) -----
-    def time_stage(fn, iters):
-        fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(dev)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        return e0.elapsed_time(e1) / iters * 1e-3     # seconds per launch
-
-    mel_long, mel_short = eng.mel_batch(audio)
-    zemo = eng.emotion_logit(emo)
+    # ---- per-kernel timing, live, with HIP events recorded by the library on the launch stream around
+    # the three kernels of the SAME step that was timed above (km_enable_stage_timing) ---------------
+    eng.enable_stage_timing(True)
     iters = max(10, min(args.steps, 100))
-    t_core = time_stage(lambda: eng.core_forward_z(mel_long, mel_short, zemo, out=out), iters)
-    t_mel = time_stage(lambda: eng.mel_batch(audio), iters)
+    acc = [0.0, 0.0, 0.0]
+    for _ in range(iters):
+        step()
+        for i, t in enumerate(eng.stage_times_ms()):
+            acc[i] += t
+    eng.enable_stage_timing(False)
+    t_emo, t_mel, t_core = (a * 1e-3 / iters for a in acc)         # seconds per launch
     core_tflops = FLOPS_PER_FRAME * B / t_core / 1e12
     mel_gbs = BYTES_PER_FRAME_AUDIO * B / t_mel / 1e9
-    pmc_traffic = None
+    pmc = {}
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
-            pmc_traffic = json.load(open(pmc_path))
+            pmc = json.load(open(pmc_path))
         except Exception:
-            pmc_traffic = None
-    roof_core = {"kernel": "core_fused_kernel", "bound": "mfma", "achieved": round(core_tflops, 3),
+            pmc = {}
+    roof_core = {"kernel": "core_fused_kernel<false,true>", "bound": "mfma", "achieved": round(core_tflops, 3),
                  "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(core_tflops / PEAK_F32_MFMA_TFLOPS, 4),
-                 "traffic": (pmc_traffic or {}).get("core_fused_kernel"), "launch_ms": round(t_core * 1e3, 4),
-                 "algorithmic_flops_per_launch": FLOPS_PER_FRAME * B}
-    roof_mel = {"kernel": "mel_power_kernel(+mel_log_kernel)", "bound": "hbm", "achieved": round(mel_gbs, 2),
+                 "traffic": (pmc.get("core_fused_kernel") or {}).get("hbm_bytes_per_launch"),
+                 "launch_ms": round(t_core * 1e3, 4), "algorithmic_flops_per_launch": FLOPS_PER_FRAME * B,
+                 # the kernel executes fewer FLOPs than the reference formulation (folded projections):
+                 "executed_mfma_flops_per_launch": EXECUTED_MFMA_FLOPS_PER_FRAME * B,
+                 "mfma_pipe_util": round(EXECUTED_MFMA_FLOPS_PER_FRAME * B / t_core / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+    roof_mel = {"kernel": "mel_power_kernel<1024>", "bound": "hbm", "achieved": round(mel_gbs, 2),
                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(mel_gbs / PEAK_HBM_GBS, 4),
-                "traffic": (pmc_traffic or {}).get("mel_power_kernel"), "launch_ms": round(t_mel * 1e3, 4),
-                "algorithmic_bytes_per_launch": BYTES_PER_FRAME_AUDIO * B}
+                "traffic": (pmc.get("mel_power_kernel") or {}).get("hbm_bytes_per_launch"),
+                "launch_ms": round(t_mel * 1e3, 4), "algorithmic_bytes_per_launch": BYTES_PER_FRAME_AUDIO * B}
     roofline, other = (roof_core, roof_mel) if t_core >= t_mel else (roof_mel, roof_core)
+    stage_ms = {"emotion_kernel": round(t_emo * 1e3, 4), "mel_power_kernel": round(t_mel * 1e3, 4),
+                "core_fused_kernel": round(t_core * 1e3, 4)}
 
-    # ---- CPU baseline: the oracle on this host's cores (rank 0, N=1 only) -------------------
+    # ---- CPU baseline: the oracle on this host's cores (rank 0, N=1 only), bounded sample ----------
     cpu = None
     if rank == 0 and n_gpus == 1 and args.cpu_windows > 0:
         from oracle import models
         nb = min(args.cpu_windows, B)
         orc = models.SimplifiedOracle(params)
-        orc.forward(audio_np[:2], emo_np[:2])                      # warm-up (filterbank, BLAS threads)
-        orc.reset_temporal_state()
-        tc0 = time.perf_counter()
-        ref = orc.forward(audio_np[:nb], emo_np[:nb])["blendshapes"]
-        tc = time.perf_counter() - tc0
-        # same weights, same inputs: report the agreement as a sanity line
-        chk = eng.forward_audio(audio[:nb], emo[:nb]).cpu().numpy()
-        cpu = {"value": round(nb / tc, 2), "unit": "frames/s", "cores": int(torch.get_num_threads()),
-               "kind": "port", "sample": f"one pass over {nb} windows of 136448 samples "
-               f"(numpy float64 STFT + float32 mel/dB, torch-CPU fp32 core), {tc:.1f} s",
+        orc.forward(audio_np[:2], emo_np[:2], smooth=False)        # warm-up (filterbank, BLAS threads)
+        done, tc, ref = 0, 0.0, None
+        while tc < args.cpu_seconds and done < 40 * nb:            # ~10-30 s of CPU work
+            tc0 = time.perf_counter()
+            ref = orc.forward(audio_np[:nb], emo_np[:nb], smooth=False)["blendshapes"]
+            tc += time.perf_counter() - tc0
+            done += nb
+        chk = eng.forward_audio(audio[:nb], emo[:nb]).cpu().numpy()  # same weights, same inputs
+        cpu = {"value": round(done / tc, 2), "unit": "frames/s", "cores": int(torch.get_num_threads()),
+               "kind": "port", "sample": f"{done // nb} passes over {nb} windows of 136448 samples = {done} frames in "
+               f"{tc:.1f} s (numpy float64 STFT + float32 mel/dB single-threaded, torch-CPU fp32 core on "
+               f"{int(torch.get_num_threads())} threads)",
                "max_abs_diff_vs_gpu": float(np.abs(chk - ref).max())}
 
     if rank == 0:
@@ -167,7 +171,7 @@ def main():
                                    "80-bin log-mel (257 frames) -> dual-stream attention d_model=256, 8 heads, "
                                    "window 256 -> 52 coefficients + EMA; from audio resident in HBM",
                        "windows_per_gpu": B, "samples_per_window": L, "parallelism": f"window-sharded x{n_gpus}, no collective"},
-            "roofline": roofline, "roofline_other_stage": other, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_other_kernel": other, "kernel_ms": stage_ms, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if dist is not None:

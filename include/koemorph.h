@@ -183,6 +183,14 @@ int km_sequence_forward(km_handle h, const float* audio_dev, int64_t B, int64_t 
                         const float* emotion_dev, int32_t stride_frames, int32_t smooth,
                         float* out_dev, void* stream);
 
+/* ---- measurement aid used by bench.py ------------------------------------------------------------
+ * With stage timing enabled, km_forward_audio records HIP events on the launch stream around its three
+ * kernels (emotion logits, power-mel front end, fused core); km_stage_times synchronises on the last
+ * event and returns the elapsed milliseconds of the most recent call: ms[0] emotion, ms[1] front end,
+ * ms[2] core.  Event records are not graph-capturable: keep it off in production. */
+int km_enable_stage_timing(km_handle h, int32_t enable);
+int km_stage_times(km_handle h, float* ms3);
+
 /* ---- introspection used by the tests ------------------------------------------------- */
 /* Copy a named host-side folded/packed buffer (after km_finalize_host) into out; returns its
  * length in floats via *n when out == NULL. */

@@ -91,6 +91,8 @@ int km_destroy(km_handle h) {
         if (kv.second.dev) (void)hipFree(kv.second.dev);
     (void)free_ws(c);
     for (MelPlan* p : c->mel_plans) free_mel_plan(p);
+    for (void* e : c->stage_ev)
+        if (e) (void)hipEventDestroy((hipEvent_t)e);
     delete h;
     return KM_OK;
 }
@@ -178,10 +180,40 @@ int km_forward_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L, 
     if (B > c->ws_windows || n_frames > c->ws_frames)
         return fail(KM_ERR_WORKSPACE, "workspace too small for %lld windows x %lld samples: call km_reserve",
                     (long long)B, (long long)L);
-    if (int rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, stream)) return rc;
     // three launches: emotion logits, power-mel + window maxima, fused core (dB conversion on load)
+    hipStream_t st = (hipStream_t)stream;
+    const bool tm = c->stage_timing;
+    if (tm) HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[0], st));
+    if (int rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, stream)) return rc;
+    if (tm) HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[1], st));
     if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, L, stream)) return rc;
-    return launch_core_fused_db(c, c->mel_plans[0], B, n_frames, c->ws_zemo, out_dev, state_dev, first, stream);
+    if (tm) HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[2], st));
+    if (int rc = launch_core_fused_db(c, c->mel_plans[0], B, n_frames, c->ws_zemo, out_dev, state_dev, first, stream)) return rc;
+    if (tm) HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[3], st));
+    return KM_OK;
+}
+
+int km_enable_stage_timing(km_handle h, int32_t enable) {
+    if (!h) return fail(KM_ERR_INVALID_ARG, "NULL handle");
+    Context* c = h;
+    if (enable && !c->stage_ev[0])
+        for (int i = 0; i < 4; ++i) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            c->stage_ev[i] = e;
+        }
+    c->stage_timing = enable != 0;
+    return KM_OK;
+}
+
+int km_stage_times(km_handle h, float* ms3) {
+    if (!h || !ms3) return fail(KM_ERR_INVALID_ARG, "km_stage_times: NULL argument");
+    Context* c = h;
+    if (!c->stage_ev[0]) return fail(KM_ERR_INVALID_ARG, "stage timing was never enabled");
+    HIP_TRY(hipEventSynchronize((hipEvent_t)c->stage_ev[3]));
+    for (int i = 0; i < 3; ++i)
+        HIP_TRY(hipEventElapsedTime(&ms3[i], (hipEvent_t)c->stage_ev[i], (hipEvent_t)c->stage_ev[i + 1]));
+    return KM_OK;
 }
 
 int64_t km_sequence_num_outputs(km_handle h, int64_t L, int32_t stride_frames) {

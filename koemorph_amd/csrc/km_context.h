@@ -70,6 +70,8 @@ struct Context {
     float* ws_mel = nullptr;       // (windows, frames, 80) log-mel
     float* ws_short = nullptr;     // (windows, 3, 80)
     int64_t ws_frames = 0;
+    bool stage_timing = false;
+    void* stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // hipEvent_t
     bool melmax_dirty = true;      // ws_melmax may hold stale maxima (see launch_mel_power)
 };
 

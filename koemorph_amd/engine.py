@@ -271,6 +271,15 @@ class Engine:
                                              1 if first else 0, _stream_ptr(audio.device)))
         return out
 
+    def enable_stage_timing(self, enable: bool = True) -> None:
+        check(self._lib.km_enable_stage_timing(self._h, 1 if enable else 0))
+
+    def stage_times_ms(self):
+        """(emotion, front end, core) milliseconds of the most recent forward_audio (HIP events)."""
+        ms = (C.c_float * 3)()
+        check(self._lib.km_stage_times(self._h, ms))
+        return float(ms[0]), float(ms[1]), float(ms[2])
+
     def sequence_forward(self, audio, emotion, stride_frames: int = 1, smooth: bool = True, max_tile: int = 2048):
         """audio (B, L) -> (B, N, 52): one frame per window position (km_sequence_forward)."""
         torch = _torch()
