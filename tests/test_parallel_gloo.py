@@ -1,0 +1,76 @@
+"""N>1 path on the CPU: world_size-2 gloo processes exercise the sharding, gather and gradient all-reduce
+logic that the GPU ranks use over RCCL (there is no data-path collective to test for inference)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from koemorph_amd import parallel
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w, _ = parallel.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    g = torch.Generator().manual_seed(0)
+    audio = torch.randn(7, 64, generator=g)                     # 7 windows: uneven split 4 + 3
+    emo = torch.randn(7, 5, generator=g)
+    calls = []
+
+    def fn(a, e):                                               # stand-in for the per-rank HIP forward
+        calls.append(a.shape[0])
+        return torch.stack([a.sum(1), e.sum(1), a[:, 0]], dim=1)
+
+    out = parallel.sharded_apply(fn, audio, emo)
+    want = fn(audio, emo)
+    ok_gather = torch.equal(out, want) and calls[0] == (4 if rank == 0 else 3)
+    local = parallel.sharded_apply(fn, audio, emo, gather=False)
+    lo, hi = parallel.shard_range(7, rank, world)
+    ok_local = torch.equal(local, want[lo:hi])
+    grad = torch.full((837738,), float(rank + 1))               # the flat gradient bucket of the d=256 model
+    parallel.allreduce_gradients(grad)
+    ok_grad = bool(torch.all(grad == 1.5))
+    q.put((rank, ok_gather, ok_local, ok_grad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharding_gather_and_gradient_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True, True, True), (1, True, True, True)]
+
+
+def test_shard_ranges_and_stream_owner():
+    for n in (0, 1, 7, 256, 1024, 1025):
+        for world in (1, 2, 3, 8):
+            rs = [parallel.shard_range(n, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+            sizes = [h - l for l, h in rs]
+            assert max(sizes) - min(sizes) <= 1
+    # BASELINE config 5: 1024 streams sharded 128 per GPU
+    assert [parallel.stream_owner(s, 1024, 8) for s in (0, 127, 128, 1023)] == [0, 0, 1, 7]
+    with pytest.raises(ValueError):
+        parallel.stream_owner(1024, 1024, 8)
