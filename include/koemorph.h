@@ -183,6 +183,29 @@ int km_sequence_forward(km_handle h, const float* audio_dev, int64_t B, int64_t 
                         const float* emotion_dev, int32_t stride_frames, int32_t smooth,
                         float* out_dev, void* stream);
 
+/* ---- streaming: many concurrent speaker streams, state resident on the device -------------------------
+ * Replaces, for all streams of this GPU at once, MelAudioBuffer.add_audio_frame / get_current_audio
+ * (src/features/mel_sliding_window.py:70-140), MelSlidingWindowExtractor.process_audio_frame (:252-324) and
+ * SimplifiedDualStreamModel.process_audio_frame_realtime (src/model/simplified_dual_stream_model.py:452-498).
+ *   km_stream_create  n_streams rings of int(context_window_s * sr) samples; the ring hop is
+ *                     int(sr / (1 / update_interval_s)) (= 532 for 0.0333 s, reference quirk); mel_cfg is the
+ *                     sliding-window front end (n_fft 1024 / hop 533 / reflect / dB when built by the model,
+ *                     simplified_dual_stream_model.py:122-131), out_frames = int(context_window / update_interval).
+ *                     Allocates; call once, outside any graph capture.
+ *   km_stream_push    samples_dev (n_streams, n_per_stream): one frame per stream; n_per_stream must be within
+ *                     +/-1 of the ring hop (reference rejects others, :80-82) and is padded / truncated to it.
+ *   km_stream_tick    emotion_dev (n_streams, emotion_dim) -> out_dev (n_streams, 52) for every stream whose ring
+ *                     is full; ready_dev (n_streams) u8 mirrors MelAudioBuffer.is_full (rows of not-ready streams
+ *                     are left untouched).  Per-stream EMA state lives in the handle.  The short-term rows are
+ *                     the last three kept frames.  push + tick never allocate or synchronise: capture them in a
+ *                     hipGraph and replay it per 33 ms tick.
+ *   km_stream_reset   clear rings, readiness and EMA state (MelSlidingWindowExtractor.reset :373-383). */
+int km_stream_create(km_handle h, int64_t n_streams, double context_window_s, double update_interval_s,
+                     const km_mel_config* mel_cfg);
+int km_stream_push(km_handle h, const float* samples_dev, int64_t n_per_stream, void* stream);
+int km_stream_tick(km_handle h, const float* emotion_dev, float* out_dev, uint8_t* ready_dev, void* stream);
+int km_stream_reset(km_handle h, void* stream);
+
 /* ---- measurement aid used by bench.py ------------------------------------------------------------
  * With stage timing enabled, km_forward_audio records HIP events on the launch stream around its three
  * kernels (emotion logits, power-mel front end, fused core); km_stage_times synchronises on the last

@@ -71,6 +71,10 @@ SIGNATURES = {
     "km_forward_audio": (C.c_int, [_h, _p, _i64, _i64, _p, _p, _p, _i32, _p]),
     "km_sequence_num_outputs": (_i64, [_h, _i64, _i32]),
     "km_sequence_forward": (C.c_int, [_h, _p, _i64, _i64, _p, _i32, _i32, _p, _p]),
+    "km_stream_create": (C.c_int, [_h, _i64, C.c_double, C.c_double, C.POINTER(KMMelConfig)]),
+    "km_stream_push": (C.c_int, [_h, _p, _i64, _p]),
+    "km_stream_tick": (C.c_int, [_h, _p, _p, _p, _p]),
+    "km_stream_reset": (C.c_int, [_h, _p]),
     "km_enable_stage_timing": (C.c_int, [_h, _i32]),
     "km_stage_times": (C.c_int, [_h, C.POINTER(C.c_float)]),
     "km_debug_buffer": (C.c_int, [_h, C.c_char_p, _p, C.POINTER(_i64)]),

@@ -13,6 +13,8 @@ using namespace km;
         if (e_ != hipSuccess) return fail(KM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+static int free_streams(Context* c);
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static int need_ready(Context* c) {
@@ -90,6 +92,7 @@ int km_destroy(km_handle h) {
     for (auto& kv : c->packed)
         if (kv.second.dev) (void)hipFree(kv.second.dev);
     (void)free_ws(c);
+    (void)free_streams(c);
     for (MelPlan* p : c->mel_plans) free_mel_plan(p);
     for (void* e : c->stage_ev)
         if (e) (void)hipEventDestroy((hipEvent_t)e);
@@ -190,6 +193,89 @@ int km_forward_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L, 
     if (tm) HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[2], st));
     if (int rc = launch_core_fused_db(c, c->mel_plans[0], B, n_frames, c->ws_zemo, out_dev, state_dev, first, stream)) return rc;
     if (tm) HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[3], st));
+    return KM_OK;
+}
+
+static int free_streams(Context* c) {
+    void* ptrs[] = {c->ring, c->ring_wptr, c->ring_frames, c->ring_ready, c->ring_started, c->ring_state};
+    for (void* p : ptrs)
+        if (p) HIP_TRY(hipFree(p));
+    c->ring = nullptr; c->ring_wptr = nullptr; c->ring_frames = nullptr; c->ring_ready = nullptr;
+    c->ring_started = nullptr; c->ring_state = nullptr; c->n_streams = 0;
+    return KM_OK;
+}
+
+int km_stream_reset(km_handle h, void* stream) {
+    if (int rc = need_ready(h)) return rc;
+    Context* c = h;
+    if (c->n_streams <= 0) return fail(KM_ERR_INVALID_ARG, "km_stream_reset: no streams (km_stream_create first)");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(c->ring, 0, (size_t)c->n_streams * c->ring_len * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(c->ring_wptr, 0, (size_t)c->n_streams * sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(c->ring_frames, 0, (size_t)c->n_streams * sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(c->ring_ready, 0, (size_t)c->n_streams, st));
+    HIP_TRY(hipMemsetAsync(c->ring_started, 0, (size_t)c->n_streams, st));
+    HIP_TRY(hipMemsetAsync(c->ring_state, 0, (size_t)c->n_streams * c->NB * sizeof(float), st));
+    return KM_OK;
+}
+
+int km_stream_create(km_handle h, int64_t n_streams, double context_window_s, double update_interval_s,
+                     const km_mel_config* mel_cfg) {
+    if (int rc = need_ready(h)) return rc;
+    Context* c = h;
+    if (n_streams <= 0 || !(context_window_s > 0) || !(update_interval_s > 0) || !mel_cfg)
+        return fail(KM_ERR_INVALID_ARG, "km_stream_create: bad argument");
+    if (mel_cfg->n_fft != 512 && mel_cfg->n_fft != 1024) return fail(KM_ERR_UNSUPPORTED, "n_fft must be 512 or 1024");
+    if (mel_cfg->n_mels != c->NK) return fail(KM_ERR_INVALID_ARG, "stream front end must produce %d mel channels", c->NK);
+    if (int rc = free_streams(c)) return rc;
+    const int sr = mel_cfg->sample_rate;
+    c->ring_len = (int64_t)(context_window_s * sr);                                // mel_sliding_window.py:46
+    const double target_fps = 1.0 / update_interval_s;
+    c->ring_hop = (int)((double)sr / target_fps);                                   // :49-50 (532 for 0.0333)
+    c->stream_out_frames = (int64_t)(context_window_s / update_interval_s);         // :300
+    if (c->ring_hop <= 0 || c->ring_len <= mel_cfg->n_fft / 2) return fail(KM_ERR_INVALID_ARG, "context window too short");
+    c->n_streams = n_streams;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ring), (size_t)n_streams * c->ring_len * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ring_wptr), (size_t)n_streams * sizeof(int)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ring_frames), (size_t)n_streams * sizeof(int)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ring_ready), (size_t)n_streams));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ring_started), (size_t)n_streams));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ring_state), (size_t)n_streams * c->NB * sizeof(float)));
+    c->stream_plan = find_or_add_plan(c, *mel_cfg);
+    if (int rc = upload_mel_plan(c->stream_plan)) return rc;
+    if (int rc = km_reserve(h, n_streams, c->ring_len)) return rc;
+    if (int rc = km_stream_reset(h, nullptr)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return KM_OK;
+}
+
+int km_stream_push(km_handle h, const float* samples_dev, int64_t n_per_stream, void* stream) {
+    if (int rc = need_ready(h)) return rc;
+    Context* c = h;
+    if (c->n_streams <= 0) return fail(KM_ERR_INVALID_ARG, "km_stream_push: no streams (km_stream_create first)");
+    if (!samples_dev) return fail(KM_ERR_INVALID_ARG, "km_stream_push: NULL samples");
+    const int64_t diff = n_per_stream - c->ring_hop;
+    if (diff > 1 || diff < -1)                                                      // :80-82
+        return fail(KM_ERR_INVALID_ARG, "Frame size mismatch: expected ~%d, got %lld", c->ring_hop, (long long)n_per_stream);
+    return launch_ring_push(c, samples_dev, n_per_stream, stream);
+}
+
+int km_stream_tick(km_handle h, const float* emotion_dev, float* out_dev, uint8_t* ready_dev, void* stream) {
+    if (int rc = need_ready(h)) return rc;
+    Context* c = h;
+    if (c->n_streams <= 0) return fail(KM_ERR_INVALID_ARG, "km_stream_tick: no streams (km_stream_create first)");
+    if (!emotion_dev || !out_dev) return fail(KM_ERR_INVALID_ARG, "km_stream_tick: NULL argument");
+    if (!c->fused_ok)
+        return fail(KM_ERR_UNSUPPORTED, "no kernel for d_model=%d, mel_sequence_length=%d, heads=%d", c->d, c->T, c->H);
+    const int64_t S = c->n_streams, L = c->ring_len;
+    const int64_t n_frames = 1 + L / c->stream_plan->cfg.hop_length;
+    if (S > c->ws_windows || n_frames > c->ws_frames) return fail(KM_ERR_WORKSPACE, "stream workspace too small");
+    if (int rc = launch_emotion(c, emotion_dev, S, c->ws_zemo, stream)) return rc;
+    if (int rc = launch_mel_power(c, c->stream_plan, c->ring, S, L, stream, L, 0, 0, 1, c->ring_wptr, c->ring_ready)) return rc;
+    if (int rc = launch_core_fused_db(c, c->stream_plan, S, n_frames, c->ws_zemo, out_dev, c->ring_state, 0, stream, 0, 1,
+                                      c->stream_out_frames, c->ring_ready, c->ring_started)) return rc;
+    if (ready_dev)
+        HIP_TRY(hipMemcpyAsync(ready_dev, c->ring_ready, (size_t)S, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return KM_OK;
 }
 

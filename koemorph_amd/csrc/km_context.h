@@ -70,6 +70,17 @@ struct Context {
     float* ws_mel = nullptr;       // (windows, frames, 80) log-mel
     float* ws_short = nullptr;     // (windows, 3, 80)
     int64_t ws_frames = 0;
+    // streaming state (km_stream_*): device-resident per-stream audio rings (MelAudioBuffer semantics)
+    int64_t n_streams = 0, ring_len = 0;
+    int ring_hop = 0;
+    float* ring = nullptr;              // (n_streams, ring_len)
+    int* ring_wptr = nullptr;           // (n_streams) write pointer == chronological start once full
+    int* ring_frames = nullptr;         // (n_streams) frames added
+    unsigned char* ring_ready = nullptr;    // (n_streams) is_full
+    unsigned char* ring_started = nullptr;  // (n_streams) EMA state valid
+    float* ring_state = nullptr;        // (n_streams, 52) EMA state
+    MelPlan* stream_plan = nullptr;
+    int64_t stream_out_frames = 0;
     bool stage_timing = false;
     void* stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // hipEvent_t
     bool melmax_dirty = true;      // ws_melmax may hold stale maxima (see launch_mel_power)
@@ -90,13 +101,16 @@ int launch_core_fused(Context* c, const float* mel, int64_t B, int64_t T_in, con
                       void* stream);
 // fused variant: reads the workspace power-mel + window maxima, applies the log/dB conversion on load
 int launch_core_fused_db(Context* c, MelPlan* p, int64_t B, int64_t n_frames, const float* zemo, float* out,
-                         float* state, int first, void* stream, int64_t win0 = 0, int zemo_div = 1);
+                         float* state, int first, void* stream, int64_t win0 = 0, int zemo_div = 1, int64_t n_use = 0,
+                         const unsigned char* ready = nullptr, unsigned char* started = nullptr);
 int launch_ema_scan(Context* c, float* x, int64_t B, int64_t N, void* stream);
 int launch_smooth(Context* c, float* x, float* state, int64_t B, int first, void* stream);
 
 // km_mel.hip
 int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, void* stream,
-                     int64_t clip_len = 0, int64_t win_step = 0, int64_t win0 = 0, int wins_per_clip = 1);
+                     int64_t clip_len = 0, int64_t win_step = 0, int64_t win0 = 0, int wins_per_clip = 1,
+                     const int* ring_start = nullptr, const unsigned char* ready = nullptr);
+int launch_ring_push(Context* c, const float* samples, int64_t n_per_stream, void* stream);
 int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, int64_t out_frames,
                float* mel_long, float* mel_short, void* stream);
 int upload_mel_plan(MelPlan* p);

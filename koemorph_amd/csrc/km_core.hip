@@ -72,6 +72,11 @@ struct CoreArgs {
     // sequence mode: one emotion logit per clip, shared by its windows: zemo[(win0 + b) / zemo_div]
     int64_t win0;
     int zemo_div;
+    // streaming mode: frames kept by the truncate / repeat-last policy (255 of 256, mel_sliding_window.py:300-307),
+    // per-stream readiness (ring full) and per-stream 'EMA started' flags
+    int n_use;
+    const unsigned char* ready;   // (B) or null: windows with ready[b] == 0 are skipped entirely
+    unsigned char* started;       // (B) or null: first = !started[b], then started[b] = 1
 };
 
 // blendshape index -> mouth query slot (MOUTH_INDICES = 14..40, 51; dual_stream_attention.py:14-45)
@@ -90,6 +95,9 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, j = lane & 15;
+    if constexpr (FUSE_DB) {
+        if (a.ready && !a.ready[b]) return;     // stream still filling its ring (workgroup-uniform)
+    }
 
     // ---- phase 0: X -> LDS, [t][c] exactly as the caller's (t_in, 80) rows --------------------
     if constexpr (FUSE_DB) {
@@ -98,13 +106,17 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
         // (simplified_dual_stream_model.py:199-214)
         float ref_db, floor_db;
         log_window_consts(a.lp, __uint_as_float(a.melmax[b]), ref_db, floor_db);
-        const int F = a.n_frames;
-        const int tv = F < T ? F : T;
+        const int F = a.n_frames;          // frames the front end computed (the dB reference spans all of them)
+        const int U = a.n_use;             // rows kept: truncated, or padded by repeating the last frame
+        const int tv = U < T ? U : T;
         const float4* src = reinterpret_cast<const float4*>(a.melpow + (int64_t)b * F * NK);
         float4* dst = reinterpret_cast<float4*>(R1);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = tid; i < tv * 20; i += NT) {
-            const float4 v = src[i];
+            int fr = i / 20;
+            const int c4 = i - fr * 20;
+            fr = fr < F ? fr : F - 1;
+            const float4 v = src[fr * 20 + c4];
             dst[i] = make_float4(log_one(a.lp, v.x, ref_db, floor_db), log_one(a.lp, v.y, ref_db, floor_db),
                                  log_one(a.lp, v.z, ref_db, floor_db), log_one(a.lp, v.w, ref_db, floor_db));
         }
@@ -113,7 +125,8 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
             const int r = tid / 20;
             float4 v = z4;
             int fr = -1;
-            if (F >= 3) fr = F - 3 + r; else if (r < F) fr = r;
+            if (U >= 3) fr = U - 3 + r; else if (r < U) fr = r;
+            if (fr >= F) fr = F - 1;
             if (fr >= 0) {
                 const float4 u = src[fr * 20 + (tid - r * 20)];
                 v = make_float4(log_one(a.lp, u.x, ref_db, floor_db), log_one(a.lp, u.y, ref_db, floor_db),
@@ -384,10 +397,16 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
         if (a.raw) a.raw[(int64_t)b * 52 + tid] = bs;
         if (a.state) {                                                  // EMA (simplified_dual_stream_model.py:357-366)
             float* st = a.state + (int64_t)b * 52 + tid;
-            if (!a.first) val = a.alpha * val + (1.0f - a.alpha) * (*st);
+            const bool first = a.started ? !a.started[b] : (a.first != 0);
+            if (!first) val = a.alpha * val + (1.0f - a.alpha) * (*st);
             *st = val;
         }
         a.out[(int64_t)b * 52 + tid] = val;
+    }
+    if constexpr (FUSE_DB) {
+        // all 52 threads above read started[b] before this barrier-free point?  No: order it explicitly.
+        __syncthreads();
+        if (tid == 0 && a.started) a.started[b] = 1;
     }
 }
 
@@ -709,13 +728,15 @@ int launch_core_fused(Context* c, const float* mel, int64_t B, int64_t T_in, con
 LogParams plan_log_params(MelPlan* p);
 
 int launch_core_fused_db(Context* c, MelPlan* p, int64_t B, int64_t n_frames, const float* zemo, float* out,
-                         float* state, int first, void* stream, int64_t win0, int zemo_div) {
+                         float* state, int first, void* stream, int64_t win0, int zemo_div, int64_t n_use,
+                         const unsigned char* ready, unsigned char* started) {
     if (int rc = core_attrs()) return rc;
     CoreArgs a{};
     core_weights(c, a);
     a.zemo = zemo; a.t_in = (int)n_frames;
     a.out = out; a.state = state; a.first = first; a.win0 = win0; a.zemo_div = zemo_div > 0 ? zemo_div : 1;
     a.melpow = c->ws_melpow; a.melmax = c->ws_melmax; a.n_frames = (int)n_frames; a.lp = plan_log_params(p);
+    a.n_use = (int)(n_use > 0 ? n_use : n_frames); a.ready = ready; a.started = started;
     hipLaunchKernelGGL((core_fused_kernel<false, true>), dim3((unsigned)B), dim3(fused::NT), fused::LDS_BYTES, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return KM_OK;

@@ -97,6 +97,10 @@ struct MelArgs {
     int64_t clip_len, win_step;
     int64_t win0;
     int wins_per_clip;
+    // ring mode (km_stream_*): window b is the ring of stream b read in chronological order starting at
+    // ring_start[b] (mod L); streams whose ring is not full yet (ready[b] == 0) are skipped
+    const int* ring_start;
+    const unsigned char* ready;
     int n_frames;         // frames computed per window = 1 + L / hop
     int hop;
     int pad_mode;
@@ -114,8 +118,8 @@ struct MelArgs {
 
 // raw samples of the frame pair (fa, fa+1) into z[i] = (x_a[lane + 64 i], x_b[lane + 64 i]); wave-uniform fa
 template <int NFFT>
-__device__ __forceinline__ void load_pair(const MelArgs& a, const float* __restrict__ x, int64_t Lv, int fa, int lane,
-                                          float2 (&z)[NFFT / 64]) {
+__device__ __forceinline__ void load_pair(const MelArgs& a, const float* __restrict__ x, int64_t Lv, int rs, int fa,
+                                          int lane, float2 (&z)[NFFT / 64]) {
     constexpr int R0 = NFFT / 64;
     if (fa >= a.n_frames) {
 #pragma unroll
@@ -124,6 +128,29 @@ __device__ __forceinline__ void load_pair(const MelArgs& a, const float* __restr
     }
     const int64_t p0 = (int64_t)fa * a.hop - NFFT / 2;
     const bool have_b = fa + 1 < a.n_frames;
+    if (rs >= 0) {                                            // ring: logical sample q lives at (rs + q) mod L
+        const int Li = (int)Lv;
+#pragma unroll
+        for (int i = 0; i < R0; ++i) {
+            int qa = (int)p0 + lane + 64 * i, qb = qa + a.hop;
+            float va = 0.f, vb = 0.f;
+            if (a.pad_mode == KM_PAD_REFLECT) {
+                qa = qa < 0 ? -qa : (qa >= Li ? 2 * (Li - 1) - qa : qa);
+                qb = qb < 0 ? -qb : (qb >= Li ? 2 * (Li - 1) - qb : qb);
+                int ia = rs + qa; ia -= ia >= Li ? Li : 0;
+                int ib = rs + qb; ib -= ib >= Li ? Li : 0;
+                va = x[ia];
+                vb = have_b ? x[ib] : 0.f;
+            } else {
+                int ia = rs + qa; ia -= ia >= Li ? Li : 0;
+                int ib = rs + qb; ib -= ib >= Li ? Li : 0;
+                if (qa >= 0 && qa < Li) va = x[ia];
+                if (have_b && qb >= 0 && qb < Li) vb = x[ib];
+            }
+            z[i] = make_float2(va, vb);
+        }
+        return;
+    }
     if (p0 >= 0 && p0 + a.hop + NFFT <= Lv && have_b) {      // interior pair: no padding, 32-bit offsets
         const float* xa = x + p0 + lane;
         const float* xb = xa + a.hop;
@@ -172,6 +199,8 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
     const int64_t clip = gw / a.wins_per_clip, woff = (gw - clip * a.wins_per_clip) * a.win_step;
     const float* x = a.audio + clip * a.clip_len + woff;
     const int64_t Lv = (a.clip_len - woff) < a.L ? (a.clip_len - woff) : a.L;   // samples that exist; the rest reads as zero
+    if (a.ready && !a.ready[b]) return;                        // workgroup-uniform: stream still filling
+    const int rs = a.ring_start ? a.ring_start[b] : -1;
     float2* buf = fbuf + wave * FFT_BUF;
     const int n_chunks = (a.n_frames + FPB - 1) / FPB;
 
@@ -196,7 +225,7 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
     float vmax = 0.f;
     float2 zn[R0];                          // software prefetch: raw samples of the NEXT pair of this wave
     int chunk = blockIdx.x;
-    load_pair<NFFT>(a, x, Lv, chunk * FPB + 2 * wave, lane, zn);
+    load_pair<NFFT>(a, x, Lv, rs, chunk * FPB + 2 * wave, lane, zn);
     for (; chunk < n_chunks; chunk += gridDim.x) {
         const int f0 = chunk * FPB;
 #pragma unroll 1
@@ -209,7 +238,7 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
             {   // issue the next pair's loads now; they complete under this pair's FFT
                 const int fn = (pi + 1 < FPB / 2 / WAVES) ? fa + 2 * WAVES
                                                           : (chunk + (int)gridDim.x) * FPB + 2 * wave;
-                load_pair<NFFT>(a, x, Lv, (pi + 1 < FPB / 2 / WAVES || chunk + (int)gridDim.x < n_chunks) ? fn : a.n_frames,
+                load_pair<NFFT>(a, x, Lv, rs, (pi + 1 < FPB / 2 / WAVES || chunk + (int)gridDim.x < n_chunks) ? fn : a.n_frames,
                                 lane, zn);
             }
             if (fa < a.n_frames) {   // wave-uniform
@@ -389,7 +418,8 @@ static LogParams log_params(const km_mel_config& m) {
 
 // power-mel (B, n_frames, n_mels) + per-window max into the workspace
 int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, void* stream,
-                     int64_t clip_len, int64_t win_step, int64_t win0, int wins_per_clip) {
+                     int64_t clip_len, int64_t win_step, int64_t win0, int wins_per_clip, const int* ring_start,
+                     const unsigned char* ready) {
     const km_mel_config& m = p->cfg;
     const int64_t n_frames = 1 + L / m.hop_length;
     if (m.pad_mode == KM_PAD_REFLECT && L <= m.n_fft / 2)
@@ -415,7 +445,8 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     }
     MelArgs a;
     a.audio = audio; a.L = L; a.clip_len = clip_len > 0 ? clip_len : L; a.win_step = win_step; a.win0 = win0;
-    a.wins_per_clip = wins_per_clip > 0 ? wins_per_clip : 1; a.n_frames = (int)n_frames; a.hop = m.hop_length; a.pad_mode = m.pad_mode;
+    a.wins_per_clip = wins_per_clip > 0 ? wins_per_clip : 1; a.n_frames = (int)n_frames;
+    a.ring_start = ring_start; a.ready = ready; a.hop = m.hop_length; a.pad_mode = m.pad_mode;
     a.n_mels = m.n_mels; a.window = p->d_window; a.twiddle = reinterpret_cast<const float2*>(p->d_twiddle);
     a.fb_start = p->d_fb_start; a.fb_count = p->d_fb_count; a.fb_offset = p->d_fb_offset; a.fb_weight = p->d_fb_weight;
     a.fb_nnz = (int)p->fb_weight.size();
@@ -450,6 +481,41 @@ int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L,
         hipLaunchKernelGGL(mel_log_kernel, grid2, dim3(256), 0, (hipStream_t)stream, g);
         HIP_TRY(hipGetLastError());
     }
+    return KM_OK;
+}
+
+// MelAudioBuffer.add_audio_frame for every stream at once (mel_sliding_window.py:70-116): the incoming frame
+// is zero-padded / truncated to the ring's own hop (532 by default: the reference derives it from
+// update_interval = 0.0333 s), written at the write pointer with wrap-around, and the ring is marked full once
+// frames_added * hop >= ring_len.
+__global__ void ring_push_kernel(float* __restrict__ ring, int* __restrict__ wptr, int* __restrict__ frames,
+                                 unsigned char* __restrict__ ready, const float* __restrict__ samples,
+                                 int n_in, int hop, int ring_len) {
+    const int s = blockIdx.x;
+    const int w0 = wptr[s];
+    float* r = ring + (int64_t)s * ring_len;
+    const float* in = samples + (int64_t)s * n_in;
+    for (int i = threadIdx.x; i < hop; i += blockDim.x) {
+        int p = w0 + i;
+        p -= p >= ring_len ? ring_len : 0;
+        r[p] = i < n_in ? in[i] : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int w = w0 + hop;
+        w -= w >= ring_len ? ring_len : 0;
+        wptr[s] = w;
+        const int f = frames[s] + 1;
+        frames[s] = f;
+        if ((int64_t)f * hop >= ring_len) ready[s] = 1;
+    }
+}
+
+int launch_ring_push(Context* c, const float* samples, int64_t n_per_stream, void* stream) {
+    hipLaunchKernelGGL(ring_push_kernel, dim3((unsigned)c->n_streams), dim3(256), 0, (hipStream_t)stream, c->ring,
+                       c->ring_wptr, c->ring_frames, c->ring_ready, samples, (int)n_per_stream, c->ring_hop,
+                       (int)c->ring_len);
+    HIP_TRY(hipGetLastError());
     return KM_OK;
 }
 
