@@ -49,11 +49,13 @@ int km_finalize(km_handle h, void* stream) {
 
 static int free_ws(Context* c) {
     if (c->ws_zemo) HIP_TRY(hipFree(c->ws_zemo));
+    if (c->ws_zemo_win) HIP_TRY(hipFree(c->ws_zemo_win));
     if (c->ws_melpow) HIP_TRY(hipFree(c->ws_melpow));
     if (c->ws_melmax) HIP_TRY(hipFree(c->ws_melmax));
     if (c->ws_mel) HIP_TRY(hipFree(c->ws_mel));
     if (c->ws_short) HIP_TRY(hipFree(c->ws_short));
-    c->ws_zemo = c->ws_melpow = c->ws_mel = c->ws_short = nullptr;
+    if (c->ws_generic) HIP_TRY(hipFree(c->ws_generic));
+    c->ws_zemo = c->ws_zemo_win = c->ws_melpow = c->ws_mel = c->ws_short = c->ws_generic = nullptr;
     c->ws_melmax = nullptr;
     c->ws_windows = c->ws_samples = c->ws_frames = 0;
     return KM_OK;
@@ -69,18 +71,22 @@ int km_reserve(km_handle h, int64_t max_windows, int64_t max_samples) {
         if (p->cfg.n_mels > max_mels) max_mels = p->cfg.n_mels;
     }
     const int64_t frames = max_samples > 0 ? 1 + max_samples / min_hop : 0;
-    if (max_windows <= c->ws_windows && frames <= c->ws_frames) return KM_OK;
+    const bool need_generic = c->host_finalized && !c->fused_ok;
+    if (max_windows <= c->ws_windows && frames <= c->ws_frames && (c->ws_generic || !need_generic)) return KM_OK;
     const int64_t W = max_windows > c->ws_windows ? max_windows : c->ws_windows;
     const int64_t F = frames > c->ws_frames ? frames : c->ws_frames;
     const int64_t S = max_samples > c->ws_samples ? max_samples : c->ws_samples;
     if (int rc = free_ws(c)) return rc;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_zemo), (size_t)W * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_zemo_win), (size_t)W * sizeof(float)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_melmax), (size_t)W * sizeof(unsigned)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_short), (size_t)W * 3 * max_mels * sizeof(float)));
     if (F > 0) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_melpow), (size_t)W * F * max_mels * sizeof(float)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_mel), (size_t)W * F * max_mels * sizeof(float)));
     }
+    if (need_generic)
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_generic), (size_t)W * generic_ws_floats(c) * sizeof(float)));
     c->ws_windows = W; c->ws_frames = F; c->ws_samples = S;
     c->melmax_dirty = true;
     return KM_OK;
@@ -137,11 +143,13 @@ int km_core_forward(km_handle h, const float* mel_dev, int64_t B, int64_t T_in, 
         return fail(KM_ERR_INVALID_ARG, "km_core_forward: bad argument");
     if (!aligned16(mel_dev) || !aligned16(mel_short_dev))
         return fail(KM_ERR_INVALID_ARG, "km_core_forward: mel pointers must be 16-byte aligned");
-    if (!c->fused_ok)
-        return fail(KM_ERR_UNSUPPORTED, "no kernel for d_model=%d, mel_sequence_length=%d, heads=%d", c->d, c->T, c->H);
     if (B > c->ws_windows) return fail(KM_ERR_WORKSPACE, "workspace holds %lld windows, need %lld: call km_reserve",
                                        (long long)c->ws_windows, (long long)B);
     if (int rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, stream)) return rc;
+    if (!c->fused_ok) {
+        if (!c->ws_generic) return fail(KM_ERR_WORKSPACE, "generic workspace missing: call km_reserve after km_finalize");
+        return launch_core_generic(c, mel_dev, B, T_in, mel_short_dev, c->ws_zemo, out_dev, raw_dev, attn_mel_dev, stream);
+    }
     return launch_core_fused(c, mel_dev, B, T_in, mel_short_dev, c->ws_zemo, out_dev, raw_dev, attn_mel_dev,
                              nullptr, 1, stream);
 }
@@ -160,8 +168,10 @@ int km_core_forward_z(km_handle h, const float* mel_dev, int64_t B, int64_t T_in
         return fail(KM_ERR_INVALID_ARG, "km_core_forward_z: bad argument");
     if (!aligned16(mel_dev) || !aligned16(mel_short_dev))
         return fail(KM_ERR_INVALID_ARG, "km_core_forward_z: mel pointers must be 16-byte aligned");
-    if (!c->fused_ok)
-        return fail(KM_ERR_UNSUPPORTED, "no kernel for d_model=%d, mel_sequence_length=%d, heads=%d", c->d, c->T, c->H);
+    if (!c->fused_ok) {
+        if (B > c->ws_windows || !c->ws_generic) return fail(KM_ERR_WORKSPACE, "generic workspace missing or too small: call km_reserve after km_finalize");
+        return launch_core_generic(c, mel_dev, B, T_in, mel_short_dev, z_dev, out_dev, raw_dev, attn_mel_dev, stream);
+    }
     return launch_core_fused(c, mel_dev, B, T_in, mel_short_dev, z_dev, out_dev, raw_dev, attn_mel_dev, nullptr, 1, stream);
 }
 
@@ -177,12 +187,18 @@ int km_forward_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L, 
     Context* c = h;
     if (!audio_dev || !emotion_dev || !out_dev || B <= 0 || L <= 0)
         return fail(KM_ERR_INVALID_ARG, "km_forward_audio: bad argument");
-    if (!c->fused_ok)
-        return fail(KM_ERR_UNSUPPORTED, "no kernel for d_model=%d, mel_sequence_length=%d, heads=%d", c->d, c->T, c->H);
     const int64_t n_frames = 1 + L / c->cfg.mel.hop_length;
     if (B > c->ws_windows || n_frames > c->ws_frames)
         return fail(KM_ERR_WORKSPACE, "workspace too small for %lld windows x %lld samples: call km_reserve",
                     (long long)B, (long long)L);
+    if (!c->fused_ok) {     // generic shapes: staged front end, GEMM-chain core, stand-alone EMA
+        if (!c->ws_generic) return fail(KM_ERR_WORKSPACE, "generic workspace missing: call km_reserve after km_finalize");
+        if (int rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, stream)) return rc;
+        if (int rc = launch_mel(c, c->mel_plans[0], audio_dev, B, L, 0, c->ws_mel, c->ws_short, stream)) return rc;
+        if (int rc = launch_core_generic(c, c->ws_mel, B, n_frames, c->ws_short, c->ws_zemo, out_dev, nullptr, nullptr, stream)) return rc;
+        if (state_dev) return launch_smooth(c, out_dev, state_dev, B, first, stream);
+        return KM_OK;
+    }
     // three launches: emotion logits, power-mel + window maxima, fused core (dB conversion on load)
     hipStream_t st = (hipStream_t)stream;
     const bool tm = c->stage_timing;
@@ -316,8 +332,8 @@ int km_sequence_forward(km_handle h, const float* audio_dev, int64_t B, int64_t 
     Context* c = h;
     if (!audio_dev || !emotion_dev || !out_dev || B <= 0 || L <= 0 || stride_frames <= 0)
         return fail(KM_ERR_INVALID_ARG, "km_sequence_forward: bad argument");
-    if (!c->fused_ok)
-        return fail(KM_ERR_UNSUPPORTED, "no kernel for d_model=%d, mel_sequence_length=%d, heads=%d", c->d, c->T, c->H);
+    if (!c->fused_ok && !c->ws_generic)
+        return fail(KM_ERR_WORKSPACE, "generic workspace missing: call km_reserve after km_finalize");
     const int hop = c->cfg.mel.hop_length;
     const int64_t N = km_sequence_num_outputs(h, L, stride_frames);
     const int64_t W = (int64_t)c->T * hop;                 // window_samples (sequential_dual_stream_model.py:54)
@@ -332,9 +348,17 @@ int km_sequence_forward(km_handle h, const float* audio_dev, int64_t B, int64_t 
     const int64_t total = B * N, tile = c->ws_windows;
     for (int64_t w0 = 0; w0 < total; w0 += tile) {
         const int64_t nw = (total - w0) < tile ? (total - w0) : tile;
-        if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, nw, W, stream, L, step, w0, (int)N)) return rc;
-        if (int rc = launch_core_fused_db(c, c->mel_plans[0], nw, n_frames, c->ws_zemo, out_dev + w0 * c->NB, nullptr, 1,
-                                          stream, w0, (int)N)) return rc;
+        if (c->fused_ok) {
+            if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, nw, W, stream, L, step, w0, (int)N)) return rc;
+            if (int rc = launch_core_fused_db(c, c->mel_plans[0], nw, n_frames, c->ws_zemo, out_dev + w0 * c->NB, nullptr, 1,
+                                              stream, w0, (int)N)) return rc;
+        } else {
+            // generic shapes: staged log-mel, per-window logits gathered from the per-clip ones, GEMM-chain core
+            if (int rc = launch_mel(c, c->mel_plans[0], audio_dev, nw, W, 0, c->ws_mel, c->ws_short, stream, L, step, w0, (int)N)) return rc;
+            if (int rc = launch_gather_clip_logits(c, c->ws_zemo, c->ws_zemo_win, nw, w0, (int)N, stream)) return rc;
+            if (int rc = launch_core_generic(c, c->ws_mel, nw, n_frames, c->ws_short, c->ws_zemo_win, out_dev + w0 * c->NB,
+                                             nullptr, nullptr, stream)) return rc;
+        }
     }
     if (smooth) return launch_ema_scan(c, out_dev, B, N, stream);
     return KM_OK;

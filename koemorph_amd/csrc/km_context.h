@@ -65,10 +65,12 @@ struct Context {
     // workspace (device)
     int64_t ws_windows = 0, ws_samples = 0;
     float* ws_zemo = nullptr;      // (windows)             emotion-stream logit
+    float* ws_zemo_win = nullptr;  // (windows)             per-window copy of per-clip logits (generic sequence mode)
     float* ws_melpow = nullptr;    // (windows, frames, 80) power-mel
     unsigned* ws_melmax = nullptr; // (windows)             max power (float bits)
     float* ws_mel = nullptr;       // (windows, frames, 80) log-mel
     float* ws_short = nullptr;     // (windows, 3, 80)
+    float* ws_generic = nullptr;   // generic (non-fused) core intermediates, generic_ws_floats() per window
     int64_t ws_frames = 0;
     // streaming state (km_stream_*): device-resident per-stream audio rings (MelAudioBuffer semantics)
     int64_t n_streams = 0, ring_len = 0;
@@ -106,13 +108,20 @@ int launch_core_fused_db(Context* c, MelPlan* p, int64_t B, int64_t n_frames, co
 int launch_ema_scan(Context* c, float* x, int64_t B, int64_t N, void* stream);
 int launch_smooth(Context* c, float* x, float* state, int64_t B, int first, void* stream);
 
+// km_generic.hip
+int64_t generic_ws_floats(Context* c);
+int launch_gather_clip_logits(Context* c, const float* zclip, float* zwin, int64_t nw, int64_t w0, int wins_per_clip, void* stream);
+int launch_core_generic(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short, const float* zemo,
+                        float* out, float* raw, float* attn, void* stream);
+
 // km_mel.hip
 int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, void* stream,
                      int64_t clip_len = 0, int64_t win_step = 0, int64_t win0 = 0, int wins_per_clip = 1,
                      const int* ring_start = nullptr, const unsigned char* ready = nullptr);
 int launch_ring_push(Context* c, const float* samples, int64_t n_per_stream, void* stream);
 int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, int64_t out_frames,
-               float* mel_long, float* mel_short, void* stream);
+               float* mel_long, float* mel_short, void* stream, int64_t clip_len = 0, int64_t win_step = 0,
+               int64_t win0 = 0, int wins_per_clip = 1);
 int upload_mel_plan(MelPlan* p);
 void free_mel_plan(MelPlan* p);
 

@@ -168,6 +168,8 @@ int finalize_host(Context* c) {
     put(c, "w2", std::vector<float>(P(c, "blendshape_decoder.3.weight")));
     put(c, "b2", std::vector<float>(P(c, "blendshape_decoder.3.bias")));
     put(c, "wsum", std::move(wsum));
+    put(c, "wce_raw", std::vector<float>(P(c, "mel_channel_encoder.weight")));          // (d, KT), generic path
+    put(c, "wv_raw", to_f(Wv));                                                           // (d, d), generic path
 
     // ---- packed MFMA operand images for the fused gfx950 kernel -------------------------
     // v_mfma_f32_16x16x4_f32 operand maps: lane l = 16*g + j supplies A[i=j][k=g] and B[k=g][n=j].

@@ -467,8 +467,9 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
 }
 
 int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, int64_t out_frames,
-               float* mel_long, float* mel_short, void* stream) {
-    if (int rc = launch_mel_power(c, p, audio, B, L, stream, 0, 0, 0, 1)) return rc;
+               float* mel_long, float* mel_short, void* stream, int64_t clip_len, int64_t win_step, int64_t win0,
+               int wins_per_clip) {
+    if (int rc = launch_mel_power(c, p, audio, B, L, stream, clip_len, win_step, win0, wins_per_clip)) return rc;
     const km_mel_config& m = p->cfg;
     const int64_t n_frames = 1 + L / m.hop_length;
     c->melmax_dirty = true;     // mel_log_kernel leaves the maxima in place

@@ -102,6 +102,7 @@ class Engine:
         self.emotion_dim, self.num_blendshapes, self.n_mels = emotion_dim, num_blendshapes, num_mel_channels
         self._reserved: Tuple[int, int] = (0, 0)
         self.device = None
+        self.fused = (d_model == 256 and num_heads == 8 and mel_sequence_length == 256 and num_mel_channels == 80)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -155,6 +156,7 @@ class Engine:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         with torch.cuda.device(self.device):
             check(self._lib.km_finalize(self._h, _stream_ptr(self.device)))
+        self._reserved = (0, 0)        # the generic-path workspace depends on the finalized configuration
 
     def reserve(self, max_windows: int, max_samples: int = 0) -> None:
         if max_windows <= self._reserved[0] and max_samples <= self._reserved[1]:

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import CORE_CASES_D256, golden_case
+from conftest import CORE_CASES_D256, CORE_CASES_OTHER, golden_case
 from koemorph_amd import synth
 from koemorph_amd.engine import Engine
 from oracle import core
@@ -94,12 +94,33 @@ def test_core_error_paths():
         e.core_forward(dev(mel)[0], dev(short), dev(emo))                       # bad rank
     with pytest.raises(ValueError):
         e.core_forward(dev(mel), dev(short), dev(emo)[:, :100])                 # bad emotion dim
-    e512 = Engine(d_model=512, mel_sequence_length=512)
-    e512.load_state_dict(synth.make_core_params(2, 512, 512))
-    e512.finalize()
-    m5, s5, e5 = synth.make_core_inputs(1, 2, 513)
-    with pytest.raises(KoeMorphError, match="no kernel"):
-        e512.core_forward(dev(m5), dev(s5), dev(e5))
+
+
+@pytest.mark.parametrize("name", CORE_CASES_OTHER)
+def test_generic_shapes_match_reference_golden(name):
+    """BASELINE config 4 (d_model 512, window 512, 8 / 16 heads) and the small d=64 configuration run the
+    shape-generic GEMM-chain path (km_generic.hip)."""
+    c, params, (mel, short, emo), g = golden_case(name)
+    e = engine_for(params, d_model=c["d"], num_heads=c["H"], mel_sequence_length=c["T"])
+    assert not e.fused
+    o = e.core_forward(dev(mel), dev(short), dev(emo), return_attention=True)
+    err = np.abs(o["blendshapes"].cpu().numpy() - g["blendshapes"]).max()
+    assert err < TOL, err
+    np.testing.assert_allclose(o["mel_attention_weights"].cpu().numpy(), g["mel_attention_weights"], atol=TOL)
+    raw = o["raw"].cpu().numpy()
+    np.testing.assert_allclose(raw[:, synth.MOUTH_INDICES], g["mel_blendshapes"][:, synth.MOUTH_INDICES], atol=2e-5)
+    np.testing.assert_allclose(raw[:, synth.EXPRESSION_INDICES], g["emotion_blendshapes"][:, synth.EXPRESSION_INDICES], atol=2e-5)
+
+
+def test_generic_path_full_batch_against_oracle():
+    """BASELINE config 4 at batch size, plus the zero-pad (T_in < T) and truncate (T_in > T) branches."""
+    params = synth.make_core_params(88, 512, 512, style="trained")
+    e = engine_for(params, d_model=512, num_heads=8, mel_sequence_length=512)
+    for B, t_in in ((64, 513), (5, 300), (3, 600)):
+        mel, short, emo = synth.make_core_inputs(700 + B, B, t_in)
+        ref = core.core_forward_np(params, mel, short, emo, num_heads=8, mel_sequence_length=512)["blendshapes"]
+        got = e.core_forward(dev(mel), dev(short), dev(emo))["blendshapes"].cpu().numpy()
+        assert np.abs(got - ref).max() < TOL
 
 
 def test_smooth_kernel_matches_oracle():

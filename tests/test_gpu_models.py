@@ -177,3 +177,31 @@ def test_realtime_path_and_rt_loop(tmp_path):
     assert sent == len(lines) == 270 - 255
     rec = json.loads(lines[-1])
     assert len(rec["blendshapes"]) == 52 and all(0.0 <= v <= 1.0 for v in rec["blendshapes"])
+
+
+def test_60fps_long_context_configuration_end_to_end():
+    """BASELINE config 4: target_fps 60 (hop 266), window 512 frames, d_model 512 -- whole model from audio,
+    and the sequential wrapper, on the shape-generic path."""
+    params = synth.make_core_params(55, 512, 512, style="trained")
+    kw = dict(d_model=512, num_heads=8, target_fps=60, mel_sequence_length=512)
+    m = SimplifiedDualStreamModel(**kw).cuda().eval()
+    m.load_state_dict(full_state(params))
+    assert m.hop_length == 266
+    orc = models.SimplifiedOracle(params, num_heads=8, mel_sequence_length=512, target_fps=60)
+    for i in range(2):
+        audio = synth.make_audio(97 + i, 2, 512 * 266)
+        emo = synth.normal(98 + i, (2, 256))
+        want = orc.forward(audio, emo)["blendshapes"]
+        got = m(dev(audio), emotion_features=dev(emo))["blendshapes"].cpu().numpy()
+        assert np.abs(got - want).max() < 5e-6
+    long, short = m.extract_mel_features(dev(audio))
+    assert long.shape == (2, 513, 80)
+    seq = SequentialDualStreamModel(stride_frames=2, **kw).cuda().eval()
+    seq.load_state_dict(full_state(params))
+    sorc = models.SequentialOracle(params, num_heads=8, mel_sequence_length=512, target_fps=60, stride_frames=2)
+    audio = synth.make_audio(99, 2, 512 * 266 + 266 * 6 + 50)
+    emo = synth.normal(100, (2, 256))
+    w = sorc.forward(audio, emo)
+    g = seq(dev(audio), emotion_features=dev(emo))
+    assert g["num_frames"] == w["num_frames"] == 4 and g["fps"] == 60
+    assert np.abs(g["blendshapes"].cpu().numpy() - w["blendshapes"]).max() < 5e-6
