@@ -183,6 +183,27 @@ int km_sequence_forward(km_handle h, const float* audio_dev, int64_t B, int64_t 
                         const float* emotion_dev, int32_t stride_frames, int32_t smooth,
                         float* out_dev, void* stream);
 
+/* ---- legacy single-stream variant --------------------------------------------------------------------
+ * SimplifiedKoeMorphModel (src/model/simplified_model.py:12-156), used by the reference's src/train.py,
+ * scripts/rt_simplified.py and scripts/test_model.py: same librosa-style log-mel front end, a two-layer
+ * per-frame audio encoder, ONE nn.MultiheadAttention with 52 learnable blendshape queries over the T_mel
+ * encoded frames (the literal "52 x 256" attention of the north star), a 3-layer decoder + sigmoid per query
+ * row and a mean over the 52 rows.  State-dict keys: audio_encoder.{0,3}.*, attention.*, decoder.{0,3,6}.*,
+ * blendshape_queries.  The handle is used with km_load_param / km_finalize / km_reserve / km_destroy as usual.
+ *   km_legacy_forward      audio_dev (B, L)            -> out_dev (B, 52)   (forward, :114-149)
+ *   km_legacy_forward_mel  mel_dev (B, T_mel, 80)      -> out_dev (B, 52)   (everything after extract_mel_features) */
+typedef struct km_legacy_config {
+    int32_t abi_version;       /* KM_ABI_VERSION */
+    int32_t d_model;           /* 256 */
+    int32_t num_heads;         /* 8 */
+    int32_t decoder_hidden;    /* 128 */
+    int32_t num_blendshapes;   /* 52 */
+    km_mel_config mel;
+} km_legacy_config;
+int km_legacy_create(const km_legacy_config* cfg, km_handle* out);
+int km_legacy_forward(km_handle h, const float* audio_dev, int64_t B, int64_t L, float* out_dev, void* stream);
+int km_legacy_forward_mel(km_handle h, const float* mel_dev, int64_t B, int64_t T_mel, float* out_dev, void* stream);
+
 /* ---- streaming: many concurrent speaker streams, state resident on the device -------------------------
  * Replaces, for all streams of this GPU at once, MelAudioBuffer.add_audio_frame / get_current_audio
  * (src/features/mel_sliding_window.py:70-140), MelSlidingWindowExtractor.process_audio_frame (:252-324) and

@@ -35,6 +35,11 @@ class KMConfig(C.Structure):
                 ("num_blendshapes", C.c_int32), ("temperature", C.c_float), ("mel", KMMelConfig)]
 
 
+class KMLegacyConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("d_model", C.c_int32), ("num_heads", C.c_int32),
+                ("decoder_hidden", C.c_int32), ("num_blendshapes", C.c_int32), ("mel", KMMelConfig)]
+
+
 KM_MEL_SLANEY, KM_MEL_HTK = 0, 1
 KM_PAD_CONSTANT, KM_PAD_REFLECT = 0, 1
 KM_LOG_DB_MAX, KM_LOG_LN_EPS = 0, 1
@@ -71,6 +76,9 @@ SIGNATURES = {
     "km_forward_audio": (C.c_int, [_h, _p, _i64, _i64, _p, _p, _p, _i32, _p]),
     "km_sequence_num_outputs": (_i64, [_h, _i64, _i32]),
     "km_sequence_forward": (C.c_int, [_h, _p, _i64, _i64, _p, _i32, _i32, _p, _p]),
+    "km_legacy_create": (C.c_int, [C.POINTER(KMLegacyConfig), C.POINTER(_h)]),
+    "km_legacy_forward": (C.c_int, [_h, _p, _i64, _i64, _p, _p]),
+    "km_legacy_forward_mel": (C.c_int, [_h, _p, _i64, _i64, _p, _p]),
     "km_stream_create": (C.c_int, [_h, _i64, C.c_double, C.c_double, C.POINTER(KMMelConfig)]),
     "km_stream_push": (C.c_int, [_h, _p, _i64, _p]),
     "km_stream_tick": (C.c_int, [_h, _p, _p, _p, _p]),

@@ -23,6 +23,12 @@ static int need_ready(Context* c) {
     return KM_OK;
 }
 
+static int need_dual(Context* c) {
+    if (int rc = need_ready(c)) return rc;
+    if (c->kind != 0) return fail(KM_ERR_INVALID_ARG, "this entry point needs a dual-stream handle (km_create), not a legacy one");
+    return KM_OK;
+}
+
 extern "C" {
 
 int km_finalize(km_handle h, void* stream) {
@@ -85,8 +91,10 @@ int km_reserve(km_handle h, int64_t max_windows, int64_t max_samples) {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_melpow), (size_t)W * F * max_mels * sizeof(float)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_mel), (size_t)W * F * max_mels * sizeof(float)));
     }
-    if (need_generic)
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_generic), (size_t)W * generic_ws_floats(c) * sizeof(float)));
+    if (need_generic) {
+        const int64_t per = c->kind == 1 ? legacy_ws_floats(c, F > 0 ? F : 1) : generic_ws_floats(c);
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_generic), (size_t)W * per * sizeof(float)));
+    }
     c->ws_windows = W; c->ws_frames = F; c->ws_samples = S;
     c->melmax_dirty = true;
     return KM_OK;
@@ -137,7 +145,7 @@ int km_mel_extract(km_handle h, const km_mel_config* cfg, const float* audio_dev
 
 int km_core_forward(km_handle h, const float* mel_dev, int64_t B, int64_t T_in, const float* mel_short_dev,
                     const float* emotion_dev, float* out_dev, float* raw_dev, float* attn_mel_dev, void* stream) {
-    if (int rc = need_ready(h)) return rc;
+    if (int rc = need_dual(h)) return rc;
     Context* c = h;
     if (!mel_dev || !mel_short_dev || !emotion_dev || !out_dev || B <= 0 || T_in <= 0)
         return fail(KM_ERR_INVALID_ARG, "km_core_forward: bad argument");
@@ -155,14 +163,14 @@ int km_core_forward(km_handle h, const float* mel_dev, int64_t B, int64_t T_in, 
 }
 
 int km_emotion_logit(km_handle h, const float* emotion_dev, int64_t B, float* z_dev, void* stream) {
-    if (int rc = need_ready(h)) return rc;
+    if (int rc = need_dual(h)) return rc;
     if (!emotion_dev || !z_dev || B <= 0) return fail(KM_ERR_INVALID_ARG, "km_emotion_logit: bad argument");
     return launch_emotion(h, emotion_dev, B, z_dev, stream);
 }
 
 int km_core_forward_z(km_handle h, const float* mel_dev, int64_t B, int64_t T_in, const float* mel_short_dev,
                       const float* z_dev, float* out_dev, float* raw_dev, float* attn_mel_dev, void* stream) {
-    if (int rc = need_ready(h)) return rc;
+    if (int rc = need_dual(h)) return rc;
     Context* c = h;
     if (!mel_dev || !mel_short_dev || !z_dev || !out_dev || B <= 0 || T_in <= 0)
         return fail(KM_ERR_INVALID_ARG, "km_core_forward_z: bad argument");
@@ -175,6 +183,30 @@ int km_core_forward_z(km_handle h, const float* mel_dev, int64_t B, int64_t T_in
     return launch_core_fused(c, mel_dev, B, T_in, mel_short_dev, z_dev, out_dev, raw_dev, attn_mel_dev, nullptr, 1, stream);
 }
 
+int km_legacy_forward_mel(km_handle h, const float* mel_dev, int64_t B, int64_t T_mel, float* out_dev, void* stream) {
+    if (int rc = need_ready(h)) return rc;
+    Context* c = h;
+    if (c->kind != 1) return fail(KM_ERR_INVALID_ARG, "not a legacy handle (km_legacy_create)");
+    if (!mel_dev || !out_dev || B <= 0 || T_mel <= 0) return fail(KM_ERR_INVALID_ARG, "km_legacy_forward_mel: bad argument");
+    if (B > c->ws_windows || T_mel > c->ws_frames || !c->ws_generic)
+        return fail(KM_ERR_WORKSPACE, "workspace too small for %lld windows x %lld frames: call km_reserve",
+                    (long long)B, (long long)T_mel);
+    return launch_legacy(c, mel_dev, B, T_mel, out_dev, stream);
+}
+
+int km_legacy_forward(km_handle h, const float* audio_dev, int64_t B, int64_t L, float* out_dev, void* stream) {
+    if (int rc = need_ready(h)) return rc;
+    Context* c = h;
+    if (c->kind != 1) return fail(KM_ERR_INVALID_ARG, "not a legacy handle (km_legacy_create)");
+    if (!audio_dev || !out_dev || B <= 0 || L <= 0) return fail(KM_ERR_INVALID_ARG, "km_legacy_forward: bad argument");
+    const int64_t n_frames = 1 + L / c->cfg.mel.hop_length;
+    if (B > c->ws_windows || n_frames > c->ws_frames || !c->ws_generic)
+        return fail(KM_ERR_WORKSPACE, "workspace too small for %lld windows x %lld samples: call km_reserve",
+                    (long long)B, (long long)L);
+    if (int rc = launch_mel(c, c->mel_plans[0], audio_dev, B, L, 0, c->ws_mel, nullptr, stream)) return rc;
+    return launch_legacy(c, c->ws_mel, B, n_frames, out_dev, stream);
+}
+
 int km_smooth(km_handle h, float* x_dev, float* state_dev, int64_t B, int32_t first, void* stream) {
     if (int rc = need_ready(h)) return rc;
     if (!x_dev || !state_dev || B <= 0) return fail(KM_ERR_INVALID_ARG, "km_smooth: bad argument");
@@ -183,7 +215,7 @@ int km_smooth(km_handle h, float* x_dev, float* state_dev, int64_t B, int32_t fi
 
 int km_forward_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L, const float* emotion_dev,
                      float* out_dev, float* state_dev, int32_t first, void* stream) {
-    if (int rc = need_ready(h)) return rc;
+    if (int rc = need_dual(h)) return rc;
     Context* c = h;
     if (!audio_dev || !emotion_dev || !out_dev || B <= 0 || L <= 0)
         return fail(KM_ERR_INVALID_ARG, "km_forward_audio: bad argument");
@@ -222,7 +254,7 @@ static int free_streams(Context* c) {
 }
 
 int km_stream_reset(km_handle h, void* stream) {
-    if (int rc = need_ready(h)) return rc;
+    if (int rc = need_dual(h)) return rc;
     Context* c = h;
     if (c->n_streams <= 0) return fail(KM_ERR_INVALID_ARG, "km_stream_reset: no streams (km_stream_create first)");
     hipStream_t st = (hipStream_t)stream;
@@ -237,7 +269,7 @@ int km_stream_reset(km_handle h, void* stream) {
 
 int km_stream_create(km_handle h, int64_t n_streams, double context_window_s, double update_interval_s,
                      const km_mel_config* mel_cfg) {
-    if (int rc = need_ready(h)) return rc;
+    if (int rc = need_dual(h)) return rc;
     Context* c = h;
     if (n_streams <= 0 || !(context_window_s > 0) || !(update_interval_s > 0) || !mel_cfg)
         return fail(KM_ERR_INVALID_ARG, "km_stream_create: bad argument");
@@ -266,7 +298,7 @@ int km_stream_create(km_handle h, int64_t n_streams, double context_window_s, do
 }
 
 int km_stream_push(km_handle h, const float* samples_dev, int64_t n_per_stream, void* stream) {
-    if (int rc = need_ready(h)) return rc;
+    if (int rc = need_dual(h)) return rc;
     Context* c = h;
     if (c->n_streams <= 0) return fail(KM_ERR_INVALID_ARG, "km_stream_push: no streams (km_stream_create first)");
     if (!samples_dev) return fail(KM_ERR_INVALID_ARG, "km_stream_push: NULL samples");
@@ -277,7 +309,7 @@ int km_stream_push(km_handle h, const float* samples_dev, int64_t n_per_stream, 
 }
 
 int km_stream_tick(km_handle h, const float* emotion_dev, float* out_dev, uint8_t* ready_dev, void* stream) {
-    if (int rc = need_ready(h)) return rc;
+    if (int rc = need_dual(h)) return rc;
     Context* c = h;
     if (c->n_streams <= 0) return fail(KM_ERR_INVALID_ARG, "km_stream_tick: no streams (km_stream_create first)");
     if (!emotion_dev || !out_dev) return fail(KM_ERR_INVALID_ARG, "km_stream_tick: NULL argument");
@@ -328,7 +360,7 @@ int64_t km_sequence_num_outputs(km_handle h, int64_t L, int32_t stride_frames) {
 
 int km_sequence_forward(km_handle h, const float* audio_dev, int64_t B, int64_t L, const float* emotion_dev,
                         int32_t stride_frames, int32_t smooth, float* out_dev, void* stream) {
-    if (int rc = need_ready(h)) return rc;
+    if (int rc = need_dual(h)) return rc;
     Context* c = h;
     if (!audio_dev || !emotion_dev || !out_dev || B <= 0 || L <= 0 || stride_frames <= 0)
         return fail(KM_ERR_INVALID_ARG, "km_sequence_forward: bad argument");

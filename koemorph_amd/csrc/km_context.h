@@ -50,6 +50,8 @@ struct MelPlan {
 
 struct Context {
     km_config cfg{};
+    int kind = 0;                                // 0 dual-stream production model, 1 legacy SimplifiedKoeMorphModel
+    int legacy_hidden = 128;
     int d = 0, H = 0, hd = 0, T = 0, KT = 0, ED = 0, DH = 0, NB = 0, NK = 0;
     std::map<std::string, HostParam> params;     // reference state-dict tensors (fp32 masters)
     std::vector<std::string> param_order;
@@ -110,6 +112,9 @@ int launch_smooth(Context* c, float* x, float* state, int64_t B, int first, void
 
 // km_generic.hip
 int64_t generic_ws_floats(Context* c);
+int64_t legacy_ws_floats(Context* c, int64_t frames);
+int finalize_host_legacy(Context* c);
+int launch_legacy(Context* c, const float* mel, int64_t B, int64_t T_mel, float* out, void* stream);
 int launch_gather_clip_logits(Context* c, const float* zclip, float* zwin, int64_t nw, int64_t w0, int wins_per_clip, void* stream);
 int launch_core_generic(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short, const float* zemo,
                         float* out, float* raw, float* attn, void* stream);

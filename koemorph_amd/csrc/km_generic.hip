@@ -163,6 +163,34 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
     if (lane + 64 < w) p[lane + 64] = eb * inv;
 }
 
+// softmax over rows of any width, one wave per row (three passes over the row, which sits in L2)
+__global__ __launch_bounds__(256) void softmax_rows_wide_kernel(float* __restrict__ x, int64_t rows, int w) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* p = x + row * w;
+    float m = -INFINITY;
+    for (int i = lane; i < w; i += 64) m = fmaxf(m, p[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+    for (int i = lane; i < w; i += 64) { const float e = expf(p[i] - m); p[i] = e; s += e; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float inv = 1.0f / s;
+    for (int i = lane; i < w; i += 64) p[i] *= inv;
+}
+
+// out[b][j] = mean over the NQ query rows of sigmoid(x[b][q][j])   (simplified_model.py:72,147)
+__global__ __launch_bounds__(64) void sigmoid_mean_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int NQ, int NB) {
+    const int b = blockIdx.x, j = threadIdx.x;
+    if (j >= NB) return;
+    const float* p = x + (int64_t)b * NQ * NB + j;
+    float s = 0.f;
+    for (int q = 0; q < NQ; ++q) s += 1.0f / (1.0f + expf(-p[(int64_t)q * NB]));
+    out[(int64_t)b * NB + j] = s / NQ;
+}
+
 // head-averaged attention weights: (B, H, 28, 80) -> (B, 28, 80)
 __global__ void head_mean_kernel(const float* __restrict__ p, float* __restrict__ out, int64_t B, int H, int per) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -276,6 +304,67 @@ int launch_core_generic(Context* c, const float* mel, int64_t B, int64_t T_in, c
     if (int rc = launch_gemm(g, 1, stream)) return rc;
     hipLaunchKernelGGL(decoder_tail_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, Hd, DH, dv(c, "w2"),
                        dv(c, "b2"), zemo, dv(c, "wsum"), out, raw);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Legacy single-stream model (SimplifiedKoeMorphModel.forward, simplified_model.py:114-149), eval mode
+// ---------------------------------------------------------------------------------------------------------
+int64_t legacy_ws_floats(Context* c, int64_t F) {
+    const int64_t d = c->d, H = c->H, NQ = c->NB, hid = c->legacy_hidden;
+    return 4 * F * d /* E1, E, K, V */ + H * NQ * F /* S */ + 2 * NQ * d /* O, A1 */ + 2 * NQ * hid + NQ * NQ;
+}
+
+static GemmArgs lin(const float* A, int64_t a_rs, const float* W, int K, float* C, int64_t rows, int N, const float* bias, int relu) {
+    GemmArgs g{};      // C (rows x N) = A (rows x K) W^T (+ bias) with W stored (N x K) like nn.Linear
+    g.alpha = 1.f; g.batch2 = 1;
+    g.A = A; g.a_rs = a_rs; g.a_cs = 1;
+    g.B = W; g.b_rs = 1; g.b_cs = K;
+    g.C = C; g.c_rs = N; g.M = (int)rows; g.N = N; g.K = K; g.bias = bias; g.bias_mode = bias ? 1 : 0; g.relu = relu;
+    return g;
+}
+
+int launch_legacy(Context* c, const float* mel, int64_t B, int64_t Tm, float* out, void* stream) {
+    const int d = c->d, H = c->H, hd = c->hd, NQ = c->NB, hid = c->legacy_hidden, NKk = c->NK;
+    float* E1 = c->ws_generic;
+    float* E = E1 + B * Tm * d;
+    float* Kp = E + B * Tm * d;
+    float* Vp = Kp + B * Tm * d;
+    float* S = Vp + B * Tm * d;
+    float* O = S + B * H * NQ * Tm;
+    float* A1 = O + B * NQ * d;
+    float* D1 = A1 + B * NQ * d;
+    float* D2 = D1 + B * NQ * hid;
+    float* D3 = D2 + B * NQ * hid;
+    // audio_encoder: Linear(80,d) ReLU [Dropout] Linear(d,d) ReLU [Dropout]   (:44-51, :129)
+    if (int rc = launch_gemm(lin(mel, NKk, dv(c, "l_w0"), NKk, E1, B * Tm, d, dv(c, "l_b0"), 1), 1, stream)) return rc;
+    if (int rc = launch_gemm(lin(E1, d, dv(c, "l_w3"), d, E, B * Tm, d, dv(c, "l_b3"), 1), 1, stream)) return rc;
+    // nn.MultiheadAttention(query = 52 learnable rows, key = value = encoded frames)   (:136-141)
+    if (int rc = launch_gemm(lin(E, d, dv(c, "l_wk"), d, Kp, B * Tm, d, dv(c, "l_bk"), 0), 1, stream)) return rc;
+    if (int rc = launch_gemm(lin(E, d, dv(c, "l_wv"), d, Vp, B * Tm, d, dv(c, "l_bv"), 0), 1, stream)) return rc;
+    GemmArgs g{};
+    g.alpha = 1.f;
+    g.A = dv(c, "l_q"); g.a_rs = d; g.a_cs = 1; g.a_bs1 = 0; g.a_bs2 = hd;                       // Q_h (NQ x hd), pre-scaled
+    g.B = Kp; g.b_rs = 1; g.b_cs = d; g.b_bs1 = Tm * d; g.b_bs2 = hd;                           // K_h^T
+    g.C = S; g.c_rs = Tm; g.c_bs1 = (int64_t)H * NQ * Tm; g.c_bs2 = (int64_t)NQ * Tm;
+    g.M = NQ; g.N = (int)Tm; g.K = hd; g.batch2 = H;
+    if (int rc = launch_gemm(g, (int)(B * H), stream)) return rc;
+    hipLaunchKernelGGL(softmax_rows_wide_kernel, dim3((unsigned)((B * H * NQ + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S,
+                       B * H * NQ, (int)Tm);
+    g = GemmArgs{};
+    g.alpha = 1.f;
+    g.A = S; g.a_rs = Tm; g.a_cs = 1; g.a_bs1 = (int64_t)H * NQ * Tm; g.a_bs2 = (int64_t)NQ * Tm;
+    g.B = Vp; g.b_rs = d; g.b_cs = 1; g.b_bs1 = Tm * d; g.b_bs2 = hd;
+    g.C = O; g.c_rs = d; g.c_bs1 = (int64_t)NQ * d; g.c_bs2 = hd;
+    g.M = NQ; g.N = hd; g.K = (int)Tm; g.batch2 = H;
+    if (int rc = launch_gemm(g, (int)(B * H), stream)) return rc;
+    if (int rc = launch_gemm(lin(O, d, dv(c, "l_wo"), d, A1, B * NQ, d, dv(c, "l_bo"), 0), 1, stream)) return rc;
+    // decoder: Linear(d,hid) ReLU Linear(hid,hid) ReLU Linear(hid,52) Sigmoid, then mean over the query rows (:63-72, :144-147)
+    if (int rc = launch_gemm(lin(A1, d, dv(c, "l_d0w"), d, D1, B * NQ, hid, dv(c, "l_d0b"), 1), 1, stream)) return rc;
+    if (int rc = launch_gemm(lin(D1, hid, dv(c, "l_d3w"), hid, D2, B * NQ, hid, dv(c, "l_d3b"), 1), 1, stream)) return rc;
+    if (int rc = launch_gemm(lin(D2, hid, dv(c, "l_d6w"), hid, D3, B * NQ, NQ, dv(c, "l_d6b"), 0), 1, stream)) return rc;
+    hipLaunchKernelGGL(sigmoid_mean_rows_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, D3, out, NQ, NQ);
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }

@@ -102,9 +102,39 @@ static void fold_chain(const dvec& bin, const dvec& Wa, const dvec& ba, const dv
     for (int i = 0; i < DH; ++i) f[i] += b1[i];
 }
 
+// SimplifiedKoeMorphModel (simplified_model.py:44-77): the queries are input independent, so
+// Q = (blendshape_queries Wq^T + bq) / sqrt(hd) is precomputed; everything else keeps the reference's layers.
+int finalize_host_legacy(Context* c) {
+    const int d = c->d, hd = c->hd, NQ = c->NB;
+    const dvec inw = to_d(P(c, "attention.in_proj_weight")), inb = to_d(P(c, "attention.in_proj_bias"));
+    dvec Wq(inw.begin(), inw.begin() + (size_t)d * d);
+    dvec Q = mm(to_d(P(c, "blendshape_queries")), transpose(Wq, d, d), NQ, d, d);
+    const double scale = 1.0 / std::sqrt((double)hd);
+    for (int q = 0; q < NQ; ++q)
+        for (int i = 0; i < d; ++i) Q[(size_t)q * d + i] = (Q[(size_t)q * d + i] + inb[i]) * scale;
+    put(c, "l_q", to_f(Q));
+    put(c, "l_wk", std::vector<float>(P(c, "attention.in_proj_weight").begin() + (size_t)d * d,
+                                      P(c, "attention.in_proj_weight").begin() + (size_t)2 * d * d));
+    put(c, "l_wv", std::vector<float>(P(c, "attention.in_proj_weight").begin() + (size_t)2 * d * d,
+                                      P(c, "attention.in_proj_weight").end()));
+    put(c, "l_bk", std::vector<float>(P(c, "attention.in_proj_bias").begin() + d, P(c, "attention.in_proj_bias").begin() + 2 * d));
+    put(c, "l_bv", std::vector<float>(P(c, "attention.in_proj_bias").begin() + 2 * d, P(c, "attention.in_proj_bias").end()));
+    const char* raw[][2] = {{"l_w0", "audio_encoder.0.weight"}, {"l_b0", "audio_encoder.0.bias"},
+                            {"l_w3", "audio_encoder.3.weight"}, {"l_b3", "audio_encoder.3.bias"},
+                            {"l_wo", "attention.out_proj.weight"}, {"l_bo", "attention.out_proj.bias"},
+                            {"l_d0w", "decoder.0.weight"}, {"l_d0b", "decoder.0.bias"},
+                            {"l_d3w", "decoder.3.weight"}, {"l_d3b", "decoder.3.bias"},
+                            {"l_d6w", "decoder.6.weight"}, {"l_d6b", "decoder.6.bias"}};
+    for (auto& r : raw) put(c, r[0], std::vector<float>(P(c, r[1])));
+    c->fused_ok = false;
+    c->host_finalized = true;
+    return KM_OK;
+}
+
 int finalize_host(Context* c) {
     for (const auto& k : c->param_order)
         if (!c->params[k].loaded) return fail(KM_ERR_NOT_FINALIZED, "parameter '%s' was never loaded", k.c_str());
+    if (c->kind == 1) return finalize_host_legacy(c);
     const int d = c->d, H = c->H, hd = c->hd, KT = c->KT, ED = c->ED, DH = c->DH, NB = c->NB;
     const int NQ = kNumMouth;
 
@@ -375,6 +405,43 @@ int km_create(const km_config* cfg, km_handle* out) {
     expect(c, "smoothing_alpha", {});
     c->params["smoothing_alpha"].data[0] = 0.8f;
     c->params["smoothing_alpha"].loaded = true;
+    c->mel_plans.push_back(build_mel_plan(cfg->mel));
+    *out = c;
+    return KM_OK;
+}
+
+int km_legacy_create(const km_legacy_config* cfg, km_handle* out) {
+    if (!cfg || !out) return fail(KM_ERR_INVALID_ARG, "km_legacy_create: NULL argument");
+    if (cfg->abi_version != KM_ABI_VERSION) return fail(KM_ERR_INVALID_ARG, "km_legacy_config.abi_version %d != %d", cfg->abi_version, KM_ABI_VERSION);
+    if (cfg->d_model <= 0 || cfg->num_heads <= 0 || cfg->d_model % cfg->num_heads != 0)
+        return fail(KM_ERR_INVALID_ARG, "embed_dim %d must be divisible by num_heads %d", cfg->d_model, cfg->num_heads);
+    if (cfg->decoder_hidden <= 0 || cfg->num_blendshapes <= 0 || cfg->num_blendshapes > 64)
+        return fail(KM_ERR_INVALID_ARG, "bad decoder_hidden / num_blendshapes");
+    if (int rc = check_mel_cfg(cfg->mel)) return rc;
+    km_context* c = new km_context();
+    c->kind = 1;
+    c->cfg.abi_version = KM_ABI_VERSION; c->cfg.d_model = cfg->d_model; c->cfg.num_heads = cfg->num_heads;
+    c->cfg.num_mel_channels = cfg->mel.n_mels; c->cfg.num_blendshapes = cfg->num_blendshapes; c->cfg.mel = cfg->mel;
+    c->cfg.temperature = 1.0f;
+    c->d = cfg->d_model; c->H = cfg->num_heads; c->hd = c->d / c->H; c->NB = cfg->num_blendshapes; c->NK = cfg->mel.n_mels;
+    c->legacy_hidden = cfg->decoder_hidden;
+    const int64_t d = c->d, hid = cfg->decoder_hidden;
+    // state-dict layout of SimplifiedKoeMorphModel (simplified_model.py:44-77)
+    expect(c, "audio_encoder.0.weight", {d, c->NK});
+    expect(c, "audio_encoder.0.bias", {d});
+    expect(c, "audio_encoder.3.weight", {d, d});
+    expect(c, "audio_encoder.3.bias", {d});
+    expect(c, "attention.in_proj_weight", {3 * d, d});
+    expect(c, "attention.in_proj_bias", {3 * d});
+    expect(c, "attention.out_proj.weight", {d, d});
+    expect(c, "attention.out_proj.bias", {d});
+    expect(c, "decoder.0.weight", {hid, d});
+    expect(c, "decoder.0.bias", {hid});
+    expect(c, "decoder.3.weight", {hid, hid});
+    expect(c, "decoder.3.bias", {hid});
+    expect(c, "decoder.6.weight", {c->NB, hid});
+    expect(c, "decoder.6.bias", {c->NB});
+    expect(c, "blendshape_queries", {c->NB, d});
     c->mel_plans.push_back(build_mel_plan(cfg->mel));
     *out = c;
     return KM_OK;

@@ -3,6 +3,7 @@ from .dual_stream_attention import (DualStreamCrossAttention, MOUTH_INDICES, EXP
                                     ARKIT_BLENDSHAPES, MOUTH_BLENDSHAPES)
 from .simplified_dual_stream_model import SimplifiedDualStreamModel
 from .sequential_dual_stream_model import SequentialDualStreamModel
+from .simplified_model import SimplifiedKoeMorphModel
 
-__all__ = ["DualStreamCrossAttention", "SimplifiedDualStreamModel", "SequentialDualStreamModel",
+__all__ = ["DualStreamCrossAttention", "SimplifiedDualStreamModel", "SequentialDualStreamModel", "SimplifiedKoeMorphModel",
            "MOUTH_INDICES", "EXPRESSION_INDICES", "ARKIT_BLENDSHAPES", "MOUTH_BLENDSHAPES"]

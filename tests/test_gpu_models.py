@@ -205,3 +205,24 @@ def test_60fps_long_context_configuration_end_to_end():
     g = seq(dev(audio), emotion_features=dev(emo))
     assert g["num_frames"] == w["num_frames"] == 4 and g["fps"] == 60
     assert np.abs(g["blendshapes"].cpu().numpy() - w["blendshapes"]).max() < 5e-6
+
+
+def test_legacy_simplified_koemorph_model():
+    """the legacy single-stream model (52 queries over 257 encoded mel frames)."""
+    from koemorph_amd.model import SimplifiedKoeMorphModel
+    from oracle import legacy
+    params = legacy.make_legacy_params(7)
+    m = SimplifiedKoeMorphModel().cuda().eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    mel = synth.uniform(8, (3, 257, 80), 0, 1)
+    got = m.forward_mel(dev(mel)).cpu().numpy()
+    want = legacy.legacy_forward_mel(params, mel)
+    assert got.shape == (3, 52) and np.abs(got - want).max() < 5e-6
+    audio = synth.make_audio(9, 2, 136448)
+    got = m(dev(audio)).cpu().numpy()
+    want = legacy.legacy_forward(params, audio)
+    assert np.abs(got - want).max() < 1e-4          # contract
+    assert np.abs(got - want).max() < 2e-5
+    assert m.extract_mel_features(dev(audio)).shape == (2, 257, 80)
+    with pytest.raises(ValueError):
+        m(dev(audio)[0])
