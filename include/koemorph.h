@@ -183,6 +183,41 @@ int km_sequence_forward(km_handle h, const float* audio_dev, int64_t B, int64_t 
                         const float* emotion_dev, int32_t stride_frames, int32_t smooth,
                         float* out_dev, void* stream);
 
+/* ---- training step (data-parallel ready) -------------------------------------------------------------
+ * Replaces the body of SequentialTrainer.train_epoch (src/train_sequential.py:158-181: forward, loss,
+ * backward, clip_grad_norm_(1.0), AdamW.step) for the 28 tensors of DualStreamCrossAttention + smoothing_alpha.
+ * Parameters, AdamW moments and gradients are FLAT fp32 vectors in state-dict order (km_train_param_offset);
+ * the gradient bucket is caller-owned so that the data-parallel build can all-reduce it over RCCL between
+ * km_train_step* and km_train_adamw.  Eval-mode arithmetic (dropout = 0); loss = mse_weight * MSE +
+ * l1_weight * L1 of the (optionally EMA-smoothed) prediction against target (src/model/losses.py:112-121).
+ *   km_train_init        allocate the training state for up to max_windows windows per step and upload the
+ *                        currently loaded parameters (allocates; call after km_finalize)
+ *   km_train_step        mel_dev (B,T_in,80), mel_short_dev (B,3,80), emotion_dev (B,ED), target_dev (B,52) ->
+ *                        flat_grad_dev (n_params), loss_dev (1), out_dev (B,52) or NULL; ema_state_dev (B,52) or
+ *                        NULL applies the model's temporal smoothing inside the forward as the reference does
+ *   km_train_step_audio  same from audio_dev (B, L): runs the log-mel front end first (no gradient flows into
+ *                        it in the reference either: NumPy round trip, simplified_dual_stream_model.py:184-229)
+ *   km_train_adamw       grad-norm clipping (max_grad_norm <= 0 disables) + AdamW on the flat vectors; `step`
+ *                        is the 1-based optimizer step for the bias correction
+ *   km_train_get_params / km_train_set_params   flat master copy <-> host
+ *   km_train_sync        make the inference kernels see the trained weights (device master -> host store ->
+ *                        fold + pack + upload) */
+int km_train_init(km_handle h, int64_t max_windows, void* stream);
+int64_t km_train_num_params(km_handle h);
+int64_t km_train_param_offset(km_handle h, const char* key);
+int km_train_step(km_handle h, const float* mel_dev, int64_t B, int64_t T_in, const float* mel_short_dev,
+                  const float* emotion_dev, const float* target_dev, float mse_weight, float l1_weight,
+                  float* flat_grad_dev, float* loss_dev, float* out_dev, float* ema_state_dev, int32_t ema_first,
+                  void* stream);
+int km_train_step_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L, const float* emotion_dev,
+                        const float* target_dev, float mse_weight, float l1_weight, float* flat_grad_dev,
+                        float* loss_dev, float* out_dev, float* ema_state_dev, int32_t ema_first, void* stream);
+int km_train_adamw(km_handle h, const float* flat_grad_dev, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, float max_grad_norm, int64_t step, void* stream);
+int km_train_get_params(km_handle h, float* flat_host, int64_t n);
+int km_train_set_params(km_handle h, const float* flat_host, int64_t n);
+int km_train_sync(km_handle h, void* stream);
+
 /* ---- legacy single-stream variant --------------------------------------------------------------------
  * SimplifiedKoeMorphModel (src/model/simplified_model.py:12-156), used by the reference's src/train.py,
  * scripts/rt_simplified.py and scripts/test_model.py: same librosa-style log-mel front end, a two-layer

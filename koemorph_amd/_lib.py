@@ -76,6 +76,15 @@ SIGNATURES = {
     "km_forward_audio": (C.c_int, [_h, _p, _i64, _i64, _p, _p, _p, _i32, _p]),
     "km_sequence_num_outputs": (_i64, [_h, _i64, _i32]),
     "km_sequence_forward": (C.c_int, [_h, _p, _i64, _i64, _p, _i32, _i32, _p, _p]),
+    "km_train_init": (C.c_int, [_h, _i64, _p]),
+    "km_train_num_params": (_i64, [_h]),
+    "km_train_param_offset": (_i64, [_h, C.c_char_p]),
+    "km_train_step": (C.c_int, [_h, _p, _i64, _i64, _p, _p, _p, C.c_float, C.c_float, _p, _p, _p, _p, _i32, _p]),
+    "km_train_step_audio": (C.c_int, [_h, _p, _i64, _i64, _p, _p, C.c_float, C.c_float, _p, _p, _p, _p, _i32, _p]),
+    "km_train_adamw": (C.c_int, [_h, _p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i64, _p]),
+    "km_train_get_params": (C.c_int, [_h, _p, _i64]),
+    "km_train_set_params": (C.c_int, [_h, _p, _i64]),
+    "km_train_sync": (C.c_int, [_h, _p]),
     "km_legacy_create": (C.c_int, [C.POINTER(KMLegacyConfig), C.POINTER(_h)]),
     "km_legacy_forward": (C.c_int, [_h, _p, _i64, _i64, _p, _p]),
     "km_legacy_forward_mel": (C.c_int, [_h, _p, _i64, _i64, _p, _p]),

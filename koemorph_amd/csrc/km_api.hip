@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <vector>
 
 #include "km_context.h"
 
@@ -14,6 +15,7 @@ using namespace km;
     } while (0)
 
 static int free_streams(Context* c);
+static int free_train(Context* c);
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -107,6 +109,7 @@ int km_destroy(km_handle h) {
         if (kv.second.dev) (void)hipFree(kv.second.dev);
     (void)free_ws(c);
     (void)free_streams(c);
+    (void)free_train(c);
     for (MelPlan* p : c->mel_plans) free_mel_plan(p);
     for (void* e : c->stage_ev)
         if (e) (void)hipEventDestroy((hipEvent_t)e);
@@ -181,6 +184,132 @@ int km_core_forward_z(km_handle h, const float* mel_dev, int64_t B, int64_t T_in
         return launch_core_generic(c, mel_dev, B, T_in, mel_short_dev, z_dev, out_dev, raw_dev, attn_mel_dev, stream);
     }
     return launch_core_fused(c, mel_dev, B, T_in, mel_short_dev, z_dev, out_dev, raw_dev, attn_mel_dev, nullptr, 1, stream);
+}
+
+static int free_train(Context* c) {
+    void* ptrs[] = {c->tr_params, c->tr_m, c->tr_v, c->tr_act, c->tr_q, c->tr_dq, c->tr_part, c->tr_gnorm, c->tr_loss};
+    for (void* p : ptrs)
+        if (p) HIP_TRY(hipFree(p));
+    c->tr_params = c->tr_m = c->tr_v = c->tr_act = c->tr_q = c->tr_dq = c->tr_part = c->tr_gnorm = c->tr_loss = nullptr;
+    c->tr_windows = 0;
+    return KM_OK;
+}
+
+static int upload_train_params(Context* c, void* stream) {
+    std::vector<float> flat((size_t)c->tr_nparams);
+    for (const auto& k : c->param_order) {
+        const HostParam& hp = c->params.at(k);
+        std::memcpy(flat.data() + c->tr_offset.at(k), hp.data.data(), hp.data.size() * sizeof(float));
+    }
+    HIP_TRY(hipMemcpyAsync(c->tr_params, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return KM_OK;
+}
+
+int km_train_init(km_handle h, int64_t max_windows, void* stream) {
+    if (int rc = need_dual(h)) return rc;
+    Context* c = h;
+    if (max_windows <= 0) return fail(KM_ERR_INVALID_ARG, "km_train_init: bad max_windows");
+    if (int rc = free_train(c)) return rc;
+    c->tr_offset.clear();
+    int64_t off = 0;
+    for (const auto& k : c->param_order) {            // state-dict order; every offset a multiple of 4 floats (16 B)
+        c->tr_offset[k] = off;
+        off += ((int64_t)c->params.at(k).data.size() + 3) / 4 * 4;
+    }
+    c->tr_nparams = off;
+    const size_t nb = (size_t)off * sizeof(float);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_params), nb));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_m), nb));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_v), nb));
+    HIP_TRY(hipMemsetAsync(c->tr_params, 0, nb, (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(c->tr_m, 0, nb, (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(c->tr_v, 0, nb, (hipStream_t)stream));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_act), (size_t)max_windows * train_act_floats(c) * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_q), (size_t)28 * c->d * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_dq), (size_t)28 * c->d * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_part), 256 * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_gnorm), sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_loss), sizeof(float)));
+    c->tr_windows = max_windows;
+    return upload_train_params(c, stream);
+}
+
+int64_t km_train_num_params(km_handle h) { return h ? h->tr_nparams : -1; }
+
+int64_t km_train_param_offset(km_handle h, const char* key) {
+    if (!h || !key) return -1;
+    auto it = h->tr_offset.find(key);
+    return it == h->tr_offset.end() ? -1 : it->second;
+}
+
+static int need_train(Context* c, int64_t B) {
+    if (int rc = need_dual(c)) return rc;
+    if (!c->tr_params) return fail(KM_ERR_NOT_FINALIZED, "call km_train_init first");
+    if (B <= 0 || B > c->tr_windows) return fail(KM_ERR_WORKSPACE, "km_train_init sized the step for %lld windows, got %lld",
+                                                 (long long)c->tr_windows, (long long)B);
+    return KM_OK;
+}
+
+int km_train_step(km_handle h, const float* mel_dev, int64_t B, int64_t T_in, const float* mel_short_dev,
+                  const float* emotion_dev, const float* target_dev, float mse_weight, float l1_weight,
+                  float* flat_grad_dev, float* loss_dev, float* out_dev, float* ema_state_dev, int32_t ema_first,
+                  void* stream) {
+    if (int rc = need_train(h, B)) return rc;
+    if (!mel_dev || !mel_short_dev || !emotion_dev || !target_dev || !flat_grad_dev || !loss_dev || T_in <= 0)
+        return fail(KM_ERR_INVALID_ARG, "km_train_step: bad argument");
+    return train_forward_backward(h, mel_dev, B, T_in, mel_short_dev, emotion_dev, target_dev, mse_weight, l1_weight,
+                                  flat_grad_dev, loss_dev, out_dev, ema_state_dev, ema_first, stream);
+}
+
+int km_train_step_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L, const float* emotion_dev,
+                        const float* target_dev, float mse_weight, float l1_weight, float* flat_grad_dev,
+                        float* loss_dev, float* out_dev, float* ema_state_dev, int32_t ema_first, void* stream) {
+    if (int rc = need_train(h, B)) return rc;
+    Context* c = h;
+    if (!audio_dev || !emotion_dev || !target_dev || !flat_grad_dev || !loss_dev || L <= 0)
+        return fail(KM_ERR_INVALID_ARG, "km_train_step_audio: bad argument");
+    const int64_t n_frames = 1 + L / c->cfg.mel.hop_length;
+    if (B > c->ws_windows || n_frames > c->ws_frames)
+        return fail(KM_ERR_WORKSPACE, "workspace too small for %lld windows x %lld samples: call km_reserve", (long long)B, (long long)L);
+    if (int rc = launch_mel(c, c->mel_plans[0], audio_dev, B, L, 0, c->ws_mel, c->ws_short, stream)) return rc;
+    return train_forward_backward(c, c->ws_mel, B, n_frames, c->ws_short, emotion_dev, target_dev, mse_weight, l1_weight,
+                                  flat_grad_dev, loss_dev, out_dev, ema_state_dev, ema_first, stream);
+}
+
+int km_train_adamw(km_handle h, const float* flat_grad_dev, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, float max_grad_norm, int64_t step, void* stream) {
+    if (int rc = need_train(h, 1)) return rc;
+    if (!flat_grad_dev || step < 1) return fail(KM_ERR_INVALID_ARG, "km_train_adamw: bad argument");
+    return train_adamw(h, flat_grad_dev, lr, beta1, beta2, eps, weight_decay, max_grad_norm, step, stream);
+}
+
+int km_train_get_params(km_handle h, float* flat_host, int64_t n) {
+    if (int rc = need_train(h, 1)) return rc;
+    if (!flat_host || n != h->tr_nparams) return fail(KM_ERR_INVALID_ARG, "km_train_get_params: size mismatch");
+    HIP_TRY(hipMemcpy(flat_host, h->tr_params, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return KM_OK;
+}
+
+int km_train_set_params(km_handle h, const float* flat_host, int64_t n) {
+    if (int rc = need_train(h, 1)) return rc;
+    if (!flat_host || n != h->tr_nparams) return fail(KM_ERR_INVALID_ARG, "km_train_set_params: size mismatch");
+    HIP_TRY(hipMemcpy(h->tr_params, flat_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    return KM_OK;
+}
+
+int km_train_sync(km_handle h, void* stream) {
+    if (int rc = need_train(h, 1)) return rc;
+    Context* c = h;
+    std::vector<float> flat((size_t)c->tr_nparams);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(flat.data(), c->tr_params, flat.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (const auto& k : c->param_order) {
+        HostParam& hp = c->params.at(k);
+        std::memcpy(hp.data.data(), flat.data() + c->tr_offset.at(k), hp.data.size() * sizeof(float));
+    }
+    c->host_finalized = false;
+    return km_finalize(h, stream);
 }
 
 int km_legacy_forward_mel(km_handle h, const float* mel_dev, int64_t B, int64_t T_mel, float* out_dev, void* stream) {

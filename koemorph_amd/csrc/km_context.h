@@ -85,6 +85,14 @@ struct Context {
     float* ring_state = nullptr;        // (n_streams, 52) EMA state
     MelPlan* stream_plan = nullptr;
     int64_t stream_out_frames = 0;
+    // training state (km_train_*): flat fp32 master parameters + AdamW moments on the device, in state-dict order
+    int64_t tr_nparams = 0, tr_windows = 0;
+    std::map<std::string, int64_t> tr_offset;
+    float* tr_params = nullptr; float* tr_m = nullptr; float* tr_v = nullptr;
+    float* tr_act = nullptr; float* tr_q = nullptr; float* tr_dq = nullptr; float* tr_part = nullptr; float* tr_gnorm = nullptr;
+    float* tr_loss = nullptr;
+    bool tr_alpha_live = false;      // smoothing_alpha was in the last step's graph (see adamw_kernel)
+    int64_t tr_alpha_steps = 0;
     bool stage_timing = false;
     void* stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // hipEvent_t
     bool melmax_dirty = true;      // ws_melmax may hold stale maxima (see launch_mel_power)
@@ -109,6 +117,14 @@ int launch_core_fused_db(Context* c, MelPlan* p, int64_t B, int64_t n_frames, co
                          const unsigned char* ready = nullptr, unsigned char* started = nullptr);
 int launch_ema_scan(Context* c, float* x, int64_t B, int64_t N, void* stream);
 int launch_smooth(Context* c, float* x, float* state, int64_t B, int first, void* stream);
+
+// km_train.hip
+int64_t train_act_floats(Context* c);
+int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short, const float* emo,
+                           const float* target, float mse_w, float l1_w, float* flat_grad, float* loss_dev, float* out_dev,
+                           float* ema_state, int ema_first, void* stream);
+int train_adamw(Context* c, const float* flat_grad, float lr, float b1, float b2, float eps, float wd, float max_norm,
+                int64_t step, void* stream);
 
 // km_generic.hip
 int64_t generic_ws_floats(Context* c);

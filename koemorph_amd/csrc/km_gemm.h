@@ -1,0 +1,27 @@
+// Strided-batched exact-fp32 MFMA GEMM shared by km_generic.hip (inference on generic shapes, legacy model)
+// and km_train.hip (training forward / backward).
+#pragma once
+
+#include <cstdint>
+
+namespace km {
+
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K;
+    int64_t a_rs, a_cs, b_rs, b_cs, c_rs;       // A(m,k) = A[m*a_rs + k*a_cs], B(k,n) = B[k*b_rs + n*b_cs], C(m,n) = C[m*c_rs + n]
+    int batch2;                                  // output batch index z = z1 * batch2 + z2
+    int64_t a_bs1, a_bs2, b_bs1, b_bs2, c_bs1, c_bs2;
+    // contraction batch: the K loop runs kb_count times with A += a_kbs, B += b_kbs (C = sum_kb A_kb B_kb);
+    // used for gradients that sum over the windows of a batch
+    int kb_count;
+    int64_t a_kbs, b_kbs;
+    float alpha, beta;
+    int bias_mode;                               // 0 none, 1 bias[n], 2 bias[m]
+    int relu;
+};
+
+int launch_gemm(const GemmArgs& g, int batch, void* stream);
+int launch_softmax_rows(float* x, int64_t rows, int w, void* stream);
+
+}  // namespace km

@@ -23,6 +23,7 @@
 
 #include "km_context.h"
 #include "km_device.h"
+#include "km_gemm.h"
 
 namespace km {
 
@@ -34,17 +35,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
         hipError_t e_ = (expr);                                                               \
         if (e_ != hipSuccess) return fail(KM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
-
-struct GemmArgs {
-    const float* A; const float* B; float* C; const float* bias;
-    int M, N, K;
-    int64_t a_rs, a_cs, b_rs, b_cs, c_rs;       // A(m,k) = A[m*a_rs + k*a_cs], B(k,n) = B[k*b_rs + n*b_cs], C(m,n) = C[m*c_rs + n]
-    int batch2;                                  // z = z1 * batch2 + z2
-    int64_t a_bs1, a_bs2, b_bs1, b_bs2, c_bs1, c_bs2;
-    float alpha, beta;
-    int bias_mode;                               // 0 none, 1 bias[n], 2 bias[m]
-    int relu;
-};
 
 namespace gg {
 constexpr int BM = 64, BN = 64, BK = 16, LDT = 80;   // LDS tile row stride (floats)
@@ -70,6 +60,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) { acc[i][0] = f32x4{0, 0, 0, 0}; acc[i][1] = f32x4{0, 0, 0, 0}; }
 
+    const int kbn = g.kb_count > 0 ? g.kb_count : 1;
+    for (int kb = 0; kb < kbn; ++kb, A += g.a_kbs, Bp += g.b_kbs)
     for (int k0 = 0; k0 < g.K; k0 += BK) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {                        // 64 x 16 = 1024 elements per operand, 4 per thread
@@ -114,6 +106,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 }
             }
 }
+
+int launch_softmax_rows(float* x, int64_t rows, int w, void* stream);
 
 int launch_gemm(const GemmArgs& g, int batch, void* stream) {
     const dim3 grid((unsigned)((g.N + gg::BN - 1) / gg::BN), (unsigned)((g.M + gg::BM - 1) / gg::BM), (unsigned)batch);
@@ -189,6 +183,15 @@ __global__ __launch_bounds__(64) void sigmoid_mean_rows_kernel(const float* __re
     float s = 0.f;
     for (int q = 0; q < NQ; ++q) s += 1.0f / (1.0f + expf(-p[(int64_t)q * NB]));
     out[(int64_t)b * NB + j] = s / NQ;
+}
+
+int launch_softmax_rows(float* x, int64_t rows, int w, void* stream) {
+    if (w <= 128)
+        hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, rows, w);
+    else
+        hipLaunchKernelGGL(softmax_rows_wide_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, rows, w);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
 }
 
 // head-averaged attention weights: (B, H, 28, 80) -> (B, 28, 80)

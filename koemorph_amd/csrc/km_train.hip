@@ -1,0 +1,539 @@
+// Training step of the dual-stream core for gfx950: unfolded forward with saved activations, loss, backward,
+// global-norm clipping and fused AdamW.  SURVEY.md section 8 row a13 / 8(f) rank 1.
+//
+// Replaces, per rank, the body of SequentialTrainer.train_epoch (reference src/train_sequential.py:158-181):
+//   outputs = model(audio); loss = criterion(...); loss.backward(); clip_grad_norm_(params, 1.0); AdamW.step()
+// for the 28 tensors of DualStreamCrossAttention + smoothing_alpha (837 738 fp32 at d=256/T=256).  The mel and
+// emotion features carry no gradient in the reference (NumPy round trip), so backward stops at the core inputs.
+// Gradients land in ONE flat caller-owned bucket in state-dict order, which is what the data-parallel build
+// all-reduces over RCCL (koemorph_amd/parallel.py) before km_train_adamw.
+//
+// Arithmetic: eval-mode (dropout p = 0) so that parity against torch.autograd on the reference module is exact up
+// to summation order (tests/golden/core_*_grads.npz).  Every contraction is the exact-fp32 MFMA GEMM of
+// km_generic.hip (NT / NN / TN through strides, contraction over the batch through the k-batch loop), so the
+// path is shape generic.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "km_context.h"
+#include "km_device.h"
+#include "km_gemm.h"
+
+namespace km {
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(KM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+__device__ __forceinline__ int tr_mouth_slot(int i) { return (i >= 14 && i <= 40) ? i - 14 : (i == 51 ? 27 : -1); }
+
+// ---- elementwise / reduction kernels --------------------------------------------------------------------
+
+// y = LayerNorm(x) out of place, statistics saved for the backward pass (one wave per row)
+__global__ __launch_bounds__(256) void ln_fwd_save_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows,
+                                                          int d, const float* __restrict__ gam, const float* __restrict__ bet,
+                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* p = x + row * d;
+    float s = 0.f;
+    for (int i = lane; i < d; i += 64) s += p[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / d;
+    float v = 0.f;
+    for (int i = lane; i < d; i += 64) { const float t = p[i] - mean; v += t * t; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float rstd = 1.0f / sqrtf(v / d + 1e-5f);
+    for (int i = lane; i < d; i += 64) y[row * d + i] = (p[i] - mean) * rstd * gam[i] + bet[i];
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)), dxhat = dy * gamma; dy is overwritten by dx
+__global__ __launch_bounds__(256) void ln_bwd_kernel(float* __restrict__ dy, const float* __restrict__ x, int64_t rows, int d,
+                                                     const float* __restrict__ gam, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = lane; i < d; i += 64) {
+        const float xh = (x[row * d + i] - mu) * rs, dxh = dy[row * d + i] * gam[i];
+        s1 += dxh;
+        s2 += dxh * xh;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    s1 /= d; s2 /= d;
+    for (int i = lane; i < d; i += 64) {
+        const float xh = (x[row * d + i] - mu) * rs, dxh = dy[row * d + i] * gam[i];
+        dy[row * d + i] = rs * (dxh - s1 - xh * s2);
+    }
+}
+
+// dgamma[n] = sum_rows dy * xhat, dbeta[n] = sum_rows dy   (dy BEFORE ln_bwd_kernel overwrites it)
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t rows,
+                                                            int d, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ dgam, float* __restrict__ dbet) {
+    __shared__ float sg[4][64], sb[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float ag = 0.f, ab = 0.f;
+    if (c < d)
+        for (int64_t r = rg; r < rows; r += 4) {
+            const float g = dy[r * d + c];
+            ag += g * (x[r * d + c] - mean[r]) * rstd[r];
+            ab += g;
+        }
+    sg[rg][threadIdx.x & 63] = ag; sb[rg][threadIdx.x & 63] = ab;
+    __syncthreads();
+    if (rg == 0 && c < d) {
+        dgam[c] = sg[0][threadIdx.x] + sg[1][threadIdx.x] + sg[2][threadIdx.x] + sg[3][threadIdx.x];
+        dbet[c] = sb[0][threadIdx.x] + sb[1][threadIdx.x] + sb[2][threadIdx.x] + sb[3][threadIdx.x];
+    }
+}
+
+// out[n] (+)= sum over rows of m[r * rs + n]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ m, int64_t rows, int64_t rs, int n, float* __restrict__ out,
+                                                     int accumulate) {
+    __shared__ float sh[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float a = 0.f;
+    if (c < n)
+        for (int64_t r = rg; r < rows; r += 4) a += m[r * rs + c];
+    sh[rg][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (rg == 0 && c < n) {
+        const float s = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        out[c] = accumulate ? out[c] + s : s;
+    }
+}
+
+// dS = P * (dP - rowsum(dP * P)), in place on dP; rows of width w <= 128
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(float* __restrict__ dp, const float* __restrict__ p, int64_t rows, int w) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float p0 = lane < w ? p[row * w + lane] : 0.f, p1 = lane + 64 < w ? p[row * w + lane + 64] : 0.f;
+    const float g0 = lane < w ? dp[row * w + lane] : 0.f, g1 = lane + 64 < w ? dp[row * w + lane + 64] : 0.f;
+    float s = g0 * p0 + g1 * p1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane < w) dp[row * w + lane] = p0 * (g0 - s);
+    if (lane + 64 < w) dp[row * w + lane + 64] = p1 * (g1 - s);
+}
+
+struct TailArgs {
+    const float* h1;      // (B*28, DH) post-ReLU hidden of the mouth rows
+    const float* he;      // (B, DH)    post-ReLU hidden of the (shared) expression row
+    const float* w2; const float* b2;
+    const float* mel_w; const float* emo_w;   // (52) raw stream weights
+    float temperature;
+    const float* target;  // (B, 52)
+    float* bs;            // (B, 52) sigmoid outputs
+    float* out;           // (B, 52) final (after clamp and EMA)
+    float* dz;            // (B, 52) dL/dz
+    float* ema_state;     // (B, 52) or null
+    int ema_first;
+    const float* alpha_p; // smoothing_alpha parameter
+    float mse_w, l1_w;
+    float* loss;          // (1)
+    float* d_melw; float* d_emow; float* d_alpha;   // gradients (52), (52), (1)
+    int B, DH;
+};
+
+// One workgroup: decoder output layer, sigmoid, stream weights, clamp, EMA, loss and the gradient of the loss
+// with respect to every pre-sigmoid logit.  B is small in training (8 per GPU), all loops are in a fixed order.
+__global__ __launch_bounds__(64) void train_tail_kernel(TailArgs a) {
+    __shared__ float wsum_s[52], wm_s[52], we_s[52], dws_s[52], red[64];
+    const int i = threadIdx.x;
+    if (i == 0) {   // stream weight softmaxes (dual_stream_attention.py:252-253)
+        float mm = -INFINITY, me = -INFINITY;
+        for (int k = 0; k < 52; ++k) { mm = fmaxf(mm, a.mel_w[k] / a.temperature); me = fmaxf(me, a.emo_w[k] / a.temperature); }
+        float sm = 0.f, se = 0.f;
+        for (int k = 0; k < 52; ++k) {
+            wm_s[k] = expf(a.mel_w[k] / a.temperature - mm); sm += wm_s[k];
+            we_s[k] = expf(a.emo_w[k] / a.temperature - me); se += we_s[k];
+        }
+        for (int k = 0; k < 52; ++k) { wm_s[k] /= sm; we_s[k] /= se; wsum_s[k] = 0.5f * wm_s[k] + 0.5f * we_s[k]; }
+    }
+    __syncthreads();
+    const float alpha = 1.0f / (1.0f + expf(-a.alpha_p[0]));
+    const float inv_n = 1.0f / (float)(a.B * 52);
+    float loss_acc = 0.f, dws = 0.f, dal = 0.f;
+    if (i < 52) {
+        const int slot = tr_mouth_slot(i);
+        for (int b = 0; b < a.B; ++b) {
+            const float* h = slot >= 0 ? a.h1 + ((int64_t)b * 28 + slot) * a.DH : a.he + (int64_t)b * a.DH;
+            float z = a.b2[0];
+            for (int m = 0; m < a.DH; ++m) z = fmaf(h[m], a.w2[m], z);
+            const float bs = 1.0f / (1.0f + expf(-z));
+            const float f = wsum_s[i] * bs;
+            const float x = fminf(fmaxf(f, 0.f), 1.f);
+            float y = x, dx_dy = 1.f;
+            if (a.ema_state) {
+                float* st = a.ema_state + (int64_t)b * 52 + i;
+                if (!a.ema_first) {
+                    const float prev = *st;
+                    y = alpha * x + (1.0f - alpha) * prev;
+                    dx_dy = alpha;
+                    // d y / d smoothing_alpha = (x - prev) * alpha (1 - alpha); filled in below once dL/dy is known
+                    red[i] = (x - prev);
+                }
+                *st = y;
+            }
+            const float diff = y - a.target[(int64_t)b * 52 + i];
+            loss_acc += a.mse_w * diff * diff + a.l1_w * fabsf(diff);
+            const float dy = (a.mse_w * 2.0f * diff + a.l1_w * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f))) * inv_n;
+            if (a.ema_state && !a.ema_first) dal += dy * red[i] * alpha * (1.0f - alpha);
+            const float df = dy * dx_dy * ((f >= 0.f && f <= 1.f) ? 1.f : 0.f);
+            dws += df * bs;
+            a.bs[(int64_t)b * 52 + i] = bs;
+            a.out[(int64_t)b * 52 + i] = y;
+            a.dz[(int64_t)b * 52 + i] = df * wsum_s[i] * bs * (1.0f - bs);
+        }
+        dws_s[i] = dws;
+    }
+    red[i] = i < 52 ? loss_acc : 0.f;
+    __syncthreads();
+    if (i == 0) {
+        float s = 0.f;
+        for (int k = 0; k < 52; ++k) s += red[k];
+        a.loss[0] = s * inv_n;
+    }
+    __syncthreads();
+    red[i] = i < 52 ? dal : 0.f;
+    __syncthreads();
+    if (i == 0) {
+        float s = 0.f;
+        for (int k = 0; k < 52; ++k) s += red[k];
+        a.d_alpha[0] = s;
+        // softmax backward for both stream-weight vectors: d w_j = (1/tau) w_j (g_j - sum_k g_k w_k), g = 0.5 dwsum
+        float dm = 0.f, de = 0.f;
+        for (int k = 0; k < 52; ++k) { dm += 0.5f * dws_s[k] * wm_s[k]; de += 0.5f * dws_s[k] * we_s[k]; }
+        for (int k = 0; k < 52; ++k) {
+            a.d_melw[k] = wm_s[k] * (0.5f * dws_s[k] - dm) / a.temperature;
+            a.d_emow[k] = we_s[k] * (0.5f * dws_s[k] - de) / a.temperature;
+        }
+    }
+}
+
+// backward of the decoder output layer: dH (rows, DH) = dz_row * w2 * [H > 0] for the B*28 mouth rows and the B
+// expression rows (whose dz is the sum over the 24 expression coefficients), dw2 / db2 reductions.
+__global__ __launch_bounds__(256) void train_dh_kernel(const float* __restrict__ dz, const float* __restrict__ h1,
+                                                       const float* __restrict__ he, const float* __restrict__ w2, int B, int DH,
+                                                       float* __restrict__ dh1, float* __restrict__ dhe, float* __restrict__ dw2,
+                                                       float* __restrict__ db2) {
+    // grid.x covers DH in chunks of 256 columns
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= DH) return;
+    const float w = w2[m];
+    float acc = 0.f, accb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float dze = 0.f;
+        for (int i = 0; i < 52; ++i) {
+            const int slot = tr_mouth_slot(i);
+            const float g = dz[(int64_t)b * 52 + i];
+            accb += g;
+            if (slot >= 0) {
+                const int64_t row = (int64_t)b * 28 + slot;
+                const float h = h1[row * DH + m];
+                acc += g * h;
+                dh1[row * DH + m] = h > 0.f ? g * w : 0.f;
+            } else {
+                dze += g;
+            }
+        }
+        const float h = he[(int64_t)b * DH + m];
+        acc += dze * h;
+        dhe[(int64_t)b * DH + m] = h > 0.f ? dze * w : 0.f;
+    }
+    dw2[m] = acc;
+    if (m == 0) db2[0] = accb;
+}
+
+__global__ void zero_kernel(float* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
+// ---- optimizer ---------------------------------------------------------------------------------------------
+
+// sum of squares of the flat gradient, deterministic two-stage reduction
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
+    __shared__ float sh[256];
+    float a = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += g[i] * g[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+__global__ __launch_bounds__(64) void sumsq_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += part[i];
+        out[0] = sqrtf(s);
+    }
+}
+
+// torch.nn.utils.clip_grad_norm_(max_norm) + torch.optim.AdamW (decoupled weight decay, bias correction)
+// smoothing_alpha is outside the autograd graph whenever the EMA passes its input through (first call / batch-size
+// change / smoothing off): torch leaves its .grad as None and AdamW then skips it entirely (no decay, no moment
+// update, its own step counter).  alpha_idx / alpha_live / (abc1, abc2) reproduce that.
+__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
+                             int64_t n, const float* __restrict__ gnorm, float max_norm, float lr, float b1, float b2,
+                             float eps, float wd, float bc1, float bc2, int64_t alpha_idx, int alpha_live, float abc1,
+                             float abc2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == alpha_idx) {
+        if (!alpha_live) return;
+        bc1 = abc1; bc2 = abc2;
+    }
+    float scale = 1.f;
+    if (max_norm > 0.f) {
+        const float c = max_norm / (gnorm[0] + 1e-6f);       // clip_coef, clamped to 1
+        scale = c < 1.f ? c : 1.f;
+    }
+    const float gi = g[i] * scale;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    pi -= (lr / bc1) * mi / denom;
+    p[i] = pi;
+}
+
+// ---- host orchestration ----------------------------------------------------------------------------------------
+
+static GemmArgs G(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t c_rs,
+                  int64_t M, int64_t N, int64_t K) {
+    GemmArgs g{};
+    g.alpha = 1.f; g.batch2 = 1; g.kb_count = 1;
+    g.A = A; g.a_rs = a_rs; g.a_cs = a_cs; g.B = B; g.b_rs = b_rs; g.b_cs = b_cs; g.C = C; g.c_rs = c_rs;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    return g;
+}
+// C (rows x N) = A (rows x K) W^T (+ bias), W stored (N x K) like nn.Linear
+static GemmArgs NT(const float* A, int64_t a_rs, const float* W, int64_t K, float* C, int64_t c_rs, int64_t rows, int64_t N,
+                   const float* bias, int relu) {
+    GemmArgs g = G(A, a_rs, 1, W, 1, K, C, c_rs, rows, N, K);
+    g.bias = bias; g.bias_mode = bias ? 1 : 0; g.relu = relu;
+    return g;
+}
+// C (rows x N) = A (rows x K) W, W stored (K x N)   (grad wrt the input of a Linear: dX = dY W)
+static GemmArgs NN(const float* A, int64_t a_rs, const float* W, int64_t w_rs, float* C, int64_t c_rs, int64_t rows, int64_t N, int64_t K) {
+    return G(A, a_rs, 1, W, w_rs, 1, C, c_rs, rows, N, K);
+}
+// C (M x N) = A^T B with A (rows x M), B (rows x N)   (grad wrt the weight of a Linear: dW = dY^T X)
+static GemmArgs TN(const float* A, int64_t a_rs, const float* B, int64_t b_rs, float* C, int64_t c_rs, int64_t M, int64_t N, int64_t rows) {
+    return G(A, 1, a_rs, B, b_rs, 1, C, c_rs, M, N, rows);
+}
+
+static int colsum(const float* m, int64_t rows, int64_t rs, int n, float* out, int accumulate, void* stream) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, m, rows, rs, n, out, accumulate);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+#define RUN(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
+
+int64_t train_act_floats(Context* c) {
+    const int64_t d = c->d, H = c->H, NKk = c->NK, DH = c->DH;
+    const int64_t R = NKk, Rq = 28;
+    return 2 * R * d /* Y0, Y */ + 2 * R /* mean, rstd */ + 2 * R * d /* KV */ + 2 * H * Rq * NKk /* P, dP */ +
+           3 * Rq * d /* A, O1, O2 */ + Rq * DH /* H1 */ + 2 * R * d /* dKV */ + R * d /* dY */ + 2 * Rq * d /* ping-pong grads */ +
+           Rq * DH /* dH1 */ + 5 * d /* E0, E, Ve, Oe1, Oe2 */ + 2 /* emo stats */ + DH /* He */ + 3 * d + DH /* emotion grads */ +
+           4 * 52 /* bs, out, dz, pad */;
+}
+
+struct ParamView { const float* p; float* g; };
+
+int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short, const float* emo,
+                           const float* target, float mse_w, float l1_w, float* flat_grad, float* loss_dev, float* out_dev,
+                           float* ema_state, int ema_first, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t d = c->d, H = c->H, hd = c->hd, T = c->T, KT = c->KT, DH = c->DH, NKk = c->NK, ED = c->ED;
+    const int64_t R = B * NKk, Rq = B * 28;
+    c->tr_alpha_live = ema_state != nullptr && !ema_first;
+    auto P = [&](const char* k) -> const float* { return c->tr_params + c->tr_offset.at(k); };
+    auto Gd = [&](const char* k) -> float* { return flat_grad + c->tr_offset.at(k); };
+    // carve the activation workspace
+    float* w = c->tr_act;
+    auto take = [&](int64_t n) { float* p = w; w += n; return p; };
+    float* Y0 = take(R * d); float* Y = take(R * d); float* mu = take(R); float* rs = take(R);
+    float* KV = take(R * 2 * d); float* Pm = take(B * H * 28 * NKk); float* dP = take(B * H * 28 * NKk);
+    float* A = take(Rq * d); float* O1 = take(Rq * d); float* O2 = take(Rq * d); float* H1 = take(Rq * DH);
+    float* dKV = take(R * 2 * d); float* dY = take(R * d); float* gA = take(Rq * d); float* gB = take(Rq * d);
+    float* dH1 = take(Rq * DH);
+    float* E0 = take(B * d); float* E = take(B * d); float* Ve = take(B * d); float* Oe1 = take(B * d); float* Oe2 = take(B * d);
+    float* emu = take(B); float* ers = take(B); float* He = take(B * DH);
+    float* geA = take(B * d); float* geB = take(B * d); float* geC = take(B * d); float* dHe = take(B * DH);
+    float* bs = take(B * 52); float* outb = take(B * 52); float* dz = take(B * 52);
+    float* Qb = c->tr_q;            // (28, d)
+    float* dQb = c->tr_dq;          // (28, d)
+
+    const float* Wce = P("mel_channel_encoder.weight");
+    const float* inw = P("mel_attention.in_proj_weight"); const float* inb = P("mel_attention.in_proj_bias");
+    const float* einw = P("emotion_attention.in_proj_weight"); const float* einb = P("emotion_attention.in_proj_bias");
+    const float scale = 1.0f / std::sqrt((float)hd);
+    const int64_t tv = T_in < T ? T_in : T;
+
+    // ================= forward (unfolded, dual_stream_attention.py:189-270) =================
+    {   // Y0 = X^T Wce^T + b: long rows then the 3 short-term rows
+        GemmArgs g = G(mel, 1, NKk, Wce, 1, KT, Y0, d, NKk, d, tv);
+        g.a_bs1 = T_in * NKk; g.c_bs1 = NKk * d; g.bias = P("mel_channel_encoder.bias"); g.bias_mode = 1;
+        RUN(launch_gemm(g, (int)B, stream));
+        g = G(mel_short, 1, NKk, Wce + T, 1, KT, Y0, d, NKk, d, 3);
+        g.a_bs1 = 3 * NKk; g.c_bs1 = NKk * d; g.beta = 1.f;
+        RUN(launch_gemm(g, (int)B, stream));
+    }
+    hipLaunchKernelGGL(ln_fwd_save_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, Y0, Y, R, (int)d, P("mel_norm.weight"),
+                       P("mel_norm.bias"), mu, rs);
+    RUN(launch_gemm(NT(P("mouth_queries"), d, inw, d, Qb, d, 28, d, inb, 0), 1, stream));                 // Q = mq Wq^T + bq
+    RUN(launch_gemm(NT(Y, d, inw + d * d, d, KV, 2 * d, R, 2 * d, inb + d, 0), 1, stream));               // [K | V]
+    {   // S = scale * Q_h K_h^T, softmax
+        GemmArgs g = G(Qb, d, 1, KV, 1, 2 * d, Pm, NKk, 28, NKk, hd);
+        g.alpha = scale; g.batch2 = (int)H; g.a_bs2 = hd; g.b_bs1 = NKk * 2 * d; g.b_bs2 = hd;
+        g.c_bs1 = H * 28 * NKk; g.c_bs2 = 28 * NKk;
+        RUN(launch_gemm(g, (int)(B * H), stream));
+    }
+    RUN(launch_softmax_rows(Pm, B * H * 28, (int)NKk, stream));
+    {   // A[b][:, h] = P V_h
+        GemmArgs g = G(Pm, NKk, 1, KV + d, 2 * d, 1, A, d, 28, hd, NKk);
+        g.batch2 = (int)H; g.a_bs1 = H * 28 * NKk; g.a_bs2 = 28 * NKk; g.b_bs1 = NKk * 2 * d; g.b_bs2 = hd;
+        g.c_bs1 = 28 * d; g.c_bs2 = hd;
+        RUN(launch_gemm(g, (int)(B * H), stream));
+    }
+    RUN(launch_gemm(NT(A, d, P("mel_attention.out_proj.weight"), d, O1, d, Rq, d, P("mel_attention.out_proj.bias"), 0), 1, stream));
+    RUN(launch_gemm(NT(O1, d, P("mel_output_proj.weight"), d, O2, d, Rq, d, P("mel_output_proj.bias"), 0), 1, stream));
+    RUN(launch_gemm(NT(O2, d, P("blendshape_decoder.0.weight"), d, H1, DH, Rq, DH, P("blendshape_decoder.0.bias"), 1), 1, stream));
+    // emotion stream: one token, softmax == 1 (:216-218, :234-240)
+    RUN(launch_gemm(NT(emo, ED, P("emotion_encoder.weight"), ED, E0, d, B, d, P("emotion_encoder.bias"), 0), 1, stream));
+    hipLaunchKernelGGL(ln_fwd_save_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, E0, E, B, (int)d, P("emotion_norm.weight"),
+                       P("emotion_norm.bias"), emu, ers);
+    RUN(launch_gemm(NT(E, d, einw + 2 * d * d, d, Ve, d, B, d, einb + 2 * d, 0), 1, stream));
+    RUN(launch_gemm(NT(Ve, d, P("emotion_attention.out_proj.weight"), d, Oe1, d, B, d, P("emotion_attention.out_proj.bias"), 0), 1, stream));
+    RUN(launch_gemm(NT(Oe1, d, P("emotion_output_proj.weight"), d, Oe2, d, B, d, P("emotion_output_proj.bias"), 0), 1, stream));
+    RUN(launch_gemm(NT(Oe2, d, P("blendshape_decoder.0.weight"), d, He, DH, B, DH, P("blendshape_decoder.0.bias"), 1), 1, stream));
+
+    // ================= loss and dL/dz =================
+    {
+        const int64_t n = c->tr_nparams;
+        hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flat_grad, n);
+        TailArgs t{};
+        t.h1 = H1; t.he = He; t.w2 = P("blendshape_decoder.3.weight"); t.b2 = P("blendshape_decoder.3.bias");
+        t.mel_w = P("mel_weights"); t.emo_w = P("emotion_weights"); t.temperature = c->cfg.temperature; t.target = target;
+        t.bs = bs; t.out = outb; t.dz = dz; t.ema_state = ema_state; t.ema_first = ema_first; t.alpha_p = P("smoothing_alpha");
+        t.mse_w = mse_w; t.l1_w = l1_w; t.loss = loss_dev; t.d_melw = Gd("mel_weights"); t.d_emow = Gd("emotion_weights");
+        t.d_alpha = Gd("smoothing_alpha"); t.B = (int)B; t.DH = (int)DH;
+        hipLaunchKernelGGL(train_tail_kernel, dim3(1), dim3(64), 0, st, t);
+        if (out_dev) HIP_TRY(hipMemcpyAsync(out_dev, outb, (size_t)B * 52 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+
+    // ================= backward =================
+    hipLaunchKernelGGL(train_dh_kernel, dim3((unsigned)((DH + 255) / 256)), dim3(256), 0, st, dz, H1, He,
+                       P("blendshape_decoder.3.weight"), (int)B, (int)DH, dH1, dHe, Gd("blendshape_decoder.3.weight"),
+                       Gd("blendshape_decoder.3.bias"));
+    // decoder[0] (shared by both streams): dW1 = dH1^T O2 + dHe^T Oe2, db1, dO2 = dH1 W1, dOe2 = dHe W1
+    RUN(launch_gemm(TN(dH1, DH, O2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, Rq), 1, stream));
+    { GemmArgs g = TN(dHe, DH, Oe2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, B); g.beta = 1.f; RUN(launch_gemm(g, 1, stream)); }
+    RUN(colsum(dH1, Rq, DH, (int)DH, Gd("blendshape_decoder.0.bias"), 0, stream));
+    RUN(colsum(dHe, B, DH, (int)DH, Gd("blendshape_decoder.0.bias"), 1, stream));
+    RUN(launch_gemm(NN(dH1, DH, P("blendshape_decoder.0.weight"), d, gA, d, Rq, d, DH), 1, stream));               // dO2
+    RUN(launch_gemm(NN(dHe, DH, P("blendshape_decoder.0.weight"), d, geA, d, B, d, DH), 1, stream));               // dOe2
+    // mel_output_proj
+    RUN(launch_gemm(TN(gA, d, O1, d, Gd("mel_output_proj.weight"), d, d, d, Rq), 1, stream));
+    RUN(colsum(gA, Rq, d, (int)d, Gd("mel_output_proj.bias"), 0, stream));
+    RUN(launch_gemm(NN(gA, d, P("mel_output_proj.weight"), d, gB, d, Rq, d, d), 1, stream));                        // dO1
+    // out_proj
+    RUN(launch_gemm(TN(gB, d, A, d, Gd("mel_attention.out_proj.weight"), d, d, d, Rq), 1, stream));
+    RUN(colsum(gB, Rq, d, (int)d, Gd("mel_attention.out_proj.bias"), 0, stream));
+    RUN(launch_gemm(NN(gB, d, P("mel_attention.out_proj.weight"), d, gA, d, Rq, d, d), 1, stream));                 // dA
+    float* gin_w = Gd("mel_attention.in_proj_weight"); float* gin_b = Gd("mel_attention.in_proj_bias");
+    {   // dP = dA_h V_h^T ; dV_h = P^T dA_h
+        GemmArgs g = G(gA, d, 1, KV + d, 1, 2 * d, dP, NKk, 28, NKk, hd);
+        g.batch2 = (int)H; g.a_bs1 = 28 * d; g.a_bs2 = hd; g.b_bs1 = NKk * 2 * d; g.b_bs2 = hd; g.c_bs1 = H * 28 * NKk; g.c_bs2 = 28 * NKk;
+        RUN(launch_gemm(g, (int)(B * H), stream));
+        g = G(Pm, 1, NKk, gA, d, 1, dKV + d, 2 * d, NKk, hd, 28);
+        g.batch2 = (int)H; g.a_bs1 = H * 28 * NKk; g.a_bs2 = 28 * NKk; g.b_bs1 = 28 * d; g.b_bs2 = hd; g.c_bs1 = NKk * 2 * d; g.c_bs2 = hd;
+        RUN(launch_gemm(g, (int)(B * H), stream));
+    }
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((B * H * 28 + 3) / 4)), dim3(256), 0, st, dP, Pm, B * H * 28, (int)NKk);
+    {   // dQ_h = scale * sum_b dS K_h  (contraction over the batch through the k-batch loop) ; dK_h = scale * dS^T Q_h
+        GemmArgs g = G(dP, NKk, 1, KV, 2 * d, 1, dQb, d, 28, hd, NKk);
+        g.alpha = scale; g.batch2 = (int)H; g.a_bs2 = 28 * NKk; g.b_bs2 = hd; g.c_bs2 = hd;
+        g.kb_count = (int)B; g.a_kbs = H * 28 * NKk; g.b_kbs = NKk * 2 * d;
+        RUN(launch_gemm(g, (int)H, stream));
+        g = G(dP, 1, NKk, Qb, d, 1, dKV, 2 * d, NKk, hd, 28);
+        g.alpha = scale; g.batch2 = (int)H; g.a_bs1 = H * 28 * NKk; g.a_bs2 = 28 * NKk; g.b_bs2 = hd; g.c_bs1 = NKk * 2 * d; g.c_bs2 = hd;
+        RUN(launch_gemm(g, (int)(B * H), stream));
+    }
+    // in_proj: rows [0,d) = Wq, [d,3d) = [Wk; Wv]
+    RUN(launch_gemm(TN(dQb, d, P("mouth_queries"), d, gin_w, d, d, d, 28), 1, stream));
+    RUN(colsum(dQb, 28, d, (int)d, gin_b, 0, stream));
+    RUN(launch_gemm(NN(dQb, d, inw, d, Gd("mouth_queries"), d, 28, d, d), 1, stream));
+    RUN(launch_gemm(TN(dKV, 2 * d, Y, d, gin_w + d * d, d, 2 * d, d, R), 1, stream));
+    RUN(colsum(dKV, R, 2 * d, (int)(2 * d), gin_b + d, 0, stream));
+    RUN(launch_gemm(NN(dKV, 2 * d, inw + d * d, d, dY, d, R, d, 2 * d), 1, stream));                                 // dY
+    // LayerNorm
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, st, dY, Y0, R, (int)d, mu, rs,
+                       Gd("mel_norm.weight"), Gd("mel_norm.bias"));
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, dY, Y0, R, (int)d, P("mel_norm.weight"), mu, rs);
+    {   // channel encoder: dWce = sum_b dY0_b^T X_b (long columns, then the 3 short-term columns), db
+        GemmArgs g = G(dY, 1, d, mel, 1, NKk, Gd("mel_channel_encoder.weight"), KT, d, tv, NKk);
+        g.kb_count = (int)B; g.a_kbs = NKk * d; g.b_kbs = T_in * NKk;
+        RUN(launch_gemm(g, 1, stream));
+        g = G(dY, 1, d, mel_short, 1, NKk, Gd("mel_channel_encoder.weight") + T, KT, d, 3, NKk);
+        g.kb_count = (int)B; g.a_kbs = NKk * d; g.b_kbs = 3 * NKk;
+        RUN(launch_gemm(g, 1, stream));
+        RUN(colsum(dY, R, d, (int)d, Gd("mel_channel_encoder.bias"), 0, stream));
+    }
+    // emotion stream
+    RUN(launch_gemm(TN(geA, d, Oe1, d, Gd("emotion_output_proj.weight"), d, d, d, B), 1, stream));
+    RUN(colsum(geA, B, d, (int)d, Gd("emotion_output_proj.bias"), 0, stream));
+    RUN(launch_gemm(NN(geA, d, P("emotion_output_proj.weight"), d, geB, d, B, d, d), 1, stream));                     // dOe1
+    RUN(launch_gemm(TN(geB, d, Ve, d, Gd("emotion_attention.out_proj.weight"), d, d, d, B), 1, stream));
+    RUN(colsum(geB, B, d, (int)d, Gd("emotion_attention.out_proj.bias"), 0, stream));
+    RUN(launch_gemm(NN(geB, d, P("emotion_attention.out_proj.weight"), d, geC, d, B, d, d), 1, stream));              // dVe
+    RUN(launch_gemm(TN(geC, d, E, d, Gd("emotion_attention.in_proj_weight") + 2 * d * d, d, d, d, B), 1, stream));    // only the V third
+    RUN(colsum(geC, B, d, (int)d, Gd("emotion_attention.in_proj_bias") + 2 * d, 0, stream));
+    RUN(launch_gemm(NN(geC, d, einw + 2 * d * d, d, geA, d, B, d, d), 1, stream));                                    // dE
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, st, geA, E0, B, (int)d, emu, ers,
+                       Gd("emotion_norm.weight"), Gd("emotion_norm.bias"));
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, geA, E0, B, (int)d, P("emotion_norm.weight"), emu, ers);
+    RUN(launch_gemm(TN(geA, d, emo, ED, Gd("emotion_encoder.weight"), ED, d, ED, B), 1, stream));
+    RUN(colsum(geA, B, d, (int)d, Gd("emotion_encoder.bias"), 0, stream));
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+int train_adamw(Context* c, const float* flat_grad, float lr, float b1, float b2, float eps, float wd, float max_norm,
+                int64_t step, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = c->tr_nparams;
+    const int nb = 256;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, flat_grad, n, c->tr_part);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, st, c->tr_part, nb, c->tr_gnorm);
+    const float bc1 = 1.0f - std::pow(b1, (float)step), bc2 = 1.0f - std::pow(b2, (float)step);
+    if (c->tr_alpha_live) c->tr_alpha_steps += 1;
+    const float as = (float)(c->tr_alpha_steps > 0 ? c->tr_alpha_steps : 1);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->tr_params, c->tr_m, c->tr_v, flat_grad, n,
+                       c->tr_gnorm, max_norm, lr, b1, b2, eps, wd, bc1, bc2, c->tr_offset.at("smoothing_alpha"),
+                       c->tr_alpha_live ? 1 : 0, 1.0f - std::pow(b1, as), 1.0f - std::pow(b2, as));
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+}  // namespace km

@@ -1,0 +1,131 @@
+"""Data-parallel training step of the dual-stream model on the GPU.
+
+Mirrors the step of the reference's ``SequentialTrainer.train_epoch`` (src/train_sequential.py:130-181) and its
+optimizer / scheduler set-up (:73-86): ``AdamW(lr, weight_decay, betas=(0.9, 0.999))``,
+``CosineAnnealingWarmRestarts(T_0=10, T_mult=2, eta_min=1e-6)`` stepped per epoch (:209),
+``clip_grad_norm_(params, 1.0)`` (:175-179).  The reference is single-process; the data-parallel part is new
+construction: one process per GPU, every rank runs the HIP forward/backward on its own windows, ONE all-reduce
+of the flat fp32 gradient bucket over RCCL (koemorph_amd.parallel.allreduce_gradients), then the fused AdamW.
+
+Loss: the reference's intended ``MultiTaskLoss`` does not exist in its repository (:24-29 import error); the
+nearest real criterion is ``KoeMorphLoss`` (src/model/losses.py:29) whose frame-local terms are implemented here:
+``mse_weight * MSE + l1_weight * L1`` (:112-121).  Targets are one (B, 52) frame per window (the reference's
+(B, 256, 52) targets against a (B, 52) prediction are shape-inconsistent).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import parallel
+from ._lib import check
+from .engine import Engine, _ptr, _stream_ptr
+
+
+def cosine_warm_restarts_lr(epoch: int, base_lr: float, T_0: int = 10, T_mult: int = 2, eta_min: float = 1e-6) -> float:
+    """torch.optim.lr_scheduler.CosineAnnealingWarmRestarts, evaluated at an integer epoch."""
+    if T_mult == 1:
+        T_cur, T_i = epoch % T_0, T_0
+    else:
+        n = int(math.log(epoch / T_0 * (T_mult - 1) + 1, T_mult)) if epoch >= T_0 else 0
+        T_cur = epoch - T_0 * (T_mult ** n - 1) // (T_mult - 1)
+        T_i = T_0 * T_mult ** n
+    return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * T_cur / T_i)) / 2
+
+
+class Trainer:
+    def __init__(self, engine: Engine, max_windows: int = 8, lr: float = 1e-4, weight_decay: float = 1e-5,
+                 betas=(0.9, 0.999), eps: float = 1e-8, grad_clip: float = 1.0, mse_weight: float = 1.0,
+                 l1_weight: float = 0.0, use_smoothing: bool = True):
+        if engine.device is None:
+            raise RuntimeError("finalize the Engine first")
+        self.engine, self.device = engine, engine.device
+        self._lib, self._h = engine._lib, engine._h
+        self.base_lr = self.lr = lr
+        self.weight_decay, self.betas, self.eps, self.grad_clip = weight_decay, betas, eps, grad_clip
+        self.mse_weight, self.l1_weight, self.use_smoothing = mse_weight, l1_weight, use_smoothing
+        self.max_windows = max_windows
+        with torch.cuda.device(self.device):
+            check(self._lib.km_train_init(self._h, max_windows, _stream_ptr(self.device)))
+        self.n_params = int(self._lib.km_train_num_params(self._h))
+        self.flat_grad = torch.zeros(self.n_params, device=self.device)
+        self.loss = torch.zeros(1, device=self.device)
+        self.out = torch.zeros(max_windows, 52, device=self.device)
+        self.ema_state = torch.zeros(max_windows, 52, device=self.device)
+        self._ema_batch: Optional[int] = None
+        self.step_count = 0
+        self.epoch = 0
+
+    # ---- introspection --------------------------------------------------------------------------
+    def offset(self, key: str) -> int:
+        off = int(self._lib.km_train_param_offset(self._h, key.encode()))
+        if off < 0:
+            raise KeyError(key)
+        return off
+
+    def grads(self, shapes: Dict[str, tuple]) -> Dict[str, np.ndarray]:
+        flat = self.flat_grad.cpu().numpy()
+        return {k: flat[self.offset(k):self.offset(k) + int(np.prod(s, dtype=np.int64))].reshape(s).copy()
+                for k, s in shapes.items()}
+
+    def params(self, shapes: Dict[str, tuple]) -> Dict[str, np.ndarray]:
+        flat = np.empty(self.n_params, np.float32)
+        check(self._lib.km_train_get_params(self._h, flat.ctypes.data, self.n_params))
+        return {k: flat[self.offset(k):self.offset(k) + int(np.prod(s, dtype=np.int64))].reshape(s).copy()
+                for k, s in shapes.items()}
+
+    def reset_temporal_state(self):
+        self._ema_batch = None
+
+    # ---- one optimisation step ------------------------------------------------------------------
+    def _ema_args(self, B):
+        if not self.use_smoothing:
+            return 0, 1
+        first = self._ema_batch != B          # first call or batch-size change (simplified_dual_stream_model.py:357-359)
+        self._ema_batch = B
+        return _ptr(self.ema_state), (1 if first else 0)
+
+    def forward_backward_mel(self, mel, mel_short, emotion, target):
+        B, T_in, _ = mel.shape
+        st, first = self._ema_args(B)
+        check(self._lib.km_train_step(self._h, _ptr(mel.contiguous()), B, T_in, _ptr(mel_short.contiguous()),
+                                      _ptr(emotion.contiguous()), _ptr(target.contiguous()), self.mse_weight,
+                                      self.l1_weight, _ptr(self.flat_grad), _ptr(self.loss), _ptr(self.out), st, first,
+                                      _stream_ptr(self.device)))
+        return self.loss
+
+    def forward_backward(self, audio, emotion, target):
+        B, L = audio.shape
+        self.engine.reserve(B, L)
+        st, first = self._ema_args(B)
+        check(self._lib.km_train_step_audio(self._h, _ptr(audio.contiguous()), B, L, _ptr(emotion.contiguous()),
+                                            _ptr(target.contiguous()), self.mse_weight, self.l1_weight,
+                                            _ptr(self.flat_grad), _ptr(self.loss), _ptr(self.out), st, first,
+                                            _stream_ptr(self.device)))
+        return self.loss
+
+    def optimizer_step(self):
+        parallel.allreduce_gradients(self.flat_grad)         # the ONE collective of the training step
+        self.step_count += 1
+        check(self._lib.km_train_adamw(self._h, _ptr(self.flat_grad), self.lr, self.betas[0], self.betas[1], self.eps,
+                                       self.weight_decay, self.grad_clip if self.grad_clip else 0.0, self.step_count,
+                                       _stream_ptr(self.device)))
+
+    def step(self, audio, emotion, target) -> torch.Tensor:
+        """forward + loss + backward + all-reduce + clip + AdamW on this rank's windows; returns the loss (device)."""
+        self.forward_backward(audio, emotion, target)
+        self.optimizer_step()
+        return self.loss
+
+    def end_epoch(self):
+        """scheduler.step() of the reference (:209)."""
+        self.epoch += 1
+        self.lr = cosine_warm_restarts_lr(self.epoch, self.base_lr)
+
+    def sync_inference_weights(self):
+        """Fold + pack the trained master weights so the inference kernels see them (km_train_sync)."""
+        with torch.cuda.device(self.device):
+            check(self._lib.km_train_sync(self._h, _stream_ptr(self.device)))

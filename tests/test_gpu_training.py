@@ -1,0 +1,134 @@
+"""Training step parity: HIP forward/backward gradients against torch.autograd on the REFERENCE
+module (golden G7, tests/golden/core_*_grads.npz), and forward + clip + AdamW against torch.optim.AdamW driven by the
+oracle's autograd over several steps."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_case
+from koemorph_amd import synth
+from koemorph_amd.engine import Engine
+from koemorph_amd.training import Trainer, cosine_warm_restarts_lr
+from oracle import core
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def make(params, c, **kw):
+    e = Engine(d_model=c["d"], num_heads=c["H"], mel_sequence_length=c["T"])
+    e.load_state_dict(params)
+    e.finalize()
+    return e, Trainer(e, max_windows=c["B"], use_smoothing=False, **kw)
+
+
+@pytest.mark.parametrize("name", ["core_d64_T32_H4_small", "core_d256_T256_H8_grads"])
+def test_gradients_match_reference_autograd(name):
+    c, params, (mel, short, emo), g = golden_case(name)
+    target = synth.uniform(c["seed"] * 3 + 1, (c["B"], 52), 0.0, 1.0)
+    e, tr = make(params, c)
+    loss = tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target))
+    assert abs(float(loss.item()) - float(g["loss"])) < 1e-6 * max(1.0, abs(float(g["loss"])))
+    np.testing.assert_allclose(tr.out[:c["B"]].cpu().numpy(), g["blendshapes"], atol=2e-6)
+    grads = tr.grads({k: v.shape for k, v in params.items()})
+    for k, v in grads.items():
+        if "grad/" + k in g:
+            ref = g["grad/" + k]
+            np.testing.assert_allclose(v, ref, atol=1e-7 + 2e-4 * np.abs(ref).max(), rtol=2e-4, err_msg=k)
+        else:
+            ref = g["gradsample/" + k]
+            np.testing.assert_allclose(v.ravel()[::97], ref, atol=1e-7 + 2e-4 * np.abs(ref).max(), rtol=2e-4, err_msg=k)
+            n = np.sqrt(np.sum(v.astype(np.float64) ** 2))
+            assert abs(n - float(g["gradnorm/" + k])) <= 2e-4 * float(g["gradnorm/" + k]) + 1e-9, k
+
+
+def test_training_loop_matches_torch_adamw_with_ema_and_l1():
+    """4 optimisation steps, EMA inside the forward (stateful across steps like the reference), MSE + L1, global-norm
+    clipping, AdamW: compared with the same loop in torch (autograd on the oracle forward, torch.optim.AdamW)."""
+    c = dict(d=64, T=32, H=4, B=5)
+    params = synth.make_core_params(71, 64, 32, 256, "trained")
+    params_full = dict(params)
+    e = Engine(d_model=64, num_heads=4, mel_sequence_length=32)
+    e.load_state_dict(params)
+    e.load_param("smoothing_alpha", np.float32(0.3))
+    e.finalize()
+    tr = Trainer(e, max_windows=5, lr=3e-3, weight_decay=1e-2, grad_clip=0.05, mse_weight=1.0, l1_weight=0.1,
+                 use_smoothing=True)
+    P = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in params.items()}
+    alpha_p = torch.tensor(0.3, requires_grad=True)
+    opt = torch.optim.AdamW(list(P.values()) + [alpha_p], lr=3e-3, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    prev = None
+    for step in range(4):
+        mel, short, emo = synth.make_core_inputs(300 + step, 5, 33, style="randn")
+        target = synth.uniform(400 + step, (5, 52), 0, 1)
+        loss_gpu = tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target))
+        # torch side
+        opt.zero_grad()
+        x = core.core_forward(P, mel, short, emo, num_heads=4, mel_sequence_length=32)["blendshapes"]
+        if prev is None:
+            y = x
+        else:
+            a = torch.sigmoid(alpha_p)
+            y = a * x + (1 - a) * prev
+        prev = y.detach()
+        t = torch.from_numpy(target)
+        loss = torch.nn.functional.mse_loss(y, t) + 0.1 * torch.nn.functional.l1_loss(y, t)
+        loss.backward()
+        assert abs(float(loss_gpu.item()) - float(loss.item())) < 2e-6 * max(1.0, float(loss.item())), step
+        if step > 0:
+            ga = tr.grads({"smoothing_alpha": ()})["smoothing_alpha"]
+            assert abs(float(ga) - float(alpha_p.grad)) < 1e-7 + 2e-4 * abs(float(alpha_p.grad))
+        torch.nn.utils.clip_grad_norm_(list(P.values()) + [alpha_p], 0.05)
+        opt.step()
+        tr.optimizer_step()
+    got = tr.params({**{k: v.shape for k, v in params.items()}, "smoothing_alpha": ()})
+    for k, v in P.items():
+        a, b = got[k], v.detach().numpy()
+        if k == "mel_attention.in_proj_bias":
+            # the key bias shifts every score of a query row equally, so its gradient is EXACTLY zero in exact
+            # arithmetic (softmax shift invariance); both sides hold rounding noise there, which Adam's
+            # m / sqrt(v) turns into +-lr-sized steps of random sign.  Compare the q and v thirds tightly and
+            # bound the k third by the total step budget.
+            np.testing.assert_allclose(a[:64], b[:64], atol=2e-6, rtol=2e-5, err_msg=k + "[q]")
+            np.testing.assert_allclose(a[128:], b[128:], atol=2e-6, rtol=2e-5, err_msg=k + "[v]")
+            assert np.abs(a[64:128] - b[64:128]).max() <= 2 * 4 * 3e-3
+            continue
+        # Adam divides by sqrt(v): elements whose gradient is at rounding-noise level move by lr-sized steps whose
+        # sign is noise on BOTH sides, so demand tight agreement on >= 99.9 % of every tensor and bound the rest
+        # well below one step (lr = 3e-3)
+        bad = np.abs(a - b) > 2e-6 + 2e-5 * np.abs(b)
+        assert bad.mean() <= 1e-3, (k, bad.mean())
+        assert np.abs(a - b).max() < 1e-4, (k, np.abs(a - b).max())
+    assert abs(float(got["smoothing_alpha"]) - float(alpha_p.detach())) < 2e-6
+    # the trained weights reach the inference kernels
+    tr.sync_inference_weights()
+    mel, short, emo = synth.make_core_inputs(999, 3, 33, style="randn")
+    want = core.core_forward_np({k: v.detach().numpy() for k, v in P.items()}, mel, short, emo, num_heads=4,
+                                mel_sequence_length=32)["blendshapes"]
+    inf = e.core_forward(dev(mel), dev(short), dev(emo))["blendshapes"].cpu().numpy()
+    assert np.abs(inf - want).max() < 5e-6
+
+
+def test_train_step_from_audio_and_schedule():
+    """BASELINE config 3 shape on one rank: 8 windows of 136448 samples, window 256, d_model 256."""
+    params = synth.make_core_params(72, style="init")
+    e = Engine()
+    e.load_state_dict(params)
+    e.finalize()
+    tr = Trainer(e, max_windows=8)
+    audio = dev(synth.make_audio(73, 8, 136448))
+    emo = dev(synth.normal(74, (8, 256)))
+    target = dev(synth.uniform(75, (8, 52), 0, 1))
+    losses = [float(tr.step(audio, emo, target).item()) for _ in range(6)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]           # it learns the (fixed) batch
+    assert tr.n_params >= 837738 and tr.step_count == 6
+    # CosineAnnealingWarmRestarts(T_0=10, T_mult=2, eta_min=1e-6) against torch
+    p = torch.nn.Parameter(torch.zeros(1))
+    o = torch.optim.AdamW([p], lr=1e-4)
+    s = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(o, T_0=10, T_mult=2, eta_min=1e-6)
+    for ep in range(1, 35):
+        o.step(); s.step()
+        assert abs(cosine_warm_restarts_lr(ep, 1e-4) - o.param_groups[0]["lr"]) < 1e-12
