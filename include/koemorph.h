@@ -172,6 +172,19 @@ int km_forward_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L,
                      const float* emotion_dev, float* out_dev, float* state_dev, int32_t first,
                      void* stream);
 
+/* Throughput mode of km_forward_audio: a two-deep software pipeline ACROSS calls.  The front end (VALU/LDS bound
+ * FFT) of call i runs on an internal stream concurrently with the fused core (fp32-MFMA bound) of call i-1, which
+ * the hardware co-schedules on the same CUs (separate matrix and vector pipes); the power-mel workspace is double
+ * buffered.  Differences from km_forward_audio:
+ *   - out_dev (and state_dev) of call i are complete only after the NEXT pipelined call returns and the caller's
+ *     stream has advanced past it, or after km_pipeline_flush(h, stream);
+ *   - audio_dev / emotion_dev of call i must stay untouched until then as well.
+ * EMA state is applied in call order.  Mixing with the non-pipelined entry points requires a flush in between. */
+int km_forward_audio_pipelined(km_handle h, const float* audio_dev, int64_t B, int64_t L,
+                               const float* emotion_dev, float* out_dev, float* state_dev, int32_t first,
+                               void* stream);
+int km_pipeline_flush(km_handle h, void* stream);
+
 /* Sequence forward.  Replaces SequentialDualStreamModel.forward
  * (src/model/sequential_dual_stream_model.py:63-167): slides a mel_sequence_length-frame
  * window with stride_frames over each clip, one output frame per position, EMA reset at the
@@ -263,10 +276,12 @@ int km_stream_tick(km_handle h, const float* emotion_dev, float* out_dev, uint8_
 int km_stream_reset(km_handle h, void* stream);
 
 /* ---- measurement aid used by bench.py ------------------------------------------------------------
- * With stage timing enabled, km_forward_audio records HIP events on the launch stream around its three
- * kernels (emotion logits, power-mel front end, fused core); km_stage_times synchronises on the last
- * event and returns the elapsed milliseconds of the most recent call: ms[0] emotion, ms[1] front end,
- * ms[2] core.  Event records are not graph-capturable: keep it off in production. */
+ * With stage timing enabled, km_forward_audio / km_forward_audio_pipelined record HIP events on the stream each
+ * kernel is launched on, right before and after it (emotion logits, power-mel front end, fused core);
+ * km_stage_times synchronises on the last event and returns the elapsed milliseconds of the most recent call:
+ * ms[0] emotion, ms[1] front end, ms[2] core -- in pipelined mode these are the durations WHILE the other
+ * call's kernel shares the chip, i.e. what rocprofv3 reports per dispatch.  Event records are not
+ * graph-capturable: keep it off in production. */
 int km_enable_stage_timing(km_handle h, int32_t enable);
 int km_stage_times(km_handle h, float* ms3);
 

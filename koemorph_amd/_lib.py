@@ -74,6 +74,8 @@ SIGNATURES = {
     "km_core_forward_z": (C.c_int, [_h, _p, _i64, _i64, _p, _p, _p, _p, _p, _p]),
     "km_smooth": (C.c_int, [_h, _p, _p, _i64, _i32, _p]),
     "km_forward_audio": (C.c_int, [_h, _p, _i64, _i64, _p, _p, _p, _i32, _p]),
+    "km_forward_audio_pipelined": (C.c_int, [_h, _p, _i64, _i64, _p, _p, _p, _i32, _p]),
+    "km_pipeline_flush": (C.c_int, [_h, _p]),
     "km_sequence_num_outputs": (_i64, [_h, _i64, _i32]),
     "km_sequence_forward": (C.c_int, [_h, _p, _i64, _i64, _p, _i32, _i32, _p, _p]),
     "km_train_init": (C.c_int, [_h, _i64, _p]),

@@ -42,6 +42,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-Wall", "-Wno-unused-function",
            "-Wno-unused-const-variable"]
+    cmd += os.environ.get("KM_EXTRA_FLAGS", "").split()          # kernel A/B experiments (tools/ab_mel.sh)
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     tmp = LIB_PATH + ".tmp%d" % os.getpid()
     cmd += ["-o", tmp]

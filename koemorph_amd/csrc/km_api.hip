@@ -16,6 +16,7 @@ using namespace km;
 
 static int free_streams(Context* c);
 static int free_train(Context* c);
+static int free_pipeline(Context* c);
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -110,6 +111,14 @@ int km_destroy(km_handle h) {
     (void)free_ws(c);
     (void)free_streams(c);
     (void)free_train(c);
+    (void)free_pipeline(c);
+    if (c->pipe_s1) {
+        (void)hipStreamDestroy((hipStream_t)c->pipe_s1); (void)hipStreamDestroy((hipStream_t)c->pipe_s2);
+        for (int i = 0; i < 2; ++i) {
+            (void)hipEventDestroy((hipEvent_t)c->pipe_ev_in[i]); (void)hipEventDestroy((hipEvent_t)c->pipe_ev_mel[i]);
+            (void)hipEventDestroy((hipEvent_t)c->pipe_ev_core[i]);
+        }
+    }
     for (MelPlan* p : c->mel_plans) free_mel_plan(p);
     for (void* e : c->stage_ev)
         if (e) (void)hipEventDestroy((hipEvent_t)e);
@@ -367,9 +376,9 @@ int km_forward_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L, 
     if (int rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, stream)) return rc;
     if (tm) HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[1], st));
     if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, L, stream)) return rc;
-    if (tm) HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[2], st));
+    if (tm) { HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[2], st)); HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[3], st)); }
     if (int rc = launch_core_fused_db(c, c->mel_plans[0], B, n_frames, c->ws_zemo, out_dev, state_dev, first, stream)) return rc;
-    if (tm) HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[3], st));
+    if (tm) HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[4], st));
     return KM_OK;
 }
 
@@ -460,7 +469,7 @@ int km_enable_stage_timing(km_handle h, int32_t enable) {
     if (!h) return fail(KM_ERR_INVALID_ARG, "NULL handle");
     Context* c = h;
     if (enable && !c->stage_ev[0])
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 5; ++i) {
             hipEvent_t e;
             HIP_TRY(hipEventCreate(&e));
             c->stage_ev[i] = e;
@@ -473,9 +482,96 @@ int km_stage_times(km_handle h, float* ms3) {
     if (!h || !ms3) return fail(KM_ERR_INVALID_ARG, "km_stage_times: NULL argument");
     Context* c = h;
     if (!c->stage_ev[0]) return fail(KM_ERR_INVALID_ARG, "stage timing was never enabled");
-    HIP_TRY(hipEventSynchronize((hipEvent_t)c->stage_ev[3]));
-    for (int i = 0; i < 3; ++i)
-        HIP_TRY(hipEventElapsedTime(&ms3[i], (hipEvent_t)c->stage_ev[i], (hipEvent_t)c->stage_ev[i + 1]));
+    HIP_TRY(hipEventSynchronize((hipEvent_t)c->stage_ev[4]));
+    HIP_TRY(hipEventElapsedTime(&ms3[0], (hipEvent_t)c->stage_ev[0], (hipEvent_t)c->stage_ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms3[1], (hipEvent_t)c->stage_ev[1], (hipEvent_t)c->stage_ev[2]));
+    HIP_TRY(hipEventElapsedTime(&ms3[2], (hipEvent_t)c->stage_ev[3], (hipEvent_t)c->stage_ev[4]));
+    return KM_OK;
+}
+
+static int free_pipeline(Context* c) {
+    for (int i = 0; i < 2; ++i) {
+        if (c->pipe_melpow[i]) HIP_TRY(hipFree(c->pipe_melpow[i]));
+        if (c->pipe_melmax[i]) HIP_TRY(hipFree(c->pipe_melmax[i]));
+        if (c->pipe_zemo[i]) HIP_TRY(hipFree(c->pipe_zemo[i]));
+        c->pipe_melpow[i] = nullptr; c->pipe_melmax[i] = nullptr; c->pipe_zemo[i] = nullptr; c->pipe_dirty[i] = true;
+    }
+    c->pipe_windows = c->pipe_frames = 0;
+    return KM_OK;
+}
+
+static int ensure_pipeline(Context* c, int64_t B, int64_t n_frames) {
+    if (!c->pipe_s1) {
+        hipStream_t s;
+        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); c->pipe_s1 = s;
+        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); c->pipe_s2 = s;
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->pipe_ev_in[i] = e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->pipe_ev_mel[i] = e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->pipe_ev_core[i] = e;
+        }
+    }
+    if (B <= c->pipe_windows && n_frames <= c->pipe_frames) return KM_OK;
+    HIP_TRY(hipDeviceSynchronize());                       // growing the slots: nothing may be in flight
+    if (int rc = free_pipeline(c)) return rc;
+    const int64_t W = B, F = n_frames;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->pipe_melpow[i]), (size_t)W * F * c->NK * sizeof(float)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->pipe_melmax[i]), (size_t)W * sizeof(unsigned)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->pipe_zemo[i]), (size_t)W * sizeof(float)));
+    }
+    c->pipe_windows = W; c->pipe_frames = F; c->pipe_seq = 0;
+    return KM_OK;
+}
+
+int km_forward_audio_pipelined(km_handle h, const float* audio_dev, int64_t B, int64_t L, const float* emotion_dev,
+                               float* out_dev, float* state_dev, int32_t first, void* stream) {
+    if (int rc = need_dual(h)) return rc;
+    Context* c = h;
+    if (!audio_dev || !emotion_dev || !out_dev || B <= 0 || L <= 0)
+        return fail(KM_ERR_INVALID_ARG, "km_forward_audio_pipelined: bad argument");
+    if (!c->fused_ok) return fail(KM_ERR_UNSUPPORTED, "the pipelined mode needs the fused kernel shape (d_model 256, window 256, 8 heads)");
+    const int64_t n_frames = 1 + L / c->cfg.mel.hop_length;
+    if (B > c->ws_windows || n_frames > c->ws_frames)
+        return fail(KM_ERR_WORKSPACE, "workspace too small for %lld windows x %lld samples: call km_reserve", (long long)B, (long long)L);
+    if (int rc = ensure_pipeline(c, B > c->ws_windows ? B : c->ws_windows, n_frames > c->ws_frames ? n_frames : c->ws_frames)) return rc;
+    const int slot = (int)(c->pipe_seq & 1);
+    hipStream_t caller = (hipStream_t)stream, s1 = (hipStream_t)c->pipe_s1, s2 = (hipStream_t)c->pipe_s2;
+    const bool tm = c->stage_timing;
+    // redirect the workspace pointers the launchers read to this call's slot
+    float* keep_pow = c->ws_melpow; unsigned* keep_max = c->ws_melmax; float* keep_z = c->ws_zemo; const bool keep_dirty = c->melmax_dirty;
+    c->ws_melpow = c->pipe_melpow[slot]; c->ws_melmax = c->pipe_melmax[slot]; c->ws_zemo = c->pipe_zemo[slot];
+    c->melmax_dirty = c->pipe_dirty[slot];
+    int rc = KM_OK;
+    do {
+        if (hipEventRecord((hipEvent_t)c->pipe_ev_in[slot], caller) != hipSuccess) { rc = fail(KM_ERR_HIP, "hipEventRecord failed"); break; }
+        if (hipStreamWaitEvent(s1, (hipEvent_t)c->pipe_ev_in[slot], 0) != hipSuccess) { rc = fail(KM_ERR_HIP, "hipStreamWaitEvent failed"); break; }
+        if (tm) (void)hipEventRecord((hipEvent_t)c->stage_ev[0], s1);
+        if ((rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, s1))) break;
+        if (tm) (void)hipEventRecord((hipEvent_t)c->stage_ev[1], s1);
+        if ((rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, L, s1))) break;
+        if (tm) (void)hipEventRecord((hipEvent_t)c->stage_ev[2], s1);
+        (void)hipEventRecord((hipEvent_t)c->pipe_ev_mel[slot], s1);
+        (void)hipStreamWaitEvent(s2, (hipEvent_t)c->pipe_ev_mel[slot], 0);
+        if (tm) (void)hipEventRecord((hipEvent_t)c->stage_ev[3], s2);
+        if ((rc = launch_core_fused_db(c, c->mel_plans[0], B, n_frames, c->ws_zemo, out_dev, state_dev, first, s2))) break;
+        if (tm) (void)hipEventRecord((hipEvent_t)c->stage_ev[4], s2);
+        (void)hipEventRecord((hipEvent_t)c->pipe_ev_core[slot], s2);
+        // stream-order visibility of the PREVIOUS call's result (and release of its slot for the next call)
+        if (c->pipe_seq > 0) (void)hipStreamWaitEvent(caller, (hipEvent_t)c->pipe_ev_core[slot ^ 1], 0);
+    } while (0);
+    c->pipe_dirty[slot] = c->melmax_dirty;
+    c->ws_melpow = keep_pow; c->ws_melmax = keep_max; c->ws_zemo = keep_z; c->melmax_dirty = keep_dirty;
+    if (rc == KM_OK) c->pipe_seq += 1;
+    return rc;
+}
+
+int km_pipeline_flush(km_handle h, void* stream) {
+    if (int rc = need_dual(h)) return rc;
+    Context* c = h;
+    if (c->pipe_seq > 0 && c->pipe_s1)
+        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)c->pipe_ev_core[(c->pipe_seq - 1) & 1], 0));
     return KM_OK;
 }
 

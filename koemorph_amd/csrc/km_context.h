@@ -94,7 +94,13 @@ struct Context {
     bool tr_alpha_live = false;      // smoothing_alpha was in the last step's graph (see adamw_kernel)
     int64_t tr_alpha_steps = 0;
     bool stage_timing = false;
-    void* stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // hipEvent_t
+    void* stage_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // hipEvent_t: emo b/e, mel e, core b/e
+    // two-deep pipeline across calls (km_forward_audio_pipelined)
+    void* pipe_s1 = nullptr; void* pipe_s2 = nullptr;      // hipStream_t: front end / core
+    void* pipe_ev_in[2] = {nullptr, nullptr}; void* pipe_ev_mel[2] = {nullptr, nullptr}; void* pipe_ev_core[2] = {nullptr, nullptr};
+    float* pipe_melpow[2] = {nullptr, nullptr}; unsigned* pipe_melmax[2] = {nullptr, nullptr}; float* pipe_zemo[2] = {nullptr, nullptr};
+    bool pipe_dirty[2] = {true, true};
+    int64_t pipe_seq = 0, pipe_windows = 0, pipe_frames = 0;
     bool melmax_dirty = true;      // ws_melmax may hold stale maxima (see launch_mel_power)
 };
 

@@ -117,7 +117,7 @@ struct MelArgs {
 };
 
 // raw samples of the frame pair (fa, fa+1) into z[i] = (x_a[lane + 64 i], x_b[lane + 64 i]); wave-uniform fa
-template <int NFFT>
+template <int NFFT, bool RING>
 __device__ __forceinline__ void load_pair(const MelArgs& a, const float* __restrict__ x, int64_t Lv, int rs, int fa,
                                           int lane, float2 (&z)[NFFT / 64]) {
     constexpr int R0 = NFFT / 64;
@@ -128,7 +128,7 @@ __device__ __forceinline__ void load_pair(const MelArgs& a, const float* __restr
     }
     const int64_t p0 = (int64_t)fa * a.hop - NFFT / 2;
     const bool have_b = fa + 1 < a.n_frames;
-    if (rs >= 0) {                                            // ring: logical sample q lives at (rs + q) mod L
+    if constexpr (RING) {                                     // ring: logical sample q lives at (rs + q) mod L
         const int Li = (int)Lv;
 #pragma unroll
         for (int i = 0; i < R0; ++i) {
@@ -175,7 +175,10 @@ __device__ __forceinline__ void load_pair(const MelArgs& a, const float* __restr
     }
 }
 
-template <int NFFT>
+// RING = true is the streaming instantiation (device rings read with modular addressing).  It is a separate
+// instantiation on purpose: as a run-time branch its address arithmetic pushed the batch kernel from 222 to 310
+// registers (1 wave per SIMD, 1.7x slower).
+template <int NFFT, bool RING>
 __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
     using namespace mel;
     constexpr int R0 = NFFT / 64;          // 16 or 8
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
     const float* x = a.audio + clip * a.clip_len + woff;
     const int64_t Lv = (a.clip_len - woff) < a.L ? (a.clip_len - woff) : a.L;   // samples that exist; the rest reads as zero
     if (a.ready && !a.ready[b]) return;                        // workgroup-uniform: stream still filling
-    const int rs = a.ring_start ? a.ring_start[b] : -1;
+    const int rs = RING ? a.ring_start[b] : -1;
     float2* buf = fbuf + wave * FFT_BUF;
     const int n_chunks = (a.n_frames + FPB - 1) / FPB;
 
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
     float vmax = 0.f;
     float2 zn[R0];                          // software prefetch: raw samples of the NEXT pair of this wave
     int chunk = blockIdx.x;
-    load_pair<NFFT>(a, x, Lv, rs, chunk * FPB + 2 * wave, lane, zn);
+    load_pair<NFFT, RING>(a, x, Lv, rs, chunk * FPB + 2 * wave, lane, zn);
     for (; chunk < n_chunks; chunk += gridDim.x) {
         const int f0 = chunk * FPB;
 #pragma unroll 1
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
             {   // issue the next pair's loads now; they complete under this pair's FFT
                 const int fn = (pi + 1 < FPB / 2 / WAVES) ? fa + 2 * WAVES
                                                           : (chunk + (int)gridDim.x) * FPB + 2 * wave;
-                load_pair<NFFT>(a, x, Lv, rs, (pi + 1 < FPB / 2 / WAVES || chunk + (int)gridDim.x < n_chunks) ? fn : a.n_frames,
+                load_pair<NFFT, RING>(a, x, Lv, rs, (pi + 1 < FPB / 2 / WAVES || chunk + (int)gridDim.x < n_chunks) ? fn : a.n_frames,
                                 lane, zn);
             }
             if (fa < a.n_frames) {   // wave-uniform
@@ -430,9 +433,13 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     if (!p->uploaded) return fail(KM_ERR_NOT_FINALIZED, "mel plan not uploaded (km_finalize / km_reserve first)");
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_kernel<1024>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_kernel<1024, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)mel_lds_bytes(1024)));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_kernel<512>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_kernel<512, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)mel_lds_bytes(512)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_kernel<1024, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)mel_lds_bytes(1024)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_kernel<512, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)mel_lds_bytes(512)));
         attr_set = true;
     }
@@ -458,10 +465,11 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     if (per_window > n_chunks) per_window = n_chunks;
     if (per_window < 1) per_window = 1;
     const dim3 grid((unsigned)per_window, (unsigned)B);
-    if (m.n_fft == 1024)
-        hipLaunchKernelGGL(mel_power_kernel<1024>, grid, dim3(256), mel_lds_bytes(1024, m.n_mels, a.fb_nnz), st, a);
-    else
-        hipLaunchKernelGGL(mel_power_kernel<512>, grid, dim3(256), mel_lds_bytes(512, m.n_mels, a.fb_nnz), st, a);
+    const size_t lds = mel_lds_bytes(m.n_fft, m.n_mels, a.fb_nnz);
+    if (m.n_fft == 1024 && !ring_start) hipLaunchKernelGGL((mel_power_kernel<1024, false>), grid, dim3(256), lds, st, a);
+    else if (m.n_fft == 1024) hipLaunchKernelGGL((mel_power_kernel<1024, true>), grid, dim3(256), lds, st, a);
+    else if (!ring_start) hipLaunchKernelGGL((mel_power_kernel<512, false>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((mel_power_kernel<512, true>), grid, dim3(256), lds, st, a);
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }

@@ -282,6 +282,24 @@ class Engine:
         check(self._lib.km_stage_times(self._h, ms))
         return float(ms[0]), float(ms[1]), float(ms[2])
 
+    def forward_audio_pipelined(self, audio, emotion, state=None, first: bool = True, out=None):
+        """Throughput mode (km_forward_audio_pipelined): the result is complete after the next pipelined call or
+        after pipeline_flush(); audio / emotion / out must stay alive and untouched until then."""
+        torch = _torch()
+        audio = self._chk(audio, "audio", 2)
+        emotion = self._chk(emotion, "emotion_features", 2)
+        B, L = audio.shape
+        self.reserve(B, L)
+        if out is None:
+            out = torch.empty(B, self.num_blendshapes, device=audio.device, dtype=torch.float32)
+        with torch.cuda.device(audio.device):
+            check(self._lib.km_forward_audio_pipelined(self._h, _ptr(audio), B, L, _ptr(emotion), _ptr(out), _ptr(state),
+                                                       1 if first else 0, _stream_ptr(audio.device)))
+        return out
+
+    def pipeline_flush(self) -> None:
+        check(self._lib.km_pipeline_flush(self._h, _stream_ptr(self.device)))
+
     def sequence_forward(self, audio, emotion, stride_frames: int = 1, smooth: bool = True, max_tile: int = 2048):
         """audio (B, L) -> (B, N, 52): one frame per window position (km_sequence_forward)."""
         torch = _torch()

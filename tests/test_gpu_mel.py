@@ -129,3 +129,24 @@ def test_fused_pipeline_is_bit_identical_to_staged_pipeline(eng):
         e3 = dev(synth.normal(44, (3, 256)))
         long, short = eng.mel_batch(a)
         assert torch.equal(eng.forward_audio(a, e3), eng.core_forward(long, short, e3)["blendshapes"])
+
+
+def test_pipelined_forward_is_bit_identical_to_stream_ordered_forward(eng):
+    """km_forward_audio_pipelined (front end of call i overlapped with the core of call i-1 on internal streams,
+    double-buffered workspace) must give the same bits as km_forward_audio, EMA state included."""
+    audios = [dev(synth.make_audio(120 + i, 6, 136448)) for i in range(5)]
+    emos = [dev(synth.normal(130 + i, (6, 256))) for i in range(5)]
+    st_a = torch.zeros(6, 52, device="cuda")
+    ref = [eng.forward_audio(a, e, state=st_a, first=(i == 0)).clone() for i, (a, e) in enumerate(zip(audios, emos))]
+    st_b = torch.zeros(6, 52, device="cuda")
+    outs = [torch.empty(6, 52, device="cuda") for _ in range(5)]
+    for i, (a, e) in enumerate(zip(audios, emos)):
+        eng.forward_audio_pipelined(a, e, state=st_b, first=(i == 0), out=outs[i])
+    eng.pipeline_flush()
+    torch.cuda.synchronize()
+    for i in range(5):
+        assert torch.equal(outs[i], ref[i]), i
+    assert torch.equal(st_a, st_b)
+    # and back to the stream-ordered entry point after a flush
+    again = eng.forward_audio(audios[0], emos[0])
+    assert torch.equal(again, eng.forward_audio(audios[0], emos[0]))
