@@ -196,10 +196,11 @@ int km_core_forward_z(km_handle h, const float* mel_dev, int64_t B, int64_t T_in
 }
 
 static int free_train(Context* c) {
-    void* ptrs[] = {c->tr_params, c->tr_m, c->tr_v, c->tr_act, c->tr_q, c->tr_dq, c->tr_part, c->tr_gnorm, c->tr_loss};
+    void* ptrs[] = {c->tr_params, c->tr_m, c->tr_v, c->tr_act, c->tr_q, c->tr_dq, c->tr_part, c->tr_gnorm, c->tr_loss, c->tr_red, c->tr_steps};
     for (void* p : ptrs)
         if (p) HIP_TRY(hipFree(p));
-    c->tr_params = c->tr_m = c->tr_v = c->tr_act = c->tr_q = c->tr_dq = c->tr_part = c->tr_gnorm = c->tr_loss = nullptr;
+    c->tr_params = c->tr_m = c->tr_v = c->tr_act = c->tr_q = c->tr_dq = c->tr_part = c->tr_gnorm = c->tr_loss = c->tr_red = nullptr;
+    c->tr_steps = nullptr;
     c->tr_windows = 0;
     return KM_OK;
 }
@@ -240,6 +241,9 @@ int km_train_init(km_handle h, int64_t max_windows, void* stream) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_part), 256 * sizeof(float)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_gnorm), sizeof(float)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_loss), sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_red), (size_t)32 * 2 * 2 * c->d * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_steps), 2 * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(c->tr_steps, 0, 2 * sizeof(int), (hipStream_t)stream));
     c->tr_windows = max_windows;
     return upload_train_params(c, stream);
 }

@@ -91,6 +91,8 @@ struct Context {
     float* tr_params = nullptr; float* tr_m = nullptr; float* tr_v = nullptr;
     float* tr_act = nullptr; float* tr_q = nullptr; float* tr_dq = nullptr; float* tr_part = nullptr; float* tr_gnorm = nullptr;
     float* tr_loss = nullptr;
+    float* tr_red = nullptr;         // split-reduction partials
+    int* tr_steps = nullptr;         // device-side AdamW step counters (graph replay safe)
     bool tr_alpha_live = false;      // smoothing_alpha was in the last step's graph (see adamw_kernel)
     int64_t tr_alpha_steps = 0;
     bool stage_timing = false;

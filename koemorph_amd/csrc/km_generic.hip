@@ -37,7 +37,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     } while (0)
 
 namespace gg {
-constexpr int BM = 64, BN = 64, BK = 16, LDT = 80;   // LDS tile row stride (floats)
+constexpr int BM = 64, BN = 64, BK = 32, LDT = 80;   // LDS tile row stride (floats)
+constexpr int EPT = BM * BK / 256;                   // staged elements per thread per operand
+}
+
+// Global -> register staging of one (64 x BK) A tile and one (BK x 64) B tile; the unit-stride dimension of each
+// operand is the fast thread index (coalescing).  Out-of-range elements read as zero.
+__device__ __forceinline__ void gemm_stage(const GemmArgs& g, const float* A, const float* Bp, int m0, int n0, int k0, int tid,
+                                           bool a_kfast, bool b_kfast, float (&ra)[gg::EPT], float (&rb)[gg::EPT]) {
+    using namespace gg;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int idx = tid + 256 * e;
+        int m, k;
+        if (a_kfast) { k = idx & (BK - 1); m = idx / BK; } else { m = idx & 63; k = idx >> 6; }
+        const int gm = m0 + m, gk = k0 + k;
+        ra[e] = (gm < g.M && gk < g.K) ? A[gm * g.a_rs + gk * g.a_cs] : 0.f;
+        int n, kb;
+        if (b_kfast) { kb = idx & (BK - 1); n = idx / BK; } else { n = idx & 63; kb = idx >> 6; }
+        const int gn = n0 + n, gkb = k0 + kb;
+        rb[e] = (gn < g.N && gkb < g.K) ? Bp[gkb * g.b_rs + gn * g.b_cs] : 0.f;
+    }
 }
 
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
@@ -52,30 +72,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const float* Bp = g.B + z1 * g.b_bs1 + z2 * g.b_bs2;
     float* C = g.C + z1 * g.c_bs1 + z2 * g.c_bs2;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-
-    // staging maps: make the unit-stride dimension of each operand the fast thread index (coalescing)
     const bool a_kfast = g.a_cs == 1;                        // A is K-contiguous (row-major M x K)
     const bool b_kfast = g.b_rs == 1;                        // B is K-contiguous (stored N x K, i.e. a transposed weight)
     f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) { acc[i][0] = f32x4{0, 0, 0, 0}; acc[i][1] = f32x4{0, 0, 0, 0}; }
 
+    // software pipeline (register staging): the next tile's global loads are in flight while the MFMAs of the
+    // current tile run; the flattened iteration space is (contraction batch) x (k tiles)
     const int kbn = g.kb_count > 0 ? g.kb_count : 1;
-    for (int kb = 0; kb < kbn; ++kb, A += g.a_kbs, Bp += g.b_kbs)
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
+    const int kt = (g.K + BK - 1) / BK, total = kbn * kt;
+    float ra[EPT], rb[EPT];
+    gemm_stage(g, A, Bp, m0, n0, 0, tid, a_kfast, b_kfast, ra, rb);
+    for (int it = 0; it < total; ++it) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {                        // 64 x 16 = 1024 elements per operand, 4 per thread
+        for (int e = 0; e < EPT; ++e) {
             const int idx = tid + 256 * e;
             int m, k;
-            if (a_kfast) { k = idx & 15; m = idx >> 4; } else { m = idx & 63; k = idx >> 6; }
-            const int gm = m0 + m, gk = k0 + k;
-            As[k * LDT + m] = (gm < g.M && gk < g.K) ? A[gm * g.a_rs + gk * g.a_cs] : 0.f;
+            if (a_kfast) { k = idx & (BK - 1); m = idx / BK; } else { m = idx & 63; k = idx >> 6; }
+            As[k * LDT + m] = ra[e];
             int n, kb;
-            if (b_kfast) { kb = idx & 15; n = idx >> 4; } else { n = idx & 63; kb = idx >> 6; }
-            const int gn = n0 + n, gkb = k0 + kb;
-            Bs[kb * LDT + n] = (gn < g.N && gkb < g.K) ? Bp[gkb * g.b_rs + gn * g.b_cs] : 0.f;
+            if (b_kfast) { kb = idx & (BK - 1); n = idx / BK; } else { n = idx & 63; kb = idx >> 6; }
+            Bs[kb * LDT + n] = rb[e];
         }
         __syncthreads();
+        if (it + 1 < total) {
+            const int nb = (it + 1) / kt, nk = (it + 1) - nb * kt;
+            gemm_stage(g, A + nb * g.a_kbs, Bp + nb * g.b_kbs, m0, n0, nk * BK, tid, a_kfast, b_kfast, ra, rb);
+        }
 #pragma unroll
         for (int s = 0; s < BK / 4; ++s) {
             const float* ar = As + (4 * s + lg) * LDT + 32 * wm + lj;

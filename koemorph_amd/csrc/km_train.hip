@@ -78,14 +78,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(float* __restrict__ dy, con
 }
 
 // dgamma[n] = sum_rows dy * xhat, dbeta[n] = sum_rows dy   (dy BEFORE ln_bwd_kernel overwrites it)
+// Rows are split over blockIdx.y (chunk rows each); with gridDim.y > 1 the outputs are per-chunk partials
+// [y][d] that reduce_partials_kernel sums in a fixed order (deterministic split reduction).
 __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t rows,
                                                             int d, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            float* __restrict__ dgam, float* __restrict__ dbet) {
+                                                            float* __restrict__ dgam, float* __restrict__ dbet, int64_t chunk) {
     __shared__ float sg[4][64], sb[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * chunk, r1 = (r0 + chunk) < rows ? (r0 + chunk) : rows;
+    dgam += (int64_t)blockIdx.y * d; dbet += (int64_t)blockIdx.y * d;
     float ag = 0.f, ab = 0.f;
     if (c < d)
-        for (int64_t r = rg; r < rows; r += 4) {
+        for (int64_t r = r0 + rg; r < r1; r += 4) {
             const float g = dy[r * d + c];
             ag += g * (x[r * d + c] - mean[r]) * rstd[r];
             ab += g;
@@ -100,18 +104,29 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restr
 
 // out[n] (+)= sum over rows of m[r * rs + n]
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ m, int64_t rows, int64_t rs, int n, float* __restrict__ out,
-                                                     int accumulate) {
+                                                     int accumulate, int64_t chunk) {
     __shared__ float sh[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * chunk, r1 = (r0 + chunk) < rows ? (r0 + chunk) : rows;
+    out += (int64_t)blockIdx.y * n;
     float a = 0.f;
     if (c < n)
-        for (int64_t r = rg; r < rows; r += 4) a += m[r * rs + c];
+        for (int64_t r = r0 + rg; r < r1; r += 4) a += m[r * rs + c];
     sh[rg][threadIdx.x & 63] = a;
     __syncthreads();
     if (rg == 0 && c < n) {
         const float s = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
         out[c] = accumulate ? out[c] + s : s;
     }
+}
+
+// out[c] (+)= sum_y part[y][c]
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int S, int n, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float s = 0.f;
+    for (int y = 0; y < S; ++y) s += part[(int64_t)y * n + c];
+    out[c] = accumulate ? out[c] + s : s;
 }
 
 // dS = P * (dP - rowsum(dP * P)), in place on dP; rows of width w <= 128
@@ -128,7 +143,80 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(float* __restrict__ dp
     if (lane + 64 < w) dp[row * w + lane + 64] = p1 * (g1 - s);
 }
 
+// z[row] = h[row] . w + b, one wave per row (decoder output layer, blendshape_decoder[3])
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ h, int64_t rows, int n, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float* __restrict__ z) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s = fmaf(h[row * n + i], w[i], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) z[row] = s + b[0];
+}
+
+// per-row logit gradients from dz (B, 52): g[b*28 + slot] for the mouth rows, g[B*28 + b] = sum over the 24 expression
+// coefficients (they share one row), and db2 = sum of everything
+__global__ __launch_bounds__(64) void row_grads_kernel(const float* __restrict__ dz, int B, float* __restrict__ g, float* __restrict__ db2) {
+    __shared__ float red[64];
+    const int i = threadIdx.x;
+    float tot = 0.f;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const float v = i < 52 ? dz[(int64_t)b * 52 + i] : 0.f;
+        const int slot = i < 52 ? tr_mouth_slot(i) : 0;
+        if (i < 52 && slot >= 0) g[(int64_t)b * 28 + slot] = v;
+        red[i] = (i < 52 && slot < 0) ? v : 0.f;
+        __syncthreads();
+        if (i == 0) {
+            float s = 0.f;
+            for (int k = 0; k < 52; ++k) s += red[k];
+            g[(int64_t)B * 28 + b] = s;
+        }
+        __syncthreads();
+        tot += v;
+    }
+    if (gridDim.x == 1) {       // single block: also the bias gradient, summed in a fixed order
+        red[i] = tot;
+        __syncthreads();
+        if (i == 0) {
+            float s = 0.f;
+            for (int k = 0; k < 64; ++k) s += red[k];
+            db2[0] = s;
+        }
+    }
+}
+
+// dH[row][m] = g[row] * w2[m] * [H[row][m] > 0]
+__global__ void relu_outer_bwd_kernel(const float* __restrict__ g, const float* __restrict__ h, const float* __restrict__ w2,
+                                      int64_t rows, int n, float* __restrict__ dh) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * n) return;
+    const int64_t r = i / n;
+    const int m = (int)(i - r * n);
+    dh[i] = h[i] > 0.f ? g[r] * w2[m] : 0.f;
+}
+
+// out[m] (+)= sum_r g[r] * h[r][m]   (rows split over blockIdx.y like colsum_kernel)
+__global__ __launch_bounds__(256) void wcolsum_kernel(const float* __restrict__ h, const float* __restrict__ g, int64_t rows, int n,
+                                                      float* __restrict__ out, int accumulate, int64_t chunk) {
+    __shared__ float sh[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * chunk, r1 = (r0 + chunk) < rows ? (r0 + chunk) : rows;
+    out += (int64_t)blockIdx.y * n;
+    float a = 0.f;
+    if (c < n)
+        for (int64_t r = r0 + rg; r < r1; r += 4) a = fmaf(g[r], h[r * n + c], a);
+    sh[rg][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (rg == 0 && c < n) {
+        const float s = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+        out[c] = accumulate ? out[c] + s : s;
+    }
+}
+
 struct TailArgs {
+    const float* zrows;   // (B*28 + B) decoder logits of the mouth rows, then of the shared expression rows (rowdot_kernel)
     const float* h1;      // (B*28, DH) post-ReLU hidden of the mouth rows
     const float* he;      // (B, DH)    post-ReLU hidden of the (shared) expression row
     const float* w2; const float* b2;
@@ -169,9 +257,7 @@ __global__ __launch_bounds__(64) void train_tail_kernel(TailArgs a) {
     if (i < 52) {
         const int slot = tr_mouth_slot(i);
         for (int b = 0; b < a.B; ++b) {
-            const float* h = slot >= 0 ? a.h1 + ((int64_t)b * 28 + slot) * a.DH : a.he + (int64_t)b * a.DH;
-            float z = a.b2[0];
-            for (int m = 0; m < a.DH; ++m) z = fmaf(h[m], a.w2[m], z);
+            const float z = slot >= 0 ? a.zrows[(int64_t)b * 28 + slot] : a.zrows[(int64_t)a.B * 28 + b];
             const float bs = 1.0f / (1.0f + expf(-z));
             const float f = wsum_s[i] * bs;
             const float x = fminf(fmaxf(f, 0.f), 1.f);
@@ -223,40 +309,6 @@ __global__ __launch_bounds__(64) void train_tail_kernel(TailArgs a) {
     }
 }
 
-// backward of the decoder output layer: dH (rows, DH) = dz_row * w2 * [H > 0] for the B*28 mouth rows and the B
-// expression rows (whose dz is the sum over the 24 expression coefficients), dw2 / db2 reductions.
-__global__ __launch_bounds__(256) void train_dh_kernel(const float* __restrict__ dz, const float* __restrict__ h1,
-                                                       const float* __restrict__ he, const float* __restrict__ w2, int B, int DH,
-                                                       float* __restrict__ dh1, float* __restrict__ dhe, float* __restrict__ dw2,
-                                                       float* __restrict__ db2) {
-    // grid.x covers DH in chunks of 256 columns
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= DH) return;
-    const float w = w2[m];
-    float acc = 0.f, accb = 0.f;
-    for (int b = 0; b < B; ++b) {
-        float dze = 0.f;
-        for (int i = 0; i < 52; ++i) {
-            const int slot = tr_mouth_slot(i);
-            const float g = dz[(int64_t)b * 52 + i];
-            accb += g;
-            if (slot >= 0) {
-                const int64_t row = (int64_t)b * 28 + slot;
-                const float h = h1[row * DH + m];
-                acc += g * h;
-                dh1[row * DH + m] = h > 0.f ? g * w : 0.f;
-            } else {
-                dze += g;
-            }
-        }
-        const float h = he[(int64_t)b * DH + m];
-        acc += dze * h;
-        dhe[(int64_t)b * DH + m] = h > 0.f ? dze * w : 0.f;
-    }
-    dw2[m] = acc;
-    if (m == 0) db2[0] = accb;
-}
-
 __global__ void zero_kernel(float* __restrict__ p, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.f;
@@ -286,20 +338,28 @@ __global__ __launch_bounds__(64) void sumsq_final_kernel(const float* __restrict
     }
 }
 
+__global__ void adamw_tick_kernel(int* __restrict__ steps, int alpha_live) {
+    steps[0] += 1;
+    if (alpha_live) steps[1] += 1;
+}
+
 // torch.nn.utils.clip_grad_norm_(max_norm) + torch.optim.AdamW (decoupled weight decay, bias correction)
 // smoothing_alpha is outside the autograd graph whenever the EMA passes its input through (first call / batch-size
 // change / smoothing off): torch leaves its .grad as None and AdamW then skips it entirely (no decay, no moment
 // update, its own step counter).  alpha_idx / alpha_live / (abc1, abc2) reproduce that.
 __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
                              int64_t n, const float* __restrict__ gnorm, float max_norm, float lr, float b1, float b2,
-                             float eps, float wd, float bc1, float bc2, int64_t alpha_idx, int alpha_live, float abc1,
-                             float abc2) {
+                             float eps, float wd, const int* __restrict__ steps, int64_t alpha_idx, int alpha_live) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // the 1-based step counters live on the device (advanced by adamw_tick_kernel) so that the launch can be replayed
+    // from a hipGraph: steps[0] = optimizer step, steps[1] = number of updates smoothing_alpha has received
+    int t = steps[0];
     if (i == alpha_idx) {
         if (!alpha_live) return;
-        bc1 = abc1; bc2 = abc2;
+        t = steps[1];
     }
+    const float bc1 = 1.0f - powf(b1, (float)t), bc2 = 1.0f - powf(b2, (float)t);
     float scale = 1.f;
     if (max_norm > 0.f) {
         const float c = max_norm / (gnorm[0] + 1e-6f);       // clip_coef, clamped to 1
@@ -341,8 +401,43 @@ static GemmArgs TN(const float* A, int64_t a_rs, const float* B, int64_t b_rs, f
     return G(A, 1, a_rs, B, b_rs, 1, C, c_rs, M, N, rows);
 }
 
-static int colsum(const float* m, int64_t rows, int64_t rs, int n, float* out, int accumulate, void* stream) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, m, rows, rs, n, out, accumulate);
+static constexpr int kRedSplit = 32;     // row chunks of a split reduction; scratch = kRedSplit x 2 x (2 d) floats
+
+static int split_of(int64_t rows, int64_t& chunk) {
+    int S = (int)((rows + 255) / 256);
+    if (S > kRedSplit) S = kRedSplit;
+    if (S < 1) S = 1;
+    chunk = (rows + S - 1) / S;
+    return S;
+}
+
+static int colsum(Context* c, const float* m, int64_t rows, int64_t rs, int n, float* out, int accumulate, void* stream) {
+    int64_t chunk;
+    const int S = split_of(rows, chunk);
+    hipStream_t st = (hipStream_t)stream;
+    if (S == 1) {
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((n + 63) / 64), 1), dim3(256), 0, st, m, rows, rs, n, out, accumulate, chunk);
+    } else {
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)S), dim3(256), 0, st, m, rows, rs, n, c->tr_red, 0, chunk);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->tr_red, S, n, out, accumulate);
+    }
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+static int ln_param_grad(Context* c, const float* dy, const float* x, int64_t rows, int d, const float* mean, const float* rstd,
+                         float* dgam, float* dbet, void* stream) {
+    int64_t chunk;
+    const int S = split_of(rows, chunk);
+    hipStream_t st = (hipStream_t)stream;
+    if (S == 1) {
+        hipLaunchKernelGGL(ln_param_grad_kernel, dim3((unsigned)((d + 63) / 64), 1), dim3(256), 0, st, dy, x, rows, d, mean, rstd, dgam, dbet, chunk);
+    } else {
+        float* pg = c->tr_red; float* pb = c->tr_red + (int64_t)kRedSplit * d;
+        hipLaunchKernelGGL(ln_param_grad_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)S), dim3(256), 0, st, dy, x, rows, d, mean, rstd, pg, pb, chunk);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, pg, S, d, dgam, 0);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, pb, S, d, dbet, 0);
+    }
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }
@@ -355,7 +450,7 @@ int64_t train_act_floats(Context* c) {
     return 2 * R * d /* Y0, Y */ + 2 * R /* mean, rstd */ + 2 * R * d /* KV */ + 2 * H * Rq * NKk /* P, dP */ +
            3 * Rq * d /* A, O1, O2 */ + Rq * DH /* H1 */ + 2 * R * d /* dKV */ + R * d /* dY */ + 2 * Rq * d /* ping-pong grads */ +
            Rq * DH /* dH1 */ + 5 * d /* E0, E, Ve, Oe1, Oe2 */ + 2 /* emo stats */ + DH /* He */ + 3 * d + DH /* emotion grads */ +
-           4 * 52 /* bs, out, dz, pad */;
+           4 * 52 /* bs, out, dz, pad */ + 2 * (Rq + 1) /* zrows, row grads */;
 }
 
 struct ParamView { const float* p; float* g; };
@@ -381,6 +476,7 @@ int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in
     float* emu = take(B); float* ers = take(B); float* He = take(B * DH);
     float* geA = take(B * d); float* geB = take(B * d); float* geC = take(B * d); float* dHe = take(B * DH);
     float* bs = take(B * 52); float* outb = take(B * 52); float* dz = take(B * 52);
+    float* zrows = take(Rq + B); float* grow = take(Rq + B);
     float* Qb = c->tr_q;            // (28, d)
     float* dQb = c->tr_dq;          // (28, d)
 
@@ -432,8 +528,12 @@ int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in
     {
         const int64_t n = c->tr_nparams;
         hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flat_grad, n);
+        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((Rq + 3) / 4)), dim3(256), 0, st, H1, Rq, (int)DH,
+                           P("blendshape_decoder.3.weight"), P("blendshape_decoder.3.bias"), zrows);
+        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, He, B, (int)DH,
+                           P("blendshape_decoder.3.weight"), P("blendshape_decoder.3.bias"), zrows + Rq);
         TailArgs t{};
-        t.h1 = H1; t.he = He; t.w2 = P("blendshape_decoder.3.weight"); t.b2 = P("blendshape_decoder.3.bias");
+        t.zrows = zrows; t.h1 = H1; t.he = He; t.w2 = P("blendshape_decoder.3.weight"); t.b2 = P("blendshape_decoder.3.bias");
         t.mel_w = P("mel_weights"); t.emo_w = P("emotion_weights"); t.temperature = c->cfg.temperature; t.target = target;
         t.bs = bs; t.out = outb; t.dz = dz; t.ema_state = ema_state; t.ema_first = ema_first; t.alpha_p = P("smoothing_alpha");
         t.mse_w = mse_w; t.l1_w = l1_w; t.loss = loss_dev; t.d_melw = Gd("mel_weights"); t.d_emow = Gd("emotion_weights");
@@ -443,23 +543,36 @@ int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in
     }
 
     // ================= backward =================
-    hipLaunchKernelGGL(train_dh_kernel, dim3((unsigned)((DH + 255) / 256)), dim3(256), 0, st, dz, H1, He,
-                       P("blendshape_decoder.3.weight"), (int)B, (int)DH, dH1, dHe, Gd("blendshape_decoder.3.weight"),
-                       Gd("blendshape_decoder.3.bias"));
+    {   // decoder output layer backward: row logit gradients, dH = g w2 [H > 0], dw2 = sum_rows g H, db2
+        hipLaunchKernelGGL(row_grads_kernel, dim3(1), dim3(64), 0, st, dz, (int)B, grow, Gd("blendshape_decoder.3.bias"));
+        const float* w2p = P("blendshape_decoder.3.weight");
+        hipLaunchKernelGGL(relu_outer_bwd_kernel, dim3((unsigned)((Rq * DH + 255) / 256)), dim3(256), 0, st, grow, H1, w2p, Rq, (int)DH, dH1);
+        hipLaunchKernelGGL(relu_outer_bwd_kernel, dim3((unsigned)((B * DH + 255) / 256)), dim3(256), 0, st, grow + Rq, He, w2p, B, (int)DH, dHe);
+        int64_t chunk;
+        const int S = split_of(Rq, chunk);
+        float* dw2 = Gd("blendshape_decoder.3.weight");
+        if (S == 1) {
+            hipLaunchKernelGGL(wcolsum_kernel, dim3((unsigned)((DH + 63) / 64), 1), dim3(256), 0, st, H1, grow, Rq, (int)DH, dw2, 0, chunk);
+        } else {
+            hipLaunchKernelGGL(wcolsum_kernel, dim3((unsigned)((DH + 63) / 64), (unsigned)S), dim3(256), 0, st, H1, grow, Rq, (int)DH, c->tr_red, 0, chunk);
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((DH + 255) / 256)), dim3(256), 0, st, c->tr_red, S, (int)DH, dw2, 0);
+        }
+        hipLaunchKernelGGL(wcolsum_kernel, dim3((unsigned)((DH + 63) / 64), 1), dim3(256), 0, st, He, grow + Rq, B, (int)DH, dw2, 1, B);
+    }
     // decoder[0] (shared by both streams): dW1 = dH1^T O2 + dHe^T Oe2, db1, dO2 = dH1 W1, dOe2 = dHe W1
     RUN(launch_gemm(TN(dH1, DH, O2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, Rq), 1, stream));
     { GemmArgs g = TN(dHe, DH, Oe2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, B); g.beta = 1.f; RUN(launch_gemm(g, 1, stream)); }
-    RUN(colsum(dH1, Rq, DH, (int)DH, Gd("blendshape_decoder.0.bias"), 0, stream));
-    RUN(colsum(dHe, B, DH, (int)DH, Gd("blendshape_decoder.0.bias"), 1, stream));
+    RUN(colsum(c, dH1, Rq, DH, (int)DH, Gd("blendshape_decoder.0.bias"), 0, stream));
+    RUN(colsum(c, dHe, B, DH, (int)DH, Gd("blendshape_decoder.0.bias"), 1, stream));
     RUN(launch_gemm(NN(dH1, DH, P("blendshape_decoder.0.weight"), d, gA, d, Rq, d, DH), 1, stream));               // dO2
     RUN(launch_gemm(NN(dHe, DH, P("blendshape_decoder.0.weight"), d, geA, d, B, d, DH), 1, stream));               // dOe2
     // mel_output_proj
     RUN(launch_gemm(TN(gA, d, O1, d, Gd("mel_output_proj.weight"), d, d, d, Rq), 1, stream));
-    RUN(colsum(gA, Rq, d, (int)d, Gd("mel_output_proj.bias"), 0, stream));
+    RUN(colsum(c, gA, Rq, d, (int)d, Gd("mel_output_proj.bias"), 0, stream));
     RUN(launch_gemm(NN(gA, d, P("mel_output_proj.weight"), d, gB, d, Rq, d, d), 1, stream));                        // dO1
     // out_proj
     RUN(launch_gemm(TN(gB, d, A, d, Gd("mel_attention.out_proj.weight"), d, d, d, Rq), 1, stream));
-    RUN(colsum(gB, Rq, d, (int)d, Gd("mel_attention.out_proj.bias"), 0, stream));
+    RUN(colsum(c, gB, Rq, d, (int)d, Gd("mel_attention.out_proj.bias"), 0, stream));
     RUN(launch_gemm(NN(gB, d, P("mel_attention.out_proj.weight"), d, gA, d, Rq, d, d), 1, stream));                 // dA
     float* gin_w = Gd("mel_attention.in_proj_weight"); float* gin_b = Gd("mel_attention.in_proj_bias");
     {   // dP = dA_h V_h^T ; dV_h = P^T dA_h
@@ -482,14 +595,13 @@ int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in
     }
     // in_proj: rows [0,d) = Wq, [d,3d) = [Wk; Wv]
     RUN(launch_gemm(TN(dQb, d, P("mouth_queries"), d, gin_w, d, d, d, 28), 1, stream));
-    RUN(colsum(dQb, 28, d, (int)d, gin_b, 0, stream));
+    RUN(colsum(c, dQb, 28, d, (int)d, gin_b, 0, stream));
     RUN(launch_gemm(NN(dQb, d, inw, d, Gd("mouth_queries"), d, 28, d, d), 1, stream));
     RUN(launch_gemm(TN(dKV, 2 * d, Y, d, gin_w + d * d, d, 2 * d, d, R), 1, stream));
-    RUN(colsum(dKV, R, 2 * d, (int)(2 * d), gin_b + d, 0, stream));
+    RUN(colsum(c, dKV, R, 2 * d, (int)(2 * d), gin_b + d, 0, stream));
     RUN(launch_gemm(NN(dKV, 2 * d, inw + d * d, d, dY, d, R, d, 2 * d), 1, stream));                                 // dY
     // LayerNorm
-    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, st, dY, Y0, R, (int)d, mu, rs,
-                       Gd("mel_norm.weight"), Gd("mel_norm.bias"));
+    RUN(ln_param_grad(c, dY, Y0, R, (int)d, mu, rs, Gd("mel_norm.weight"), Gd("mel_norm.bias"), stream));
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, dY, Y0, R, (int)d, P("mel_norm.weight"), mu, rs);
     {   // channel encoder: dWce = sum_b dY0_b^T X_b (long columns, then the 3 short-term columns), db
         GemmArgs g = G(dY, 1, d, mel, 1, NKk, Gd("mel_channel_encoder.weight"), KT, d, tv, NKk);
@@ -498,23 +610,22 @@ int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in
         g = G(dY, 1, d, mel_short, 1, NKk, Gd("mel_channel_encoder.weight") + T, KT, d, 3, NKk);
         g.kb_count = (int)B; g.a_kbs = NKk * d; g.b_kbs = 3 * NKk;
         RUN(launch_gemm(g, 1, stream));
-        RUN(colsum(dY, R, d, (int)d, Gd("mel_channel_encoder.bias"), 0, stream));
+        RUN(colsum(c, dY, R, d, (int)d, Gd("mel_channel_encoder.bias"), 0, stream));
     }
     // emotion stream
     RUN(launch_gemm(TN(geA, d, Oe1, d, Gd("emotion_output_proj.weight"), d, d, d, B), 1, stream));
-    RUN(colsum(geA, B, d, (int)d, Gd("emotion_output_proj.bias"), 0, stream));
+    RUN(colsum(c, geA, B, d, (int)d, Gd("emotion_output_proj.bias"), 0, stream));
     RUN(launch_gemm(NN(geA, d, P("emotion_output_proj.weight"), d, geB, d, B, d, d), 1, stream));                     // dOe1
     RUN(launch_gemm(TN(geB, d, Ve, d, Gd("emotion_attention.out_proj.weight"), d, d, d, B), 1, stream));
-    RUN(colsum(geB, B, d, (int)d, Gd("emotion_attention.out_proj.bias"), 0, stream));
+    RUN(colsum(c, geB, B, d, (int)d, Gd("emotion_attention.out_proj.bias"), 0, stream));
     RUN(launch_gemm(NN(geB, d, P("emotion_attention.out_proj.weight"), d, geC, d, B, d, d), 1, stream));              // dVe
     RUN(launch_gemm(TN(geC, d, E, d, Gd("emotion_attention.in_proj_weight") + 2 * d * d, d, d, d, B), 1, stream));    // only the V third
-    RUN(colsum(geC, B, d, (int)d, Gd("emotion_attention.in_proj_bias") + 2 * d, 0, stream));
+    RUN(colsum(c, geC, B, d, (int)d, Gd("emotion_attention.in_proj_bias") + 2 * d, 0, stream));
     RUN(launch_gemm(NN(geC, d, einw + 2 * d * d, d, geA, d, B, d, d), 1, stream));                                    // dE
-    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, st, geA, E0, B, (int)d, emu, ers,
-                       Gd("emotion_norm.weight"), Gd("emotion_norm.bias"));
+    RUN(ln_param_grad(c, geA, E0, B, (int)d, emu, ers, Gd("emotion_norm.weight"), Gd("emotion_norm.bias"), stream));
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, geA, E0, B, (int)d, P("emotion_norm.weight"), emu, ers);
     RUN(launch_gemm(TN(geA, d, emo, ED, Gd("emotion_encoder.weight"), ED, d, ED, B), 1, stream));
-    RUN(colsum(geA, B, d, (int)d, Gd("emotion_encoder.bias"), 0, stream));
+    RUN(colsum(c, geA, B, d, (int)d, Gd("emotion_encoder.bias"), 0, stream));
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }
@@ -526,12 +637,11 @@ int train_adamw(Context* c, const float* flat_grad, float lr, float b1, float b2
     const int nb = 256;
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, flat_grad, n, c->tr_part);
     hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, st, c->tr_part, nb, c->tr_gnorm);
-    const float bc1 = 1.0f - std::pow(b1, (float)step), bc2 = 1.0f - std::pow(b2, (float)step);
-    if (c->tr_alpha_live) c->tr_alpha_steps += 1;
-    const float as = (float)(c->tr_alpha_steps > 0 ? c->tr_alpha_steps : 1);
+    (void)step;
+    hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, st, c->tr_steps, c->tr_alpha_live ? 1 : 0);
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->tr_params, c->tr_m, c->tr_v, flat_grad, n,
-                       c->tr_gnorm, max_norm, lr, b1, b2, eps, wd, bc1, bc2, c->tr_offset.at("smoothing_alpha"),
-                       c->tr_alpha_live ? 1 : 0, 1.0f - std::pow(b1, as), 1.0f - std::pow(b2, as));
+                       c->tr_gnorm, max_norm, lr, b1, b2, eps, wd, c->tr_steps, c->tr_offset.at("smoothing_alpha"),
+                       c->tr_alpha_live ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }

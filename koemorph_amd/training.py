@@ -120,6 +120,31 @@ class Trainer:
         self.optimizer_step()
         return self.loss
 
+    # ---- hipGraph replay of the ~60 launches of forward + backward -----------------------------------
+    def capture(self, B: int, L: int) -> None:
+        """Record ``forward_backward`` on static input buffers into a hipGraph.  Call after at least one eager
+        step with the same batch size (so the in-forward EMA is past its first-call branch)."""
+        dev = self.device
+        self._g_audio = torch.zeros(B, L, device=dev)
+        self._g_emo = torch.zeros(B, self.engine.emotion_dim, device=dev)
+        self._g_target = torch.zeros(B, 52, device=dev)
+        self.engine.reserve(B, L)
+        if self.use_smoothing and self._ema_batch != B:
+            raise RuntimeError("run one eager step with this batch size before capture()")
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.forward_backward(self._g_audio, self._g_emo, self._g_target)
+        self._graph = g
+
+    def step_graph(self, audio, emotion, target) -> torch.Tensor:
+        self._g_audio.copy_(audio, non_blocking=True)
+        self._g_emo.copy_(emotion, non_blocking=True)
+        self._g_target.copy_(target, non_blocking=True)
+        self._graph.replay()
+        self.optimizer_step()
+        return self.loss
+
     def end_epoch(self):
         """scheduler.step() of the reference (:209)."""
         self.epoch += 1

@@ -132,3 +132,29 @@ def test_train_step_from_audio_and_schedule():
     for ep in range(1, 35):
         o.step(); s.step()
         assert abs(cosine_warm_restarts_lr(ep, 1e-4) - o.param_groups[0]["lr"]) < 1e-12
+
+
+def test_graph_replay_of_the_train_step_matches_eager():
+    params = synth.make_core_params(76, style="init")
+    def run(use_graph):
+        e = Engine()
+        e.load_state_dict(params)
+        e.finalize()
+        tr = Trainer(e, max_windows=4, lr=1e-3)
+        losses = []
+        for i in range(5):
+            audio = dev(synth.make_audio(200 + i, 4, 20000))
+            emo = dev(synth.normal(210 + i, (4, 256)))
+            target = dev(synth.uniform(220 + i, (4, 52), 0, 1))
+            if use_graph and i == 1:
+                tr.capture(4, 20000)
+            if use_graph and i >= 1:
+                losses.append(float(tr.step_graph(audio, emo, target).item()))
+            else:
+                losses.append(float(tr.step(audio, emo, target).item()))
+        return losses, tr.params({k: v.shape for k, v in params.items()})
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert l0 == l1
+    for k in p0:
+        assert np.array_equal(p0[k], p1[k]), k

@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--batch", type=int, default=8)
+ap.add_argument("--graph", action="store_true", help="replay forward+backward from a hipGraph")
 args = ap.parse_args()
 rank, world, local = parallel.init_from_env()
 torch.cuda.set_device(local)
@@ -30,12 +31,17 @@ emo = torch.from_numpy(synth.normal(20 + rank, (B, 256))).to(dev)
 target = torch.from_numpy(synth.uniform(30 + rank, (B, 52), 0, 1)).to(dev)
 for _ in range(args.warmup):
     tr.step(audio, emo, target)
+if args.graph:
+    tr.capture(B, 136448)
+    step = lambda: tr.step_graph(audio, emo, target)
+else:
+    step = lambda: tr.step(audio, emo, target)
 torch.cuda.synchronize(dev)
 if world > 1:
     dist.barrier(); torch.cuda.synchronize(dev)
 t0 = time.perf_counter()
 for _ in range(args.steps):
-    tr.step(audio, emo, target)
+    step()
 torch.cuda.synchronize(dev)
 if world > 1:
     dist.barrier(); torch.cuda.synchronize(dev)
@@ -44,7 +50,7 @@ if world > 1:
     t = torch.tensor([dt], device=dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
 if rank == 0:
     print(json.dumps({"workload": f"C3: train step, {B} windows/GPU x 136448 samples, window 256, d_model 256, AdamW, "
-                      f"flat {tr.n_params}-float gradient all-reduce", "n_gpus": world, "steps": args.steps,
+                      f"flat {tr.n_params}-float gradient all-reduce", "n_gpus": world, "graph": bool(args.graph), "steps": args.steps,
                       "ms_per_step": round(dt / args.steps * 1e3, 4), "windows_per_s": round(B * world * args.steps / dt, 1),
                       "final_loss": float(tr.loss.item())}))
 if world > 1:
