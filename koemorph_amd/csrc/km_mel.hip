@@ -24,6 +24,8 @@
 // differs by ~1e-7 of the frame's peak amplitude, visible only in bins > 60 dB below the peak.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "km_context.h"
 #include "km_device.h"
 
@@ -344,6 +346,184 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// mel_power_rp_kernel: the 1024-point front end with ONE real frame per wave, transformed as a 512-point complex
+// FFT of the even/odd-packed samples (z[m] = x[2m] + i x[2m+1]) followed by the real-input post-processing
+//     X[k] = E + W_N^k O,  X[N/2-k] = conj(E - W_N^k O),  E = (Z[k] + conj Z[M-k]) / 2,  O = (Z[k] - conj Z[M-k]) / 2i.
+// Same radix 8 x 8 x 8 passes and LDS exchange images as mel_power_kernel<512,...>, but half the live data per wave:
+// ~120 registers instead of ~240, so 512-thread workgroups run at 4 waves per SIMD (2 workgroups of 80 KB LDS per
+// CU).  The two-frames-per-wave kernel above is latency bound (T ~ 41 us + 136 us / waves-per-SIMD at the C2 shape).
+// ---------------------------------------------------------------------------------------------------------
+namespace melrp {
+constexpr int WAVES = 8, NT = 512, FPB = 16, NC = 512, FFT_BUF = 576, NFS = 514;
+}
+
+template <bool RING>
+__device__ __forceinline__ void load_frame_rp(const MelArgs& a, const float* __restrict__ x, int Li, int rs, int f, int lane,
+                                              float2 (&z)[8]) {
+    const int p0 = f * a.hop - 512 + 2 * lane;                  // window-local position of this lane's first even sample
+    if constexpr (!RING) {
+        const int lo = f * a.hop - 512;
+        if (lo >= 0 && lo + 1024 <= Li) {                       // interior frame: no padding
+            const float* xp = x + p0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) z[i] = make_float2(xp[128 * i], xp[128 * i + 1]);
+            return;
+        }
+    }
+    const bool refl = a.pad_mode == KM_PAD_REFLECT;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int q = p0 + 128 * i + e;
+            bool ok = true;
+            if (refl) q = q < 0 ? -q : (q >= Li ? 2 * (Li - 1) - q : q);      // np.pad(mode='reflect')
+            else ok = q >= 0 && q < Li;                                       // zero padding
+            if constexpr (RING) { q += rs; q -= q >= Li ? Li : 0; }           // logical sample q lives at (rs + q) mod L
+            v[e] = ok ? x[ok ? q : 0] : 0.f;
+        }
+        z[i] = make_float2(v[0], v[1]);
+    }
+}
+
+template <bool RING>
+__global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
+    using namespace melrp;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float2* fbuf = reinterpret_cast<float2*>(smem);                     // [WAVES][FFT_BUF]
+    float* pw = smem + WAVES * FFT_BUF * 2;                              // [FPB][NFS]
+    float* outs = pw + FPB * NFS;                                        // [FPB][n_mels]
+    float* redmax = outs + FPB * a.n_mels;                               // [WAVES]
+    int* fbs = reinterpret_cast<int*>(redmax + WAVES);
+    int* fbc = fbs + a.n_mels;
+    int* fbo = fbc + a.n_mels;
+    float* fbw = reinterpret_cast<float*>(fbo + a.n_mels);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int64_t gw = a.win0 + b;
+    const int64_t clip = gw / a.wins_per_clip, woff = (gw - clip * a.wins_per_clip) * a.win_step;
+    const float* x = a.audio + clip * a.clip_len + woff;
+    const int Lv = (int)((a.clip_len - woff) < a.L ? (a.clip_len - woff) : a.L);
+    if (a.ready && !a.ready[b]) return;                        // workgroup-uniform: stream still filling
+    const int rs = RING ? a.ring_start[b] : -1;
+    float2* buf = fbuf + wave * FFT_BUF;
+    const int n_chunks = (a.n_frames + FPB - 1) / FPB;
+
+    for (int i = tid; i < a.n_mels; i += NT) { fbs[i] = a.fb_start[i]; fbc[i] = a.fb_count[i]; fbo[i] = a.fb_offset[i]; }
+    for (int i = tid; i < a.fb_nnz; i += NT) fbw[i] = 0.25f * a.fb_weight[i];
+
+    // lane-constant operands (56 registers)
+    const int n2 = lane & 7, k0 = lane >> 3;
+    float2 win2[8], tw1[8], tw2[8], twp[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        win2[i] = make_float2(a.window[2 * (lane + 64 * i)], a.window[2 * (lane + 64 * i) + 1]);
+        tw1[i] = a.twiddle[(2 * lane * bitrev(i, 3)) & 1023];           // W_512^(lane k0)
+        tw2[i] = a.twiddle[(16 * n2 * bitrev(i, 3)) & 1023];            // W_64^(n2 k1)
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) twp[i] = a.twiddle[lane + 64 * i];      // W_1024^k, k = lane + 64 i
+
+    float vmax = 0.f;
+    for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const int f0 = chunk * FPB;
+#pragma unroll 1
+        for (int pi = 0; pi < FPB / WAVES; ++pi) {
+            const int fl = wave + WAVES * pi;
+            const int f = f0 + fl;
+            if (f < a.n_frames) {   // wave-uniform
+                float2 z[8];
+                load_frame_rp<RING>(a, x, Lv, rs, f, lane, z);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) z[i] = make_float2(z[i].x * win2[i].x, z[i].y * win2[i].y);
+                // ---- pass 1: radix-8 over n0 (m = 64 n0 + lane) ----
+                dif_fft<8>(z);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int kk = bitrev(i, 3);
+                    buf[kk * 72 + lane] = kk == 0 ? z[i] : cmul(z[i], tw1[i]);
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---- pass 2: radix-8 over n1 (lane = 8 n1 + n2); this lane: n2 = lane & 7, k0 = lane >> 3 ----
+                float2 y[8];
+#pragma unroll
+                for (int n1 = 0; n1 < 8; ++n1) y[n1] = buf[k0 * 72 + 8 * n1 + n2];
+                __builtin_amdgcn_wave_barrier();
+                dif_fft<8>(y);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k1 = bitrev(i, 3);
+                    // transposed image indexed by c = k0 + 8 k1, row stride 9 (padding keeps every address base + immediate;
+                    // the residual 2-way conflict on 3 of 32 slots is cheaper than per-access swizzle arithmetic)
+                    buf[(k0 + 8 * k1) * 9 + n2] = k1 == 0 ? y[i] : cmul(y[i], tw2[i]);
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---- pass 3: radix-8 over n2; this lane: c = lane; output k = c + 64 k2 ----
+#pragma unroll
+                for (int q = 0; q < 8; ++q) y[q] = buf[lane * 9 + q];
+                __builtin_amdgcn_wave_barrier();
+                dif_fft<8>(y);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) buf[lane + 64 * bitrev(i, 3)] = y[i];
+                __builtin_amdgcn_wave_barrier();
+                // ---- real-input post-processing + |.|^2 ----
+                float* pwr = pw + fl * NFS;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = lane + 64 * i;
+                    const float2 zk = buf[k], zc = buf[(NC - k) & (NC - 1)];
+                    const float2 E = make_float2(zk.x + zc.x, zk.y - zc.y);            // 2 E
+                    const float2 O = make_float2(zk.y + zc.y, zc.x - zk.x);            // 2 O
+                    const float2 Tw = cmul(O, twp[i]);                                  // 2 W^k O
+                    const float pr = E.x + Tw.x, pi2 = E.y + Tw.y, mr = E.x - Tw.x, mi = E.y - Tw.y;
+                    pwr[k] = pr * pr + pi2 * pi2;                 // 4 |X[k]|^2: the 1/4 lives in the filter weights (exact)
+                    pwr[2 * 256 - k] = mr * mr + mi * mi;
+                }
+                if (lane == 0) {                                                        // k = 256 pairs with itself
+                    const float2 zk = buf[256];
+                    pwr[256] = 4.0f * (zk.x * zk.x + zk.y * zk.y);
+                }
+            }
+        }
+        __syncthreads();
+        {   // sparse triangular mel filters, lanes = frames (see mel_power_kernel)
+            const int fl = tid & 15, par = (tid >> 4) & 1;
+            const bool fvalid = f0 + fl < a.n_frames;
+            for (int m = tid >> 5; m < a.n_mels; m += NT / 32) {
+                const int st = fbs[m], cnt = fbc[m];
+                const float* wt = fbw + fbo[m];
+                const float* pr = pw + fl * NFS + st;
+                float acc = 0.f;
+                if (fvalid) {
+#pragma unroll 4
+                    for (int i = par; i < cnt; i += 2) acc = fmaf(pr[i], wt[i], acc);
+                }
+                acc += __shfl_xor(acc, 16);
+                if (par == 0) outs[fl * a.n_mels + m] = acc;
+                vmax = fmaxf(vmax, acc);
+            }
+        }
+        __syncthreads();
+        const int nf_here = (a.n_frames - f0) < FPB ? (a.n_frames - f0) : FPB;
+        float* dst = a.melpow + ((int64_t)b * a.n_frames + f0) * a.n_mels;
+        for (int i = tid; i < nf_here * a.n_mels; i += NT) dst[i] = outs[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if (lane == 0) redmax[wave] = vmax;
+    __syncthreads();
+    if (tid == 0) {
+        float mx = redmax[0];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) mx = fmaxf(mx, redmax[w]);
+        atomicMax(a.melmax + b, __float_as_uint(mx));
+    }
+}
+
 struct LogArgs {
     const float* melpow;     // (B, n_frames, n_mels)
     const unsigned* melmax;  // (B)
@@ -406,6 +586,12 @@ void free_mel_plan(MelPlan* p) {
     delete p;
 }
 
+static size_t melrp_lds_bytes(int n_mels = 128, int nnz = 0) {
+    if (nnz == 0) nnz = 2 * 513 + 128;
+    return (size_t)(melrp::WAVES * melrp::FFT_BUF * 2 + melrp::FPB * melrp::NFS + melrp::FPB * n_mels + melrp::WAVES +
+                    3 * n_mels + nnz) * sizeof(float);
+}
+
 static size_t mel_lds_bytes(int nfft, int n_mels = 128, int nnz = 0) {
     if (nnz == 0) nnz = 2 * (nfft / 2 + 1) + 128;    // upper bound: every bin feeds at most two triangles
     return (size_t)(mel::WAVES * mel::FFT_BUF * 2 + mel::FPB * (nfft / 2 + 2) + mel::FPB * n_mels + mel::WAVES +
@@ -441,6 +627,10 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)mel_lds_bytes(1024)));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_kernel<512, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)mel_lds_bytes(512)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_rp_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)melrp_lds_bytes()));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_rp_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)melrp_lds_bytes()));
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -465,6 +655,14 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     if (per_window > n_chunks) per_window = n_chunks;
     if (per_window < 1) per_window = 1;
     const dim3 grid((unsigned)per_window, (unsigned)B);
+    static const bool use_rp = std::getenv("KM_MEL_TWO_FRAME") == nullptr;   // A/B switch: the two-frames-per-wave kernel
+    if (m.n_fft == 1024 && use_rp) {
+        const size_t ldsrp = melrp_lds_bytes(m.n_mels, a.fb_nnz);
+        if (!ring_start) hipLaunchKernelGGL((mel_power_rp_kernel<false>), grid, dim3(melrp::NT), ldsrp, st, a);
+        else hipLaunchKernelGGL((mel_power_rp_kernel<true>), grid, dim3(melrp::NT), ldsrp, st, a);
+        HIP_TRY(hipGetLastError());
+        return KM_OK;
+    }
     const size_t lds = mel_lds_bytes(m.n_fft, m.n_mels, a.fb_nnz);
     if (m.n_fft == 1024 && !ring_start) hipLaunchKernelGGL((mel_power_kernel<1024, false>), grid, dim3(256), lds, st, a);
     else if (m.n_fft == 1024) hipLaunchKernelGGL((mel_power_kernel<1024, true>), grid, dim3(256), lds, st, a);
