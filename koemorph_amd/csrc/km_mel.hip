@@ -358,33 +358,42 @@ namespace melrp {
 constexpr int WAVES = 8, NT = 512, FPB = 16, NC = 512, FFT_BUF = 576, NFS = 514;
 }
 
+// Interior frames (the common case) are 8 unit-stride 8-byte loads per lane from one base pointer.  Returns false --
+// a wave-uniform decision -- when the frame touches the padding or straddles the wrap point of a ring.
 template <bool RING>
-__device__ __forceinline__ void load_frame_rp(const MelArgs& a, const float* __restrict__ x, int Li, int rs, int f, int lane,
-                                              float2 (&z)[8]) {
-    const int p0 = f * a.hop - 512 + 2 * lane;                  // window-local position of this lane's first even sample
-    if constexpr (!RING) {
-        const int lo = f * a.hop - 512;
-        if (lo >= 0 && lo + 1024 <= Li) {                       // interior frame: no padding
-            const float* xp = x + p0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) z[i] = make_float2(xp[128 * i], xp[128 * i + 1]);
-            return;
-        }
+__device__ __forceinline__ bool load_frame_rp_fast(const float* __restrict__ x, int Li, int rs, int hop, int f, int lane,
+                                                   float2 (&z)[8]) {
+    const int lo = f * hop - 512;
+    if (lo < 0 || lo + 1024 > Li) return false;
+    int start = lo;
+    if constexpr (RING) {
+        start += rs;
+        start -= start >= Li ? Li : 0;
+        if (start + 1024 > Li) return false;
     }
-    const bool refl = a.pad_mode == KM_PAD_REFLECT;
+    const float* xp = x + start + 2 * lane;
 #pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = make_float2(xp[128 * i], xp[128 * i + 1]);
+    return true;
+}
+
+// Edge frames (2 of 257 in the batch shape): zero / reflect padding and ring wrap-around per sample.  Deliberately
+// NOT inlined and staged through the wave's LDS buffer: inlined, the compiler if-converts this path into the hot
+// block (predicated integer arithmetic executed for every frame: ~500 extra VALU instructions per frame).
+__device__ __noinline__ void load_frame_rp_slow(const float* __restrict__ x, int Li, int rs, int ring, int hop, int refl, int f,
+                                                int lane, float2* __restrict__ buf) {
+    const int p0 = f * hop - 512 + 2 * lane;
     for (int i = 0; i < 8; ++i) {
         float v[2];
-#pragma unroll
         for (int e = 0; e < 2; ++e) {
             int q = p0 + 128 * i + e;
             bool ok = true;
             if (refl) q = q < 0 ? -q : (q >= Li ? 2 * (Li - 1) - q : q);      // np.pad(mode='reflect')
             else ok = q >= 0 && q < Li;                                       // zero padding
-            if constexpr (RING) { q += rs; q -= q >= Li ? Li : 0; }           // logical sample q lives at (rs + q) mod L
+            if (ring) { q += rs; q -= q >= Li ? Li : 0; }                     // logical sample q lives at (rs + q) mod L
             v[e] = ok ? x[ok ? q : 0] : 0.f;
         }
-        z[i] = make_float2(v[0], v[1]);
+        buf[lane + 64 * i] = make_float2(v[0], v[1]);
     }
 }
 
@@ -437,7 +446,13 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
             const int f = f0 + fl;
             if (f < a.n_frames) {   // wave-uniform
                 float2 z[8];
-                load_frame_rp<RING>(a, x, Lv, rs, f, lane, z);
+                if (!load_frame_rp_fast<RING>(x, Lv, rs, a.hop, f, lane, z)) {      // wave-uniform
+                    load_frame_rp_slow(x, Lv, rs, RING ? 1 : 0, a.hop, a.pad_mode == KM_PAD_REFLECT ? 1 : 0, f, lane, buf);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) z[i] = buf[lane + 64 * i];
+                    __builtin_amdgcn_wave_barrier();
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) z[i] = make_float2(z[i].x * win2[i].x, z[i].y * win2[i].y);
                 // ---- pass 1: radix-8 over n0 (m = 64 n0 + lane) ----
