@@ -38,6 +38,8 @@ struct MelPlan {
     std::vector<int32_t> fb_count;  // n_mels: number of bins
     std::vector<int32_t> fb_offset; // n_mels: offset into fb_weight
     std::vector<float> fb_weight;   // concatenated non-zero weights
+    std::vector<int32_t> fb4_desc;  // n_mels: the same filters in 16-bin trips (km_host.cpp build_mel_plan)
+    std::vector<float> fb4_weight;  // 16 * sum(trips)
     // device mirrors
     float* d_window = nullptr;
     float* d_twiddle = nullptr;
@@ -45,6 +47,8 @@ struct MelPlan {
     int32_t* d_fb_count = nullptr;
     int32_t* d_fb_offset = nullptr;
     float* d_fb_weight = nullptr;
+    int32_t* d_fb4_desc = nullptr;
+    float* d_fb4_weight = nullptr;
     bool uploaded = false;
 };
 

@@ -309,6 +309,19 @@ MelPlan* build_mel_plan(const km_mel_config& cfg) {
         }
     }
     if (p->fb_weight.empty()) p->fb_weight.push_back(0.0f);
+    // second image of the same filters for mel_power_rp_kernel: filter i starts at its first bin rounded down to a
+    // multiple of 4 and is zero-padded to whole trips of 16 bins (4 lanes x one 16-byte LDS read each);
+    // descriptor = first bin | trips << 10 | (offset / 16) << 16
+    p->fb4_desc.assign(nm, 0);
+    for (int i = 0; i < nm; ++i) {
+        const int st4 = p->fb_start[i] & ~3, lead = p->fb_start[i] - st4;
+        const int trips = p->fb_count[i] > 0 ? (lead + p->fb_count[i] + 15) / 16 : 0;
+        const size_t off = p->fb4_weight.size();
+        p->fb4_desc[i] = (int32_t)((uint32_t)st4 | ((uint32_t)trips << 10) | ((uint32_t)(off / 16) << 16));
+        p->fb4_weight.resize(off + (size_t)16 * trips, 0.0f);
+        for (int k = 0; k < p->fb_count[i]; ++k) p->fb4_weight[off + lead + k] = p->fb_weight[p->fb_offset[i] + k];
+    }
+    if (p->fb4_weight.empty()) p->fb4_weight.assign(16, 0.0f);
     return p;
 }
 

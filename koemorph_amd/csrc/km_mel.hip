@@ -114,6 +114,9 @@ struct MelArgs {
     const int* fb_offset;
     const float* fb_weight;
     int fb_nnz;           // number of stored filter weights
+    const int* fb4_desc;  // 16-bin-trip image of the filters (mel_power_rp_kernel)
+    const float* fb4_weight;
+    int fb4_nnz;
     float* melpow;        // (B, n_frames, n_mels)
     unsigned* melmax;     // (B) float bits, zero-initialised
 };
@@ -355,14 +358,114 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
 // CU).  The two-frames-per-wave kernel above is latency bound (T ~ 41 us + 136 us / waves-per-SIMD at the C2 shape).
 // ---------------------------------------------------------------------------------------------------------
 namespace melrp {
-constexpr int WAVES = 8, NT = 512, FPB = 16, NC = 512, FFT_BUF = 576, NFS = 514;
+constexpr int WAVES = 8, NT = 512, FPB = 16, NC = 512, FFT_BUF = 576;
+constexpr int NFS = 528;   // power-row stride in dwords: 16 (mod 64), see the mel stage
+
+// Complex arithmetic on register pairs, one packed instruction (v_pk_add/mul/fma_f32) per complex operation.
+// Multiplications by -i, conjugations and the cross terms of a complex product are half-selects (op_sel / op_sel_hi)
+// and per-half sign flips (neg_lo / neg_hi) of the packed operands.  The compiler only folds splats and whole-vector
+// negations into those modifiers -- a swap becomes v_pk_mov_b32 and a one-sided negation v_xor_b32, ~100 extra
+// instructions per frame -- so the three arithmetic blocks of a frame are written as inline assembly.  gfx950 needs
+// one wait state between a packed-fp32 result and a VALU instruction that reads it (the compiler pads its own code
+// with s_nop 0 for this): inside a block no instruction reads the result of its predecessor, and each block begins
+// and ends with s_nop 0 because the hazard recogniser does not look through inline assembly.
+// Measured on gfx950: a packed fp32 instruction costs ~1.2x a scalar one and produces two results
+// (tools/micro/valu_rate.hip).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#define KM_ADD(D, A, B) "v_pk_add_f32 %[" #D "], %[" #A "], %[" #B "]\n\t"
+#define KM_SUB(D, A, B) "v_pk_add_f32 %[" #D "], %[" #A "], %[" #B "] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+// D = A + (-i) B = (A.x + B.y, A.y - B.x);  D = A - (-i) B
+#define KM_ADD_NI(D, A, B) "v_pk_add_f32 %[" #D "], %[" #A "], %[" #B "] op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+#define KM_SUB_NI(D, A, B) "v_pk_add_f32 %[" #D "], %[" #A "], %[" #B "] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+// D = (-i) S - S = (S.y - S.x, -S.x - S.y)
+#define KM_ROT3(D, S) "v_pk_add_f32 %[" #D "], %[" #S "], %[" #S "] op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]\n\t"
+// complex product in two steps: T = A.xx * W;  D = (-A.y, A.y) * W.yx + T
+#define KM_CMUL1(T, A, W) "v_pk_mul_f32 %[" #T "], %[" #A "], %[" #W "] op_sel_hi:[0,1]\n\t"
+#define KM_CMUL2(D, A, W, T) \
+    "v_pk_fma_f32 %[" #D "], %[" #A "], %[" #W "], %[" #T "] op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
+
+// radix-8 DIF of v[0..7] (26 packed instructions); output X[bitrev(i)] in v[i]
+__device__ __forceinline__ void dif8(v2f (&v)[8]) {
+    constexpr float C2 = 0.70710678118654752f;
+    const v2f c = {C2, C2};
+    v2f r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3], r4 = v[4], r5 = v[5], r6 = v[6], r7 = v[7], t;
+    asm("s_nop 0\n\t"
+        // stage 1: s_i = v_i + v_{i+4}, d_i = v_i - v_{i+4};  u1 = d1 + (-i) d1, u3 = (-i) d3 - d3 (their 1/sqrt2 is applied in stage 3)
+        KM_ADD(t, r0, r4) KM_SUB(r4, r0, r4)          // s0 = t,  d0 = r4
+        KM_ADD(r0, r1, r5) KM_SUB(r5, r1, r5)         // s1 = r0, d1 = r5
+        KM_ADD(r1, r2, r6) KM_SUB(r6, r2, r6)         // s2 = r1, d2 = r6
+        KM_ADD(r2, r3, r7) KM_SUB(r7, r3, r7)         // s3 = r2, d3 = r7
+        KM_ADD_NI(r3, r5, r5)                         // u1 = r3
+        KM_ROT3(r5, r7)                               // u3 = r5
+        // stage 2
+        KM_ADD(r7, t, r1) KM_SUB(r1, t, r1)           // a0 = r7, b0 = r1
+        KM_ADD(t, r0, r2) KM_SUB(r2, r0, r2)          // a1 = t,  g  = r2 (s1 - s3)
+        KM_ADD_NI(r0, r4, r6) KM_SUB_NI(r6, r4, r6)   // c0 = r0 = d0 + (-i) d2, e0 = r6
+        KM_ADD(r4, r3, r5) KM_SUB(r5, r3, r5)         // w = r4 = u1 + u3, q = r5 = u1 - u3
+        // stage 3
+        KM_ADD(r3, r7, t) KM_SUB(r7, r7, t)           // X0 = r3, X4 = r7
+        KM_ADD_NI(t, r1, r2) KM_SUB_NI(r2, r1, r2)    // X2 = t,  X6 = r2
+        "v_pk_fma_f32 %[r1], %[r4], %[c], %[r0]\n\t"                                   // X1 = c0 + C w
+        "v_pk_fma_f32 %[r4], %[r4], %[c], %[r0] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"     // X5 = c0 - C w
+        "v_pk_fma_f32 %[r0], %[r5], %[c], %[r6] op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]\n\t"   // X3 = e0 + C (-i) q
+        "v_pk_fma_f32 %[r5], %[r5], %[c], %[r6] op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"   // X7 = e0 - C (-i) q
+        "s_nop 0"
+        : [r0] "+v"(r0), [r1] "+v"(r1), [r2] "+v"(r2), [r3] "+v"(r3), [r4] "+v"(r4), [r5] "+v"(r5), [r6] "+v"(r6),
+          [r7] "+v"(r7), [t] "=&v"(t)
+        : [c] "s"(c));
+    v[0] = r3; v[1] = r7; v[2] = t; v[3] = r2; v[4] = r1; v[5] = r4; v[6] = r0; v[7] = r5;
 }
+
+// v[i] *= w[i] for i = 1..7 (14 packed instructions)
+__device__ __forceinline__ void cmul7(v2f (&v)[8], const v2f (&w)[8]) {
+    v2f ta, tb;
+    asm("s_nop 0\n\t"
+        KM_CMUL1(ta, v1, w1) KM_CMUL1(tb, v2, w2)
+        KM_CMUL2(v1, v1, w1, ta) KM_CMUL1(ta, v3, w3)
+        KM_CMUL2(v2, v2, w2, tb) KM_CMUL1(tb, v4, w4)
+        KM_CMUL2(v3, v3, w3, ta) KM_CMUL1(ta, v5, w5)
+        KM_CMUL2(v4, v4, w4, tb) KM_CMUL1(tb, v6, w6)
+        KM_CMUL2(v5, v5, w5, ta) KM_CMUL1(ta, v7, w7)
+        KM_CMUL2(v6, v6, w6, tb)
+        KM_CMUL2(v7, v7, w7, ta)
+        "s_nop 0"
+        : [v1] "+v"(v[1]), [v2] "+v"(v[2]), [v3] "+v"(v[3]), [v4] "+v"(v[4]), [v5] "+v"(v[5]), [v6] "+v"(v[6]),
+          [v7] "+v"(v[7]), [ta] "=&v"(ta), [tb] "=&v"(tb)
+        : [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]), [w6] "v"(w[6]), [w7] "v"(w[7]));
+}
+
+// Real-input post-processing of four bin pairs: zk_i = Z[k_i], zc_i = Z[512 - k_i], w_i = W_1024^(k_i).
+//   2E = zk + conj zc,  2O = -i (zk - conj zc),  2X[k] = 2E + w 2O,  2X[512-k] = conj(2E - w 2O)
+// Result in zk_i: (4 |X[k_i]|^2, 4 |X[512 - k_i]|^2).  32 packed instructions.
+#define KM_POST4(OP) OP(0) OP(1) OP(2) OP(3)
+#define KM_P1(i) "v_pk_add_f32 %[t" #i "], %[k" #i "], %[c" #i "] neg_hi:[0,1]\n\t"                                   /* 2E */
+#define KM_P2(i) "v_pk_add_f32 %[c" #i "], %[k" #i "], %[c" #i "] op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"     /* 2O */
+#define KM_P3(i) "v_pk_mul_f32 %[k" #i "], %[c" #i "], %[w" #i "] op_sel_hi:[0,1]\n\t"
+#define KM_P4(i) "v_pk_fma_f32 %[c" #i "], %[c" #i "], %[w" #i "], %[k" #i "] op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"  /* w 2O */
+#define KM_P5(i) "v_pk_add_f32 %[k" #i "], %[t" #i "], %[c" #i "] op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n\t"     /* Re 2X[k], Re 2X[512-k] */
+#define KM_P6(i) "v_pk_add_f32 %[c" #i "], %[t" #i "], %[c" #i "] op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]\n\t"     /* Im */
+#define KM_P7(i) "v_pk_mul_f32 %[t" #i "], %[k" #i "], %[k" #i "]\n\t"
+#define KM_P8(i) "v_pk_fma_f32 %[k" #i "], %[c" #i "], %[c" #i "], %[t" #i "]\n\t"
+__device__ __forceinline__ void post4(v2f (&zk)[4], v2f (&zc)[4], const v2f (&w)[4]) {
+    v2f t0, t1, t2, t3;
+    asm("s_nop 0\n\t"
+        KM_POST4(KM_P1) KM_POST4(KM_P2) KM_POST4(KM_P3) KM_POST4(KM_P4)
+        KM_POST4(KM_P5) KM_POST4(KM_P6) KM_POST4(KM_P7) KM_POST4(KM_P8)
+        "s_nop 0"
+        : [k0] "+v"(zk[0]), [k1] "+v"(zk[1]), [k2] "+v"(zk[2]), [k3] "+v"(zk[3]),
+          [c0] "+v"(zc[0]), [c1] "+v"(zc[1]), [c2] "+v"(zc[2]), [c3] "+v"(zc[3]),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+        : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]));
+}
+__device__ __forceinline__ v2f ld2(const float2* p) { const float2 t = *p; return v2f{t.x, t.y}; }
+}  // namespace melrp
 
 // Interior frames (the common case) are 8 unit-stride 8-byte loads per lane from one base pointer.  Returns false --
 // a wave-uniform decision -- when the frame touches the padding or straddles the wrap point of a ring.
 template <bool RING>
 __device__ __forceinline__ bool load_frame_rp_fast(const float* __restrict__ x, int Li, int rs, int hop, int f, int lane,
-                                                   float2 (&z)[8]) {
+                                                   melrp::v2f (&z)[8]) {
     const int lo = f * hop - 512;
     if (lo < 0 || lo + 1024 > Li) return false;
     int start = lo;
@@ -373,7 +476,7 @@ __device__ __forceinline__ bool load_frame_rp_fast(const float* __restrict__ x, 
     }
     const float* xp = x + start + 2 * lane;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) z[i] = make_float2(xp[128 * i], xp[128 * i + 1]);
+    for (int i = 0; i < 8; ++i) z[i] = melrp::v2f{xp[128 * i], xp[128 * i + 1]};
     return true;
 }
 
@@ -403,12 +506,8 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float2* fbuf = reinterpret_cast<float2*>(smem);                     // [WAVES][FFT_BUF]
     float* pw = smem + WAVES * FFT_BUF * 2;                              // [FPB][NFS]
-    float* outs = pw + FPB * NFS;                                        // [FPB][n_mels]
-    float* redmax = outs + FPB * a.n_mels;                               // [WAVES]
-    int* fbs = reinterpret_cast<int*>(redmax + WAVES);
-    int* fbc = fbs + a.n_mels;
-    int* fbo = fbc + a.n_mels;
-    float* fbw = reinterpret_cast<float*>(fbo + a.n_mels);
+    float* redmax = pw + FPB * NFS;                                      // [WAVES]
+    float* fbw = redmax + WAVES;                                         // [fb4_nnz] filter taps x 1/4, 16-bin trips
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -419,25 +518,44 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
     const int Lv = (int)((a.clip_len - woff) < a.L ? (a.clip_len - woff) : a.L);
     if (a.ready && !a.ready[b]) return;                        // workgroup-uniform: stream still filling
     const int rs = RING ? a.ring_start[b] : -1;
-    float2* buf = fbuf + wave * FFT_BUF;
+    v2f* buf = reinterpret_cast<v2f*>(fbuf + wave * FFT_BUF);
     const int n_chunks = (a.n_frames + FPB - 1) / FPB;
 
-    for (int i = tid; i < a.n_mels; i += NT) { fbs[i] = a.fb_start[i]; fbc[i] = a.fb_count[i]; fbo[i] = a.fb_offset[i]; }
-    for (int i = tid; i < a.fb_nnz; i += NT) fbw[i] = 0.25f * a.fb_weight[i];
+    for (int i = tid; i < a.fb4_nnz; i += NT) fbw[i] = 0.25f * a.fb4_weight[i];
+    if (tid < FPB * 15) pw[(tid / 15) * NFS + 513 + tid % 15] = 0.f;     // row padding read by the 16-bin mel trips
 
     // lane-constant operands (56 registers)
     const int n2 = lane & 7, k0 = lane >> 3;
-    float2 win2[8], tw1[8], tw2[8], twp[4];
+    v2f win2[8], tw1[8], tw2[8], twp[4];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        win2[i] = make_float2(a.window[2 * (lane + 64 * i)], a.window[2 * (lane + 64 * i) + 1]);
-        tw1[i] = a.twiddle[(2 * lane * bitrev(i, 3)) & 1023];           // W_512^(lane k0)
-        tw2[i] = a.twiddle[(16 * n2 * bitrev(i, 3)) & 1023];            // W_64^(n2 k1)
+        win2[i] = v2f{a.window[2 * (lane + 64 * i)], a.window[2 * (lane + 64 * i) + 1]};
+        tw1[i] = ld2(a.twiddle + ((2 * lane * bitrev(i, 3)) & 1023));   // W_512^(lane k0)
+        tw2[i] = ld2(a.twiddle + ((16 * n2 * bitrev(i, 3)) & 1023));    // W_64^(n2 k1)
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) twp[i] = a.twiddle[lane + 64 * i];      // W_1024^k, k = lane + 64 i
+    for (int i = 0; i < 4; ++i) twp[i] = ld2(a.twiddle + lane + 64 * i);   // W_1024^k, k = lane + 64 i
+
+    // filters of this wave (wave, wave + 8, ...): descriptor j (first bin | trips << 10 | weight offset / 16 << 16)
+    // lives in lane j and is broadcast with v_readlane
+    const int n_my = (a.n_mels - wave + WAVES - 1) / WAVES;
+    int my_desc = 0;
+    if (lane < n_my) my_desc = a.fb4_desc[wave + WAVES * lane];
+    // Use every loop-invariant operand once before the loop: the waits for their loads are placed here, not (with
+    // conservative counts that would also drain the sample prefetch) at their first use inside the loop.
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(win2[i]), "v"(tw1[i]), "v"(tw2[i]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(twp[i]));
+    asm volatile("" ::"v"(my_desc));
 
     float vmax = 0.f;
+    // Software prefetch: the samples of this wave's NEXT frame are requested as soon as pass 1 has left the registers
+    // (they complete under passes 2-3 and the post-processing; across a chunk boundary under the mel stage).  Without
+    // it every workgroup stalls on HBM latency after each barrier: the kernel is latency bound, not VALU bound.
+    v2f zn[8];
+    bool zn_ok = false;                                                  // wave-uniform: zn holds the next frame
+    if (blockIdx.x * FPB + wave < a.n_frames) zn_ok = load_frame_rp_fast<RING>(x, Lv, rs, a.hop, blockIdx.x * FPB + wave, lane, zn);
     for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const int f0 = chunk * FPB;
 #pragma unroll 1
@@ -445,87 +563,99 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
             const int fl = wave + WAVES * pi;
             const int f = f0 + fl;
             if (f < a.n_frames) {   // wave-uniform
-                float2 z[8];
-                if (!load_frame_rp_fast<RING>(x, Lv, rs, a.hop, f, lane, z)) {      // wave-uniform
-                    load_frame_rp_slow(x, Lv, rs, RING ? 1 : 0, a.hop, a.pad_mode == KM_PAD_REFLECT ? 1 : 0, f, lane, buf);
+                if (!zn_ok) {       // edge frame (padding / ring wrap): 2 of 257 in the batch shape
+                    load_frame_rp_slow(x, Lv, rs, RING ? 1 : 0, a.hop, a.pad_mode == KM_PAD_REFLECT ? 1 : 0, f, lane,
+                                       reinterpret_cast<float2*>(buf));
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) z[i] = buf[lane + 64 * i];
+                    for (int i = 0; i < 8; ++i) zn[i] = buf[lane + 64 * i];
                     __builtin_amdgcn_wave_barrier();
                 }
+                v2f z[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) z[i] = make_float2(z[i].x * win2[i].x, z[i].y * win2[i].y);
+                for (int i = 0; i < 8; ++i) z[i] = zn[i] * win2[i];
                 // ---- pass 1: radix-8 over n0 (m = 64 n0 + lane) ----
-                dif_fft<8>(z);
+                dif8(z);
+                cmul7(z, tw1);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int kk = bitrev(i, 3);
-                    buf[kk * 72 + lane] = kk == 0 ? z[i] : cmul(z[i], tw1[i]);
-                }
+                for (int i = 0; i < 8; ++i) buf[bitrev(i, 3) * 72 + lane] = z[i];
                 __builtin_amdgcn_wave_barrier();
+                {
+                    const int fnext = pi + 1 < FPB / WAVES ? f + WAVES : (chunk + (int)gridDim.x) * FPB + wave;
+                    zn_ok = fnext < a.n_frames && load_frame_rp_fast<RING>(x, Lv, rs, a.hop, fnext, lane, zn);
+                }
                 // ---- pass 2: radix-8 over n1 (lane = 8 n1 + n2); this lane: n2 = lane & 7, k0 = lane >> 3 ----
-                float2 y[8];
+                v2f y[8];
 #pragma unroll
                 for (int n1 = 0; n1 < 8; ++n1) y[n1] = buf[k0 * 72 + 8 * n1 + n2];
                 __builtin_amdgcn_wave_barrier();
-                dif_fft<8>(y);
+                dif8(y);
+                cmul7(y, tw2);
+                // transposed image indexed by c = k0 + 8 k1, row stride 9 (padding keeps every address base + immediate;
+                // the residual 2-way conflict on 3 of 32 slots is cheaper than per-access swizzle arithmetic)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int k1 = bitrev(i, 3);
-                    // transposed image indexed by c = k0 + 8 k1, row stride 9 (padding keeps every address base + immediate;
-                    // the residual 2-way conflict on 3 of 32 slots is cheaper than per-access swizzle arithmetic)
-                    buf[(k0 + 8 * k1) * 9 + n2] = k1 == 0 ? y[i] : cmul(y[i], tw2[i]);
-                }
+                for (int i = 0; i < 8; ++i) buf[(k0 + 8 * bitrev(i, 3)) * 9 + n2] = y[i];
                 __builtin_amdgcn_wave_barrier();
                 // ---- pass 3: radix-8 over n2; this lane: c = lane; output k = c + 64 k2 ----
 #pragma unroll
                 for (int q = 0; q < 8; ++q) y[q] = buf[lane * 9 + q];
                 __builtin_amdgcn_wave_barrier();
-                dif_fft<8>(y);
+                dif8(y);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) buf[lane + 64 * bitrev(i, 3)] = y[i];
                 __builtin_amdgcn_wave_barrier();
-                // ---- real-input post-processing + |.|^2 ----
+                // ---- real-input post-processing + |.|^2, two bins (k and 512 - k) per packed instruction ----
                 float* pwr = pw + fl * NFS;
+                v2f zk[4], zc[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int k = lane + 64 * i;
-                    const float2 zk = buf[k], zc = buf[(NC - k) & (NC - 1)];
-                    const float2 E = make_float2(zk.x + zc.x, zk.y - zc.y);            // 2 E
-                    const float2 O = make_float2(zk.y + zc.y, zc.x - zk.x);            // 2 O
-                    const float2 Tw = cmul(O, twp[i]);                                  // 2 W^k O
-                    const float pr = E.x + Tw.x, pi2 = E.y + Tw.y, mr = E.x - Tw.x, mi = E.y - Tw.y;
-                    pwr[k] = pr * pr + pi2 * pi2;                 // 4 |X[k]|^2: the 1/4 lives in the filter weights (exact)
-                    pwr[2 * 256 - k] = mr * mr + mi * mi;
+                    zk[i] = buf[lane + 64 * i];
+                    zc[i] = buf[(NC - lane - 64 * i) & (NC - 1)];
+                }
+                post4(zk, zc, twp);                                       // the 1/4 of |X|^2 lives in the filter weights
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pwr[lane + 64 * i] = zk[i].x;
+                    pwr[2 * 256 - lane - 64 * i] = zk[i].y;
                 }
                 if (lane == 0) {                                                        // k = 256 pairs with itself
-                    const float2 zk = buf[256];
+                    const v2f zk = buf[256];
                     pwr[256] = 4.0f * (zk.x * zk.x + zk.y * zk.y);
                 }
             }
         }
         __syncthreads();
-        {   // sparse triangular mel filters, lanes = frames (see mel_power_kernel)
-            const int fl = tid & 15, par = (tid >> 4) & 1;
-            const bool fvalid = f0 + fl < a.n_frames;
-            for (int m = tid >> 5; m < a.n_mels; m += NT / 32) {
-                const int st = fbs[m], cnt = fbc[m];
-                const float* wt = fbw + fbo[m];
-                const float* pr = pw + fl * NFS + st;
-                float acc = 0.f;
-                if (fvalid) {
-#pragma unroll 4
-                    for (int i = par; i < cnt; i += 2) acc = fmaf(pr[i], wt[i], acc);
+        {   // Sparse triangular mel filters.  One filter per wave at a time (descriptor through v_readlane, scalar loop
+            // control); lanes = 16 frames x 4 phases, a trip covers 16 bins: every lane reads 4 consecutive powers and
+            // 4 weights with one ds_read_b128 each (the plan aligns filters to 4 bins and pads them to whole trips).
+            // Row stride 528 = 16 (mod 64) dwords: the 16 lanes of a b128 beat (4 frames x 16 bins) cover all 64 banks.
+            // Results go straight to HBM (the 80 filters of a frame are written by 8 waves within one chunk, L2 merges
+            // the lines), which saves the staging buffer and its bank-conflicted transposition.
+            const int ph = lane & 3, flm = lane >> 2;
+            const bool fvalid = f0 + flm < a.n_frames;
+            const float4* prow = reinterpret_cast<const float4*>(pw + flm * NFS) + ph;
+            const float4* wrow = reinterpret_cast<const float4*>(fbw) + ph;
+            float* dst = a.melpow + ((int64_t)b * a.n_frames + f0 + flm) * a.n_mels + wave;
+            for (int j = 0; j < n_my; ++j) {
+                const int desc = __builtin_amdgcn_readlane(my_desc, j);
+                const int trips = (desc >> 10) & 63;
+                const float4* pr = prow + ((desc & 1023) >> 2);
+                const float4* wt = wrow + 4 * (int)((unsigned)desc >> 16);
+                v2f acc = {0.f, 0.f};
+                for (int t = 0; t < trips; ++t) {
+                    const float4 pv = pr[4 * t], wv = wt[4 * t];
+                    acc = __builtin_elementwise_fma(v2f{pv.x, pv.y}, v2f{wv.x, wv.y}, acc);
+                    acc = __builtin_elementwise_fma(v2f{pv.z, pv.w}, v2f{wv.z, wv.w}, acc);
                 }
-                acc += __shfl_xor(acc, 16);
-                if (par == 0) outs[fl * a.n_mels + m] = acc;
-                vmax = fmaxf(vmax, acc);
+                float r = acc.x + acc.y;
+                r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+                r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+                r = fvalid ? r : 0.f;
+                if (ph == 0 && fvalid) dst[WAVES * j] = r;
+                asm("v_max_f32 %0, %0, %1" : "+v"(vmax) : "v"(r));
             }
         }
-        __syncthreads();
-        const int nf_here = (a.n_frames - f0) < FPB ? (a.n_frames - f0) : FPB;
-        float* dst = a.melpow + ((int64_t)b * a.n_frames + f0) * a.n_mels;
-        for (int i = tid; i < nf_here * a.n_mels; i += NT) dst[i] = outs[i];
+        __syncthreads();                                                 // the power rows are free again
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
@@ -589,6 +719,8 @@ int upload_mel_plan(MelPlan* p) {
     if (int rc = upload(&p->d_fb_count, p->fb_count)) return rc;
     if (int rc = upload(&p->d_fb_offset, p->fb_offset)) return rc;
     if (int rc = upload(&p->d_fb_weight, p->fb_weight)) return rc;
+    if (int rc = upload(&p->d_fb4_desc, p->fb4_desc)) return rc;
+    if (int rc = upload(&p->d_fb4_weight, p->fb4_weight)) return rc;
     p->uploaded = true;
     return KM_OK;
 }
@@ -597,18 +729,17 @@ void free_mel_plan(MelPlan* p) {
     if (p->uploaded) {
         (void)hipFree(p->d_window); (void)hipFree(p->d_twiddle); (void)hipFree(p->d_fb_start);
         (void)hipFree(p->d_fb_count); (void)hipFree(p->d_fb_offset); (void)hipFree(p->d_fb_weight);
+        (void)hipFree(p->d_fb4_desc); (void)hipFree(p->d_fb4_weight);
     }
     delete p;
 }
 
-static size_t melrp_lds_bytes(int n_mels = 128, int nnz = 0) {
-    if (nnz == 0) nnz = 2 * 513 + 128;
-    return (size_t)(melrp::WAVES * melrp::FFT_BUF * 2 + melrp::FPB * melrp::NFS + melrp::FPB * n_mels + melrp::WAVES +
-                    3 * n_mels + nnz) * sizeof(float);
+static size_t melrp_lds_bytes(int nnz4) {
+    return (size_t)(melrp::WAVES * melrp::FFT_BUF * 2 + melrp::FPB * melrp::NFS + melrp::WAVES + nnz4) * sizeof(float);
 }
 
 static size_t mel_lds_bytes(int nfft, int n_mels = 128, int nnz = 0) {
-    if (nnz == 0) nnz = 2 * (nfft / 2 + 1) + 128;    // upper bound: every bin feeds at most two triangles
+    if (nnz == 0) nnz = 2 * (nfft / 2 + 1) + 4 * 128;    // upper bound: every bin feeds at most two triangles, rows padded to 4
     return (size_t)(mel::WAVES * mel::FFT_BUF * 2 + mel::FPB * (nfft / 2 + 2) + mel::FPB * n_mels + mel::WAVES +
                     3 * n_mels + nnz) * sizeof(float);
 }
@@ -643,9 +774,9 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_kernel<512, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)mel_lds_bytes(512)));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_rp_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)melrp_lds_bytes()));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_rp_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)melrp_lds_bytes()));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -662,6 +793,7 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     a.n_mels = m.n_mels; a.window = p->d_window; a.twiddle = reinterpret_cast<const float2*>(p->d_twiddle);
     a.fb_start = p->d_fb_start; a.fb_count = p->d_fb_count; a.fb_offset = p->d_fb_offset; a.fb_weight = p->d_fb_weight;
     a.fb_nnz = (int)p->fb_weight.size();
+    a.fb4_desc = p->d_fb4_desc; a.fb4_weight = p->d_fb4_weight; a.fb4_nnz = (int)p->fb4_weight.size();
     a.melpow = c->ws_melpow; a.melmax = c->ws_melmax;
     // persistent over frame chunks: each workgroup walks chunks blockIdx.x, +gridDim.x, ... of its window with the
     // next pair's samples prefetched; two workgroups are resident per CU (LDS), so aim at 512 in total
@@ -672,7 +804,7 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     const dim3 grid((unsigned)per_window, (unsigned)B);
     static const bool use_rp = std::getenv("KM_MEL_TWO_FRAME") == nullptr;   // A/B switch: the two-frames-per-wave kernel
     if (m.n_fft == 1024 && use_rp) {
-        const size_t ldsrp = melrp_lds_bytes(m.n_mels, a.fb_nnz);
+        const size_t ldsrp = melrp_lds_bytes(a.fb4_nnz);     // 78 KB at the production shape: two workgroups per CU
         if (!ring_start) hipLaunchKernelGGL((mel_power_rp_kernel<false>), grid, dim3(melrp::NT), ldsrp, st, a);
         else hipLaunchKernelGGL((mel_power_rp_kernel<true>), grid, dim3(melrp::NT), ldsrp, st, a);
         HIP_TRY(hipGetLastError());
