@@ -5,7 +5,7 @@ Workload (BASELINE.json configs[1], "C2"): per GPU a batch of 256 synthetic 8.5 
 (136 448 samples @16 kHz) -> 1024-pt STFT / 80-bin log-mel (257 frames) -> dual-stream
 cross-attention (d_model 256, 8 heads, window 256) -> decoder -> temporal smoothing ->
 256 x 52 fp32 coefficients.  One "step" = one pass of that path over the batch
-(km_forward_audio: emotion kernel, mel power kernel, fused core kernel with dB conversion + EMA);
+(km_forward_audio: emotion_kernel_d256, mel_power_rp_kernel, core_fused_kernel with dB conversion + EMA);
 inputs are resident in HBM before the timed region.  Windows shard embarrassingly across
 GPUs (weak scaling, no data-path collective).
 
@@ -150,12 +150,12 @@ def main():
                  # the kernel executes fewer FLOPs than the reference formulation (folded projections):
                  "executed_mfma_flops_per_launch": EXECUTED_MFMA_FLOPS_PER_FRAME * B,
                  "mfma_pipe_util": round(EXECUTED_MFMA_FLOPS_PER_FRAME * B / t_core / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
-    roof_mel = {"kernel": "mel_power_kernel<1024>", "bound": "hbm", "achieved": round(mel_gbs, 2),
+    roof_mel = {"kernel": "mel_power_rp_kernel<false>", "bound": "hbm", "achieved": round(mel_gbs, 2),
                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(mel_gbs / PEAK_HBM_GBS, 4),
-                "traffic": (pmc.get("mel_power_kernel") or {}).get("hbm_bytes_per_launch"),
+                "traffic": (pmc.get("mel_power_rp_kernel") or pmc.get("mel_power_kernel") or {}).get("hbm_bytes_per_launch"),
                 "launch_ms": round(t_mel * 1e3, 4), "algorithmic_bytes_per_launch": BYTES_PER_FRAME_AUDIO * B}
     roofline, other = (roof_core, roof_mel) if t_core >= t_mel else (roof_mel, roof_core)
-    stage_ms = {"emotion_kernel": round(t_emo * 1e3, 4), "mel_power_kernel": round(t_mel * 1e3, 4),
+    stage_ms = {"emotion_kernel_d256": round(t_emo * 1e3, 4), "mel_power_rp_kernel": round(t_mel * 1e3, 4),
                 "core_fused_kernel": round(t_core * 1e3, 4)}
 
     # ---- CPU baseline: the oracle on this host's cores (rank 0, N=1 only), bounded sample ----------

@@ -458,6 +458,27 @@ __device__ __forceinline__ void post4(v2f (&zk)[4], v2f (&zc)[4], const v2f (&w)
           [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
         : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]));
 }
+// Eight 8-byte LDS reads at a constant byte stride from one address register, drained before returning.  Written as
+// assembly because the compiler pairs neighbouring reads into ds_read2_b64, which the LDS serves at half the rate of two
+// ds_read_b64 (8 vs 2 x 2 array cycles per wave, /opt/skills/guides/MI355X_MICROARCH.md LDS table) and banks mod 32.
+__device__ __forceinline__ unsigned lds_offset(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+template <int S>
+__device__ __forceinline__ void lds_read8(unsigned addr, v2f (&y)[8]) {
+    asm volatile("ds_read_b64 %0, %8 offset:%9\n\t"
+                 "ds_read_b64 %1, %8 offset:%10\n\t"
+                 "ds_read_b64 %2, %8 offset:%11\n\t"
+                 "ds_read_b64 %3, %8 offset:%12\n\t"
+                 "ds_read_b64 %4, %8 offset:%13\n\t"
+                 "ds_read_b64 %5, %8 offset:%14\n\t"
+                 "ds_read_b64 %6, %8 offset:%15\n\t"
+                 "ds_read_b64 %7, %8 offset:%16\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]), "=&v"(y[4]), "=&v"(y[5]), "=&v"(y[6]), "=&v"(y[7])
+                 : "v"(addr), "i"(0 * S), "i"(1 * S), "i"(2 * S), "i"(3 * S), "i"(4 * S), "i"(5 * S), "i"(6 * S), "i"(7 * S)
+                 : "memory");
+}
 __device__ __forceinline__ v2f ld2(const float2* p) { const float2 t = *p; return v2f{t.x, t.y}; }
 }  // namespace melrp
 
@@ -520,6 +541,7 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
     const int rs = RING ? a.ring_start[b] : -1;
     v2f* buf = reinterpret_cast<v2f*>(fbuf + wave * FFT_BUF);
     const int n_chunks = (a.n_frames + FPB - 1) / FPB;
+    const unsigned rd2 = lds_offset(buf + (lane >> 3) * 72 + (lane & 7)), rd3 = lds_offset(buf + lane * 9);
 
     for (int i = tid; i < a.fb4_nnz; i += NT) fbw[i] = 0.25f * a.fb4_weight[i];
     if (tid < FPB * 15) pw[(tid / 15) * NFS + 513 + tid % 15] = 0.f;     // row padding read by the 16-bin mel trips
@@ -586,8 +608,7 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
                 }
                 // ---- pass 2: radix-8 over n1 (lane = 8 n1 + n2); this lane: n2 = lane & 7, k0 = lane >> 3 ----
                 v2f y[8];
-#pragma unroll
-                for (int n1 = 0; n1 < 8; ++n1) y[n1] = buf[k0 * 72 + 8 * n1 + n2];
+                lds_read8<64>(rd2, y);                                    // y[n1] = buf[k0 * 72 + 8 n1 + n2]
                 __builtin_amdgcn_wave_barrier();
                 dif8(y);
                 cmul7(y, tw2);
@@ -597,8 +618,7 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
                 for (int i = 0; i < 8; ++i) buf[(k0 + 8 * bitrev(i, 3)) * 9 + n2] = y[i];
                 __builtin_amdgcn_wave_barrier();
                 // ---- pass 3: radix-8 over n2; this lane: c = lane; output k = c + 64 k2 ----
-#pragma unroll
-                for (int q = 0; q < 8; ++q) y[q] = buf[lane * 9 + q];
+                lds_read8<8>(rd3, y);                                     // y[q] = buf[lane * 9 + q]
                 __builtin_amdgcn_wave_barrier();
                 dif8(y);
 #pragma unroll
@@ -636,6 +656,9 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
             const float4* prow = reinterpret_cast<const float4*>(pw + flm * NFS) + ph;
             const float4* wrow = reinterpret_cast<const float4*>(fbw) + ph;
             float* dst = a.melpow + ((int64_t)b * a.n_frames + f0 + flm) * a.n_mels + wave;
+            // After the quad reduction all four phase lanes of a frame hold the filter's sum: phase p keeps the results of
+            // filters j = p (mod 4) and one store per four filters writes them (4 x fewer, fuller store instructions).
+            float keep = 0.f;
             for (int j = 0; j < n_my; ++j) {
                 const int desc = __builtin_amdgcn_readlane(my_desc, j);
                 const int trips = (desc >> 10) & 63;
@@ -651,8 +674,12 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
                 r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
                 r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
                 r = fvalid ? r : 0.f;
-                if (ph == 0 && fvalid) dst[WAVES * j] = r;
                 asm("v_max_f32 %0, %0, %1" : "+v"(vmax) : "v"(r));
+                keep = ph == (j & 3) ? r : keep;
+                if ((j & 3) == 3 || j == n_my - 1) {                                   // wave-uniform
+                    const int jm = (j & ~3) + ph;
+                    if (fvalid && jm < n_my) dst[WAVES * jm] = keep;
+                }
             }
         }
         __syncthreads();                                                 // the power rows are free again

@@ -23,7 +23,7 @@ def mean_by_kernel(path, counter):
 
 
 def short(name):
-    for key in ("mel_power_kernel", "core_fused_kernel", "emotion_kernel", "mel_log_kernel", "ema_scan", "smooth_kernel"):
+    for key in ("mel_power_rp_kernel", "mel_power_kernel", "core_fused_kernel", "emotion_kernel", "mel_log_kernel", "ema_scan", "smooth_kernel"):
         if key in name:
             return key
     return None
