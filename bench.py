@@ -5,7 +5,8 @@ Workload (BASELINE.json configs[1], "C2"): per GPU a batch of 256 synthetic 8.5 
 (136 448 samples @16 kHz) -> 1024-pt STFT / 80-bin log-mel (257 frames) -> dual-stream
 cross-attention (d_model 256, 8 heads, window 256) -> decoder -> temporal smoothing ->
 256 x 52 fp32 coefficients.  One "step" = one pass of that path over the batch
-(km_forward_audio: emotion_kernel_d256, mel_power_rp_kernel, core_fused_kernel with dB conversion + EMA);
+(km_forward_audio: mel_power_rp_kernel with the emotion logits computed by its spare workgroups,
+core_fused_kernel with dB conversion + EMA);
 inputs are resident in HBM before the timed region.  Windows shard embarrassingly across
 GPUs (weak scaling, no data-path collective).
 
@@ -155,8 +156,13 @@ def main():
                 "traffic": (pmc.get("mel_power_rp_kernel") or pmc.get("mel_power_kernel") or {}).get("hbm_bytes_per_launch"),
                 "launch_ms": round(t_mel * 1e3, 4), "algorithmic_bytes_per_launch": BYTES_PER_FRAME_AUDIO * B}
     roofline, other = (roof_core, roof_mel) if t_core >= t_mel else (roof_mel, roof_core)
-    stage_ms = {"emotion_kernel_d256": round(t_emo * 1e3, 4), "mel_power_rp_kernel": round(t_mel * 1e3, 4),
-                "core_fused_kernel": round(t_core * 1e3, 4)}
+    fused_emo = os.environ.get("KM_EMOTION_SEPARATE") is None and os.environ.get("KM_MEL_TWO_FRAME") is None
+    stage_ms = {"mel_power_rp_kernel": round(t_mel * 1e3, 4), "core_fused_kernel": round(t_core * 1e3, 4)}
+    if fused_emo:   # the emotion logits are computed inside the front-end kernel; what is left is one empty event pair
+        stage_ms["emotion"] = "inside mel_power_rp_kernel"
+        stage_ms["event_pair_overhead"] = round(t_emo * 1e3, 4)
+    else:
+        stage_ms["emotion_kernel_d256"] = round(t_emo * 1e3, 4)
 
     # ---- CPU baseline: the oracle on this host's cores (rank 0, N=1 only), bounded sample ----------
     cpu = None

@@ -376,10 +376,13 @@ int km_forward_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L, 
     // three launches: emotion logits, power-mel + window maxima, fused core (dB conversion on load)
     hipStream_t st = (hipStream_t)stream;
     const bool tm = c->stage_timing;
+    const bool fuse_emo = mel_fuses_emotion(c, c->mel_plans[0]);   // emotion logits computed inside the front-end kernel
     if (tm) HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[0], st));
-    if (int rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, stream)) return rc;
+    if (!fuse_emo)
+        if (int rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, stream)) return rc;
     if (tm) HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[1], st));
-    if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, L, stream)) return rc;
+    if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, L, stream, 0, 0, 0, 1, nullptr, nullptr,
+                                  fuse_emo ? emotion_dev : nullptr, fuse_emo ? c->ws_zemo : nullptr)) return rc;
     if (tm) { HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[2], st)); HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[3], st)); }
     if (int rc = launch_core_fused_db(c, c->mel_plans[0], B, n_frames, c->ws_zemo, out_dev, state_dev, first, stream)) return rc;
     if (tm) HIP_TRY(hipEventRecord((hipEvent_t)c->stage_ev[4], st));
@@ -460,8 +463,11 @@ int km_stream_tick(km_handle h, const float* emotion_dev, float* out_dev, uint8_
     const int64_t S = c->n_streams, L = c->ring_len;
     const int64_t n_frames = 1 + L / c->stream_plan->cfg.hop_length;
     if (S > c->ws_windows || n_frames > c->ws_frames) return fail(KM_ERR_WORKSPACE, "stream workspace too small");
-    if (int rc = launch_emotion(c, emotion_dev, S, c->ws_zemo, stream)) return rc;
-    if (int rc = launch_mel_power(c, c->stream_plan, c->ring, S, L, stream, L, 0, 0, 1, c->ring_wptr, c->ring_ready)) return rc;
+    const bool fuse_emo = mel_fuses_emotion(c, c->stream_plan);
+    if (!fuse_emo)
+        if (int rc = launch_emotion(c, emotion_dev, S, c->ws_zemo, stream)) return rc;
+    if (int rc = launch_mel_power(c, c->stream_plan, c->ring, S, L, stream, L, 0, 0, 1, c->ring_wptr, c->ring_ready,
+                                  fuse_emo ? emotion_dev : nullptr, fuse_emo ? c->ws_zemo : nullptr)) return rc;
     if (int rc = launch_core_fused_db(c, c->stream_plan, S, n_frames, c->ws_zemo, out_dev, c->ring_state, 0, stream, 0, 1,
                                       c->stream_out_frames, c->ring_ready, c->ring_started)) return rc;
     if (ready_dev)
@@ -552,9 +558,11 @@ int km_forward_audio_pipelined(km_handle h, const float* audio_dev, int64_t B, i
         if (hipEventRecord((hipEvent_t)c->pipe_ev_in[slot], caller) != hipSuccess) { rc = fail(KM_ERR_HIP, "hipEventRecord failed"); break; }
         if (hipStreamWaitEvent(s1, (hipEvent_t)c->pipe_ev_in[slot], 0) != hipSuccess) { rc = fail(KM_ERR_HIP, "hipStreamWaitEvent failed"); break; }
         if (tm) (void)hipEventRecord((hipEvent_t)c->stage_ev[0], s1);
-        if ((rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, s1))) break;
+        const bool fuse_emo = mel_fuses_emotion(c, c->mel_plans[0]);
+        if (!fuse_emo && (rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, s1))) break;
         if (tm) (void)hipEventRecord((hipEvent_t)c->stage_ev[1], s1);
-        if ((rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, L, s1))) break;
+        if ((rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, L, s1, 0, 0, 0, 1, nullptr, nullptr,
+                                   fuse_emo ? emotion_dev : nullptr, fuse_emo ? c->ws_zemo : nullptr))) break;
         if (tm) (void)hipEventRecord((hipEvent_t)c->stage_ev[2], s1);
         (void)hipEventRecord((hipEvent_t)c->pipe_ev_mel[slot], s1);
         (void)hipStreamWaitEvent(s2, (hipEvent_t)c->pipe_ev_mel[slot], 0);

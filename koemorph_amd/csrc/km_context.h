@@ -150,7 +150,9 @@ int launch_core_generic(Context* c, const float* mel, int64_t B, int64_t T_in, c
 // km_mel.hip
 int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, void* stream,
                      int64_t clip_len = 0, int64_t win_step = 0, int64_t win0 = 0, int wins_per_clip = 1,
-                     const int* ring_start = nullptr, const unsigned char* ready = nullptr);
+                     const int* ring_start = nullptr, const unsigned char* ready = nullptr,
+                     const float* emotion = nullptr, float* zemo = nullptr);
+bool mel_fuses_emotion(Context* c, MelPlan* p);
 int launch_ring_push(Context* c, const float* samples, int64_t n_per_stream, void* stream);
 int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, int64_t out_frames,
                float* mel_long, float* mel_short, void* stream, int64_t clip_len = 0, int64_t win_step = 0,

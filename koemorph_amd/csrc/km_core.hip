@@ -83,6 +83,20 @@ struct CoreArgs {
 // or -1 for the 24 expression rows
 __device__ __forceinline__ int mouth_slot_of(int i) { return (i >= 14 && i <= 40) ? i - 14 : (i == 51 ? 27 : -1); }
 
+// Sum over the 16 lanes of a DPP row, result in every lane: the same pairing (hence bit-identical sums) as the
+// xor-1/2/4/8 butterfly, but four v_add_f32_dpp instead of four ds_bpermute round trips through the LDS crossbar.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
+#ifndef KM_CORE_STOP
+#define KM_CORE_STOP 99
+#endif
+#define KM_STOP_AT(n, expr) if (KM_CORE_STOP == n) { if (a.t_in == -12345) a.out[threadIdx.x] = (expr); return; }
 template <bool ATTN, bool FUSE_DB>
 __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
     using namespace fused;
@@ -98,6 +112,8 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
     if constexpr (FUSE_DB) {
         if (a.ready && !a.ready[b]) return;     // stream still filling its ring (workgroup-uniform)
     }
+    if (KM_CORE_STOP == -1) return;
+    if (KM_CORE_STOP == -2) { if (a.t_in == -12345) a.out[threadIdx.x] = a.melpow[(int64_t)b * a.n_frames * NK + tid]; return; }
 
     // ---- phase 0: X -> LDS, [t][c] exactly as the caller's (t_in, 80) rows --------------------
     if constexpr (FUSE_DB) {
@@ -112,15 +128,27 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
         const float4* src = reinterpret_cast<const float4*>(a.melpow + (int64_t)b * F * NK);
         float4* dst = reinterpret_cast<float4*>(R1);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = tid; i < tv * 20; i += NT) {
+        // all T*20/NT = 10 row loads of a thread are in flight before the first conversion (one memory round trip
+        // instead of ten dependent ones: this phase is exposed, nothing overlaps it)
+        constexpr int NLD = T * 20 / NT;
+        static_assert(NLD * NT == T * 20, "phase 0 assumes T*20 is a multiple of the workgroup size");
+        float4 xv[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = tid + NT * u;
             int fr = i / 20;
             const int c4 = i - fr * 20;
             fr = fr < F ? fr : F - 1;
-            const float4 v = src[fr * 20 + c4];
-            dst[i] = make_float4(log_one(a.lp, v.x, ref_db, floor_db), log_one(a.lp, v.y, ref_db, floor_db),
-                                 log_one(a.lp, v.z, ref_db, floor_db), log_one(a.lp, v.w, ref_db, floor_db));
+            xv[u] = i < tv * 20 ? src[fr * 20 + c4] : z4;
         }
-        for (int i = tv * 20 + tid; i < T * 20; i += NT) dst[i] = z4;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = tid + NT * u;
+            const float4 v = xv[u];
+            dst[i] = i < tv * 20 ? make_float4(log_one(a.lp, v.x, ref_db, floor_db), log_one(a.lp, v.y, ref_db, floor_db),
+                                               log_one(a.lp, v.z, ref_db, floor_db), log_one(a.lp, v.w, ref_db, floor_db))
+                                 : z4;
+        }
         if (tid < 60) {
             const int r = tid / 20;
             float4 v = z4;
@@ -150,6 +178,7 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
     if constexpr (FUSE_DB) {
         if (tid == 0) a.melmax[b] = 0u;     // every thread has read it: hand a clean slot to the next front-end launch
     }
+    KM_STOP_AT(0, R1[tid])
 
     // ---- phase 1: channel encoder GEMM -----------------------------------------------------
     f32x4 acc[5][2];
@@ -176,6 +205,7 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
             bw = bn;
         }
     }
+    KM_STOP_AT(1, acc[0][0][0] + acc[1][1][1] + acc[2][0][2] + acc[3][1][3] + acc[4][0][0] + acc[0][1][0] + acc[1][0][0] + acc[2][1][0] + acc[3][0][0] + acc[4][1][0])
     // bias; this lane's two columns are n0 = 32*wave + j and n0 + 16
     const int n0 = 32 * wave + j;
     {
@@ -201,11 +231,7 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
                     const float d0 = acc[mt][0][r] - mean[mt][r], d1 = acc[mt][1][r] - mean[mt][r];
                     v = d0 * d0 + d1 * d1;
                 }
-                v += __shfl_xor(v, 1);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 8);
-                part[mt][r] = v;
+                part[mt][r] = row16_sum(v);
             }
         if (j == 0) {
 #pragma unroll
@@ -240,6 +266,7 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
     }
     __syncthreads();
 
+    KM_STOP_AT(2, R1[tid])
     // ---- phases 2+3: S^T = Y Qk_h^T and V_h = Y Wv_h^T in one sweep over Y -------------------
     f32x4 S[5][2], V[5][2];
 #pragma unroll
@@ -272,6 +299,10 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
             q0 = q0n; q1 = q1n; v0 = v0n; v1 = v1n;
         }
     }
+    if (KM_CORE_STOP == 3) { float t = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) for (int r = 0; r < 4; ++r) t += S[mt][0][r] + S[mt][1][r] + V[mt][0][r] + V[mt][1][r];
+        if (a.t_in == -12345) a.out[threadIdx.x] = t; return; }
     // softmax over the 80 keys of each query column: 20 values in-lane, then across the 4 lane groups
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -314,6 +345,7 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
             O[1][1] = KM_MFMA(V[mt][1][r], S[mt][1][r], O[1][1]);
         }
 
+    KM_STOP_AT(4, O[0][0][0] + O[0][1][1] + O[1][0][2] + O[1][1][3] + O[0][0][1] + O[0][1][2] + O[1][0][3] + O[1][1][0] + O[0][0][2] + O[0][1][3] + O[1][0][0] + O[1][1][1] + O[0][0][3] + O[0][1][0] + O[1][0][1] + O[1][1][2])
     __syncthreads();   // every wave is done reading Y; R1 becomes O [32 q][264]
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)

@@ -28,4 +28,114 @@ __device__ __forceinline__ float log_one(const LogParams& p, float s, float ref_
     return (v + p.db_add) * p.db_scale;                               // simplified_dual_stream_model.py:200
 }
 
+// ---------------------------------------------------------------------------------------------
+// Emotion stream of ONE window by one 512-thread workgroup (production shape: d_model 256, decoder hidden 128,
+// emotion_dim <= 256), for workgroups of another kernel that have slack (the front end's second workgroup of a
+// window).  Arithmetic and summation order are exactly those of emotion_kernel_d256 (km_core.hip): layer 1 in four
+// k-quarters of 64, layer 2 in eight k-eighths of 32, partials combined in index order -- the two are bit-identical.
+// ---------------------------------------------------------------------------------------------
+struct EmoArgs {
+    const float* emo = nullptr;   // (B, ED); nullptr = not fused
+    int ED = 0;
+    const float *wee_t = nullptr /* (256, 256): rows >= ED are zero */, *bee = nullptr, *lg = nullptr, *lb = nullptr, *we2 = nullptr, *be2 = nullptr,
+                *w2 = nullptr, *b2 = nullptr;
+    float* zemo = nullptr;        // (B)
+};
+
+// scratch: 1536 floats of LDS.  Must be called by all 512 threads of the workgroup (contains barriers).
+__device__ __forceinline__ void emotion_window_d256(const EmoArgs& e, int64_t b, float* scratch) {
+    constexpr int d = 256, DH = 128;
+    float* emo_s = scratch;           // [256]
+    float* e1 = scratch + 256;        // [256]
+    float* part = scratch + 512;      // [4][256] then [8][128]
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 256) emo_s[tid] = tid < e.ED ? e.emo[b * e.ED + tid] : 0.f;
+    __syncthreads();
+    {   // layer 1: column n, k-quarters 2h and 2h+1 (64 coalesced loads in flight per quarter; wee_t is the
+        // zero-padded 256-row image, so no guards)
+        const int n = tid & 255, h = __builtin_amdgcn_readfirstlane(tid >> 8);
+#pragma unroll 1
+        for (int q = 2 * h; q < 2 * h + 2; ++q) {
+            const float* wp = e.wee_t + (size_t)64 * q * d + n;
+            float w[64];
+#pragma unroll
+            for (int u = 0; u < 64; ++u) w[u] = wp[u * d];
+            float acc = 0.f;
+#pragma unroll
+            for (int u = 0; u < 64; u += 4) {
+                const float4 x = *reinterpret_cast<const float4*>(emo_s + 64 * q + u);
+                acc = fmaf(x.x, w[u], acc);
+                acc = fmaf(x.y, w[u + 1], acc);
+                acc = fmaf(x.z, w[u + 2], acc);
+                acc = fmaf(x.w, w[u + 3], acc);
+            }
+            part[q * d + n] = acc;
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        float s = e.bee[tid];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s += part[q * d + tid];
+        e1[tid] = s;
+    }
+    __syncthreads();
+    if (tid < 64) {   // LayerNorm (eps 1e-5), two-pass, one wave
+        float x[4], s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = e1[lane + 64 * i]; s += x[i]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * (1.0f / d);
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float t = x[i] - mean; v += t * t; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        const float rstd = 1.0f / sqrtf(v * (1.0f / d) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = lane + 64 * i;
+            e1[c] = (x[i] - mean) * rstd * e.lg[c] + e.lb[c];
+        }
+    }
+    __syncthreads();
+    {   // layer 2: hidden unit m, k-eighths 2h and 2h+1
+        const int m = tid & 127, h = tid >> 7;     // two values of h per wave
+#pragma unroll 1
+        for (int q = 2 * h; q < 2 * h + 2; ++q) {
+            const float* wp = e.we2 + (size_t)32 * q * DH + m;
+            float w[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) w[u] = wp[u * DH];
+            float acc = 0.f;
+#pragma unroll
+            for (int u = 0; u < 32; u += 4) {
+                const float4 x = *reinterpret_cast<const float4*>(e1 + 32 * q + u);
+                acc = fmaf(x.x, w[u], acc);
+                acc = fmaf(x.y, w[u + 1], acc);
+                acc = fmaf(x.z, w[u + 2], acc);
+                acc = fmaf(x.w, w[u + 3], acc);
+            }
+            part[q * DH + m] = acc;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {   // ReLU, dot with w2
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mm = lane + 64 * i;
+            float hsum = e.be2[mm];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) hsum += part[q * DH + mm];
+            s += fmaxf(hsum, 0.f) * e.w2[mm];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) e.zemo[b] = s + e.b2[0];
+    }
+    __syncthreads();   // scratch is free again
+}
+
 }  // namespace km

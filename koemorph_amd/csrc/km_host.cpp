@@ -189,6 +189,12 @@ int finalize_host(Context* c) {
     put(c, "we2", to_f(We2));                                      // (d, DH)
     put(c, "be2", to_f(bfE));                                      // (DH)
     put(c, "wee_t", to_f(transpose(to_d(P(c, "emotion_encoder.weight")), d, ED)));   // (ED, d)
+    if (d == 256 && ED <= 256) {   // rows zero-padded to 256 k: the emotion step fused into the front end loads without guards
+        std::vector<float> wpad((size_t)256 * d, 0.0f);
+        const std::vector<float>& wt = c->packed.at("wee_t").host;
+        std::copy(wt.begin(), wt.end(), wpad.begin());
+        put(c, "wee_t256", std::move(wpad));
+    }
     put(c, "bee", std::vector<float>(P(c, "emotion_encoder.bias")));
     put(c, "eln_g", std::vector<float>(P(c, "emotion_norm.weight")));
     put(c, "eln_b", std::vector<float>(P(c, "emotion_norm.bias")));

@@ -119,6 +119,7 @@ struct MelArgs {
     int fb4_nnz;
     float* melpow;        // (B, n_frames, n_mels)
     unsigned* melmax;     // (B) float bits, zero-initialised
+    EmoArgs emo;          // optional: the window's emotion logit, computed by the last workgroup of each window
 };
 
 // raw samples of the frame pair (fa, fa+1) into z[i] = (x_a[lane + 64 i], x_b[lane + 64 i]); wave-uniform fa
@@ -543,6 +544,10 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
     const int n_chunks = (a.n_frames + FPB - 1) / FPB;
     const unsigned rd2 = lds_offset(buf + (lane >> 3) * 72 + (lane & 7)), rd3 = lds_offset(buf + lane * 9);
 
+    // The emotion stream of this window (0.2 MFLOP, latency bound, independent of the audio) rides in the workgroup
+    // that has one chunk less to do than its sibling: no separate launch, no exposed latency.
+    if (a.emo.emo && blockIdx.x == gridDim.x - 1) emotion_window_d256(a.emo, gw, pw);
+
     for (int i = tid; i < a.fb4_nnz; i += NT) fbw[i] = 0.25f * a.fb4_weight[i];
     if (tid < FPB * 15) pw[(tid / 15) * NFS + 513 + tid % 15] = 0.f;     // row padding read by the 16-bin mel trips
 
@@ -779,9 +784,15 @@ static LogParams log_params(const km_mel_config& m) {
 }
 
 // power-mel (B, n_frames, n_mels) + per-window max into the workspace
+// true when launch_mel_power can compute the per-window emotion logits inside the front-end kernel
+bool mel_fuses_emotion(Context* c, MelPlan* p) {
+    static const bool use_rp = std::getenv("KM_MEL_TWO_FRAME") == nullptr && std::getenv("KM_EMOTION_SEPARATE") == nullptr;
+    return use_rp && p->cfg.n_fft == 1024 && c->kind == 0 && c->d == 256 && c->DH == 128 && c->ED <= 256;
+}
+
 int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, void* stream,
                      int64_t clip_len, int64_t win_step, int64_t win0, int wins_per_clip, const int* ring_start,
-                     const unsigned char* ready) {
+                     const unsigned char* ready, const float* emotion, float* zemo) {
     const km_mel_config& m = p->cfg;
     const int64_t n_frames = 1 + L / m.hop_length;
     if (m.pad_mode == KM_PAD_REFLECT && L <= m.n_fft / 2)
@@ -822,6 +833,14 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     a.fb_nnz = (int)p->fb_weight.size();
     a.fb4_desc = p->d_fb4_desc; a.fb4_weight = p->d_fb4_weight; a.fb4_nnz = (int)p->fb4_weight.size();
     a.melpow = c->ws_melpow; a.melmax = c->ws_melmax;
+    if (emotion) {
+        if (!mel_fuses_emotion(c, p) || !zemo || wins_per_clip > 1)
+            return fail(KM_ERR_UNSUPPORTED, "launch_mel_power: emotion fusion requested for an unsupported configuration");
+        auto dvp = [&](const char* name) { return (const float*)c->packed.at(name).dev; };
+        a.emo.emo = emotion; a.emo.ED = c->ED; a.emo.zemo = zemo;
+        a.emo.wee_t = dvp("wee_t256"); a.emo.bee = dvp("bee"); a.emo.lg = dvp("eln_g"); a.emo.lb = dvp("eln_b");
+        a.emo.we2 = dvp("we2"); a.emo.be2 = dvp("be2"); a.emo.w2 = dvp("w2"); a.emo.b2 = dvp("b2");
+    }
     // persistent over frame chunks: each workgroup walks chunks blockIdx.x, +gridDim.x, ... of its window with the
     // next pair's samples prefetched; two workgroups are resident per CU (LDS), so aim at 512 in total
     const int n_chunks = (int)((n_frames + mel::FPB - 1) / mel::FPB);
