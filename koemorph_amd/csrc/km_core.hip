@@ -28,6 +28,8 @@
 // b128) -- legal because the weights are packed on the host with the same permutation.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "km_context.h"
 #include "km_device.h"
 
@@ -48,7 +50,7 @@ constexpr int KT = 259, KTP = 264, YS = 264, NW = 8, NT = 512;
 constexpr int KP = 33;               // k-step pairs of the encoder GEMM (66 steps of 4 >= 259)
 constexpr int KB = 16;               // 16-wide k blocks of the d=256 contractions
 constexpr int R1_FLOATS = KTP * NK;  // 21120: X [264][80]  ==  Y [80][264]
-constexpr int R2_FLOATS = NW * NK;   // 640: cross-wave reduction scratch
+constexpr int R2_FLOATS = 2 * NW * NK;   // 1280: cross-wave reduction scratch, one [80 rows][8 waves] image per LayerNorm pass
 constexpr int LDS_BYTES = (R1_FLOATS + R2_FLOATS) * 4;
 }  // namespace fused
 
@@ -128,8 +130,7 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
         const float4* src = reinterpret_cast<const float4*>(a.melpow + (int64_t)b * F * NK);
         float4* dst = reinterpret_cast<float4*>(R1);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        // all T*20/NT = 10 row loads of a thread are in flight before the first conversion (one memory round trip
-        // instead of ten dependent ones: this phase is exposed, nothing overlaps it)
+        // all T*20/NT = 10 row loads of a thread (and the short-row load) are in flight before the first conversion
         constexpr int NLD = T * 20 / NT;
         static_assert(NLD * NT == T * 20, "phase 0 assumes T*20 is a multiple of the workgroup size");
         float4 xv[NLD];
@@ -141,27 +142,27 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
             fr = fr < F ? fr : F - 1;
             xv[u] = i < tv * 20 ? src[fr * 20 + c4] : z4;
         }
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int i = tid + NT * u;
-            const float4 v = xv[u];
-            dst[i] = i < tv * 20 ? make_float4(log_one(a.lp, v.x, ref_db, floor_db), log_one(a.lp, v.y, ref_db, floor_db),
-                                               log_one(a.lp, v.z, ref_db, floor_db), log_one(a.lp, v.w, ref_db, floor_db))
-                                 : z4;
-        }
+        float4 sv = z4;
+        bool s_ok = false;
         if (tid < 60) {
             const int r = tid / 20;
-            float4 v = z4;
             int fr = -1;
             if (U >= 3) fr = U - 3 + r; else if (r < U) fr = r;
             if (fr >= F) fr = F - 1;
-            if (fr >= 0) {
-                const float4 u = src[fr * 20 + (tid - r * 20)];
-                v = make_float4(log_one(a.lp, u.x, ref_db, floor_db), log_one(a.lp, u.y, ref_db, floor_db),
-                                log_one(a.lp, u.z, ref_db, floor_db), log_one(a.lp, u.w, ref_db, floor_db));
-            }
-            dst[T * 20 + tid] = v;
+            s_ok = fr >= 0;
+            if (s_ok) sv = src[fr * 20 + (tid - r * 20)];
         }
+        auto convert = [&](auto mode) {          // the conversion mode is uniform: one branch, not one per value
+            constexpr int MODE = decltype(mode)::value;
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const int i = tid + NT * u;
+                dst[i] = i < tv * 20 ? log_four_t<MODE>(a.lp, xv[u], ref_db, floor_db) : z4;
+            }
+            if (tid < 60) dst[T * 20 + tid] = s_ok ? log_four_t<MODE>(a.lp, sv, ref_db, floor_db) : z4;
+        };
+        if (a.lp.log_mode == KM_LOG_LN_EPS) convert(std::integral_constant<int, KM_LOG_LN_EPS>{});
+        else convert(std::integral_constant<int, KM_LOG_DB_MAX>{});
         if (tid >= 64 && tid < 64 + (KTP - KT) * 20) dst[KT * 20 + tid - 64] = z4;
     } else {
         const int tv = a.t_in < T ? a.t_in : T;   // rows beyond T are truncated (:200-202)
@@ -233,25 +234,28 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
                 }
                 part[mt][r] = row16_sum(v);
             }
+        // partial sums of this wave's 32 columns -> [row][wave]; the two passes use separate images, so the only
+        // barrier a pass needs is the one between its writes and its reads
+        float* P = R2 + pass * (NW * NK);
         if (j == 0) {
 #pragma unroll
             for (int mt = 0; mt < 5; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) R2[wave * NK + 16 * mt + 4 * g + r] = part[mt][r];
+                for (int r = 0; r < 4; ++r) P[(16 * mt + 4 * g + r) * NW + wave] = part[mt][r];
         }
         __syncthreads();   // pass 0: also fences every wave's last read of X
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * mt + 4 * g + r;
+                const f32x4* pr = reinterpret_cast<const f32x4*>(P + (16 * mt + 4 * g + r) * NW);
+                const f32x4 lo = pr[0], hi = pr[1];
                 float s = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) s += R2[w * NK + row];
+                s += lo[0]; s += lo[1]; s += lo[2]; s += lo[3];
+                s += hi[0]; s += hi[1]; s += hi[2]; s += hi[3];          // waves in index order, as before
                 if (pass == 0) mean[mt][r] = s * (1.0f / D);
-                else rstd[mt][r] = 1.0f / sqrtf(s * (1.0f / D) + 1e-5f);
+                else rstd[mt][r] = __builtin_amdgcn_rsqf(s * (1.0f / D) + 1e-5f);     // v_rsq_f32 (1 ulp)
             }
-        __syncthreads();   // R2 is rewritten by the next pass / later phases
     }
     {
         const float g0 = a.ln_g[n0], g1 = a.ln_g[n0 + 16], be0 = a.ln_b[n0], be1 = a.ln_b[n0 + 16];
@@ -318,13 +322,13 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
         for (int mt = 0; mt < 5; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = expf(S[mt][qt][r] - m);
+                const float e = __builtin_amdgcn_exp2f((S[mt][qt][r] - m) * 1.44269504088896341f);   // v_exp_f32: arguments <= 0
                 S[mt][qt][r] = e;
                 sum += e;
             }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);                                  // v_rcp_f32 (1 ulp), sum in [1, 80]
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt)
 #pragma unroll

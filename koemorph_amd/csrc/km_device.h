@@ -12,20 +12,39 @@ struct LogParams {
     float amin, top_db, db_add, db_scale, log_eps;
 };
 
+// 10 log10(max(amin, s)) and ln(x) on the hardware log2 (v_log_f32, 1 ulp): |error| < 2e-5 dB over [amin, 1e10], i.e.
+// < 3e-7 after the 1/80 normalisation.  Operands are >= amin / eps (never denormal), so the library wrappers' denormal
+// scaling, compensated constant multiply and inf/nan selects (25 instructions per value) buy nothing here; the clamps
+// are v_med3_f32 (no canonicalising v_max pair).
+__device__ __forceinline__ float clamp_lo(float x, float lo) { return __builtin_amdgcn_fmed3f(x, lo, __builtin_inff()); }
+__device__ __forceinline__ float db10(float s, float amin) {
+    return 3.01029995663981195f * __builtin_amdgcn_logf(clamp_lo(s, amin));
+}
+
 // per-window constants of librosa.power_to_db(ref=np.max): reference level and the top_db floor
 __device__ __forceinline__ void log_window_consts(const LogParams& p, float ref, float& ref_db, float& floor_db) {
-    ref_db = 10.0f * __log10f(fmaxf(p.amin, ref));
+    ref_db = db10(ref, p.amin);
     // log_spec.max() - top_db: the window maximum is its own reference, so max_db = f(ref) - ref_db
-    floor_db = (10.0f * __log10f(fmaxf(p.amin, ref)) - ref_db) - p.top_db;
+    floor_db = (db10(ref, p.amin) - ref_db) - p.top_db;
+}
+
+template <int MODE>
+__device__ __forceinline__ float log_one_t(const LogParams& p, float s, float ref_db, float floor_db) {
+    if (MODE == KM_LOG_LN_EPS) return 0.693147180559945309f * __builtin_amdgcn_logf(s + p.log_eps);   // src/features/stft.py:123
+    float v = db10(s, p.amin) - ref_db;                                // librosa.power_to_db
+    v = clamp_lo(v, floor_db);
+    return (v + p.db_add) * p.db_scale;                               // simplified_dual_stream_model.py:200
 }
 
 __device__ __forceinline__ float log_one(const LogParams& p, float s, float ref_db, float floor_db) {
-    // hardware v_log_f32 (1 ulp in log2): |error| < 2e-5 dB over the whole [amin, 1e10] range; the
-    // operands are clamped to >= amin / eps, so no denormal reaches it
-    if (p.log_mode == KM_LOG_LN_EPS) return __logf(s + p.log_eps);    // src/features/stft.py:123
-    float v = 10.0f * __log10f(fmaxf(p.amin, s)) - ref_db;            // librosa.power_to_db
-    v = fmaxf(v, floor_db);
-    return (v + p.db_add) * p.db_scale;                               // simplified_dual_stream_model.py:200
+    return p.log_mode == KM_LOG_LN_EPS ? log_one_t<KM_LOG_LN_EPS>(p, s, ref_db, floor_db)
+                                       : log_one_t<KM_LOG_DB_MAX>(p, s, ref_db, floor_db);
+}
+
+template <int MODE>
+__device__ __forceinline__ float4 log_four_t(const LogParams& p, float4 v, float ref_db, float floor_db) {
+    return make_float4(log_one_t<MODE>(p, v.x, ref_db, floor_db), log_one_t<MODE>(p, v.y, ref_db, floor_db),
+                       log_one_t<MODE>(p, v.z, ref_db, floor_db), log_one_t<MODE>(p, v.w, ref_db, floor_db));
 }
 
 // ---------------------------------------------------------------------------------------------
