@@ -231,6 +231,26 @@ int km_train_get_params(km_handle h, float* flat_host, int64_t n);
 int km_train_set_params(km_handle h, const float* flat_host, int64_t n);
 int km_train_sync(km_handle h, void* stream);
 
+/* The remaining terms of KoeMorphLoss (src/model/losses.py:29-178), ADDED to the mse/l1 terms of km_train_step*:
+ *   perceptual  four group-weighted MSEs: mouth cols 12..31 x2.0, eye 0..11 x1.0, brow 32..43 x1.0, jaw 44..51 x1.5
+ *               (losses.py:306-338; the optional audio-visual term needs audio_features and is not computed, as when
+ *               the reference is called with audio_features=None)
+ *   temporal    MSE of (pred - prev_pred) vs (target - prev_target)           (losses.py:185-200)
+ *   velocity    L1 of the same differences                                    (losses.py:202-217)
+ *   sparsity    mean |pred|                                                   (losses.py:219-224)
+ *   smoothness  mean |pred[:, j+1] - pred[:, j]| over the 51 adjacent pairs    (losses.py:226-234)
+ *   landmark    MSE of pred W^T vs target W^T, W = the loss module's fixed (136, 52) matrix (losses.py:380-412)
+ * prev_pred_dev / prev_target_dev (B,52) are constants (no gradient); temporal and velocity are skipped when either
+ * is NULL, landmark when landmark_w_dev is NULL -- as the reference skips them.  Pointers must stay valid for every
+ * later km_train_step* call (they are read on the step's stream).  cfg = NULL switches the extra terms off. */
+typedef struct km_loss_config {
+    float perceptual_weight, temporal_weight, sparsity_weight, smoothness_weight, landmark_weight, velocity_weight;
+    const float* prev_pred_dev;
+    const float* prev_target_dev;
+    const float* landmark_w_dev;
+} km_loss_config;
+int km_train_set_loss(km_handle h, const km_loss_config* cfg);
+
 /* ---- legacy single-stream variant --------------------------------------------------------------------
  * SimplifiedKoeMorphModel (src/model/simplified_model.py:12-156), used by the reference's src/train.py,
  * scripts/rt_simplified.py and scripts/test_model.py: same librosa-style log-mel front end, a two-layer

@@ -40,6 +40,12 @@ class KMLegacyConfig(C.Structure):
                 ("decoder_hidden", C.c_int32), ("num_blendshapes", C.c_int32), ("mel", KMMelConfig)]
 
 
+class KMLossConfig(C.Structure):
+    _fields_ = [("perceptual_weight", C.c_float), ("temporal_weight", C.c_float), ("sparsity_weight", C.c_float),
+                ("smoothness_weight", C.c_float), ("landmark_weight", C.c_float), ("velocity_weight", C.c_float),
+                ("prev_pred_dev", C.c_void_p), ("prev_target_dev", C.c_void_p), ("landmark_w_dev", C.c_void_p)]
+
+
 KM_MEL_SLANEY, KM_MEL_HTK = 0, 1
 KM_PAD_CONSTANT, KM_PAD_REFLECT = 0, 1
 KM_LOG_DB_MAX, KM_LOG_LN_EPS = 0, 1
@@ -87,6 +93,7 @@ SIGNATURES = {
     "km_train_get_params": (C.c_int, [_h, _p, _i64]),
     "km_train_set_params": (C.c_int, [_h, _p, _i64]),
     "km_train_sync": (C.c_int, [_h, _p]),
+    "km_train_set_loss": (C.c_int, [_h, C.POINTER(KMLossConfig)]),
     "km_legacy_create": (C.c_int, [C.POINTER(KMLegacyConfig), C.POINTER(_h)]),
     "km_legacy_forward": (C.c_int, [_h, _p, _i64, _i64, _p, _p]),
     "km_legacy_forward_mel": (C.c_int, [_h, _p, _i64, _i64, _p, _p]),

@@ -290,6 +290,13 @@ int km_train_step_audio(km_handle h, const float* audio_dev, int64_t B, int64_t 
                                   flat_grad_dev, loss_dev, out_dev, ema_state_dev, ema_first, stream);
 }
 
+int km_train_set_loss(km_handle h, const km_loss_config* cfg) {
+    if (int rc = need_train(h, 1)) return rc;
+    Context* c = h;
+    if (cfg) c->tr_loss_cfg = *cfg; else c->tr_loss_cfg = km_loss_config{};
+    return KM_OK;
+}
+
 int km_train_adamw(km_handle h, const float* flat_grad_dev, float lr, float beta1, float beta2, float eps,
                    float weight_decay, float max_grad_norm, int64_t step, void* stream) {
     if (int rc = need_train(h, 1)) return rc;

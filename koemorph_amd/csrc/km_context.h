@@ -98,6 +98,7 @@ struct Context {
     float* tr_red = nullptr;         // split-reduction partials
     int* tr_steps = nullptr;         // device-side AdamW step counters (graph replay safe)
     bool tr_alpha_live = false;      // smoothing_alpha was in the last step's graph (see adamw_kernel)
+    km_loss_config tr_loss_cfg{};    // extra KoeMorphLoss terms (all weights 0 = off)
     int64_t tr_alpha_steps = 0;
     bool stage_timing = false;
     void* stage_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // hipEvent_t: emo b/e, mel e, core b/e

@@ -230,6 +230,9 @@ struct TailArgs {
     int ema_first;
     const float* alpha_p; // smoothing_alpha parameter
     float mse_w, l1_w;
+    km_loss_config lc;    // extra KoeMorphLoss terms (weights 0 = off)
+    float* fac;           // (B, 52) scratch: d y / d f of the clamp + EMA
+    float* xp;            // (B, 52) scratch: x - previous EMA state
     float* loss;          // (1)
     float* d_melw; float* d_emow; float* d_alpha;   // gradients (52), (52), (1)
     int B, DH;
@@ -237,8 +240,12 @@ struct TailArgs {
 
 // One workgroup: decoder output layer, sigmoid, stream weights, clamp, EMA, loss and the gradient of the loss
 // with respect to every pre-sigmoid logit.  B is small in training (8 per GPU), all loops are in a fixed order.
+// Pass A computes the prediction y (B,52); pass B the loss terms of KoeMorphLoss (src/model/losses.py:112-178) and
+// dL/dy -- the smoothness and landmark terms need the whole row of y, hence two passes.
+__device__ __forceinline__ float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }   // torch: d|x|/dx = sign(x)
+
 __global__ __launch_bounds__(64) void train_tail_kernel(TailArgs a) {
-    __shared__ float wsum_s[52], wm_s[52], we_s[52], dws_s[52], red[64];
+    __shared__ float wsum_s[52], wm_s[52], we_s[52], dws_s[52], red[64], e_s[52], u_s[136];
     const int i = threadIdx.x;
     if (i == 0) {   // stream weight softmaxes (dual_stream_attention.py:252-253)
         float mm = -INFINITY, me = -INFINITY;
@@ -253,7 +260,8 @@ __global__ __launch_bounds__(64) void train_tail_kernel(TailArgs a) {
     __syncthreads();
     const float alpha = 1.0f / (1.0f + expf(-a.alpha_p[0]));
     const float inv_n = 1.0f / (float)(a.B * 52);
-    float loss_acc = 0.f, dws = 0.f, dal = 0.f;
+    const bool ema_on = a.ema_state && !a.ema_first;
+    // ---- pass A: y = EMA(clamp(wsum * sigmoid(z))) ----
     if (i < 52) {
         const int slot = tr_mouth_slot(i);
         for (int b = 0; b < a.B; ++b) {
@@ -261,36 +269,92 @@ __global__ __launch_bounds__(64) void train_tail_kernel(TailArgs a) {
             const float bs = 1.0f / (1.0f + expf(-z));
             const float f = wsum_s[i] * bs;
             const float x = fminf(fmaxf(f, 0.f), 1.f);
-            float y = x, dx_dy = 1.f;
+            float y = x, dy_dx = 1.f, xp = 0.f;
             if (a.ema_state) {
                 float* st = a.ema_state + (int64_t)b * 52 + i;
                 if (!a.ema_first) {
                     const float prev = *st;
                     y = alpha * x + (1.0f - alpha) * prev;
-                    dx_dy = alpha;
-                    // d y / d smoothing_alpha = (x - prev) * alpha (1 - alpha); filled in below once dL/dy is known
-                    red[i] = (x - prev);
+                    dy_dx = alpha;
+                    xp = x - prev;          // d y / d smoothing_alpha = (x - prev) * alpha (1 - alpha)
                 }
                 *st = y;
             }
-            const float diff = y - a.target[(int64_t)b * 52 + i];
-            loss_acc += a.mse_w * diff * diff + a.l1_w * fabsf(diff);
-            const float dy = (a.mse_w * 2.0f * diff + a.l1_w * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f))) * inv_n;
-            if (a.ema_state && !a.ema_first) dal += dy * red[i] * alpha * (1.0f - alpha);
-            const float df = dy * dx_dy * ((f >= 0.f && f <= 1.f) ? 1.f : 0.f);
-            dws += df * bs;
             a.bs[(int64_t)b * 52 + i] = bs;
             a.out[(int64_t)b * 52 + i] = y;
+            a.fac[(int64_t)b * 52 + i] = dy_dx * ((f >= 0.f && f <= 1.f) ? 1.f : 0.f);
+            a.xp[(int64_t)b * 52 + i] = xp;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- pass B: loss terms and dL/dy, row by row ----
+    const km_loss_config& lc = a.lc;
+    const bool have_prev = lc.prev_pred_dev && lc.prev_target_dev;
+    const bool t_on = lc.temporal_weight > 0.f && have_prev, v_on = lc.velocity_weight > 0.f && have_prev;
+    const bool lm_on = lc.landmark_weight > 0.f && lc.landmark_w_dev;
+    // perceptual groups (losses.py:306-338): weight / group size
+    float pg = 0.f;
+    if (i < 52) pg = i < 12 ? 1.0f / 12.f : (i < 32 ? 2.0f / 20.f : (i < 44 ? 1.0f / 12.f : 1.5f / 8.f));
+    float loss_acc = 0.f, dws = 0.f, dal = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+        float y = 0.f, e = 0.f, dy = 0.f;
+        if (i < 52) {
+            y = a.out[(int64_t)b * 52 + i];
+            e = y - a.target[(int64_t)b * 52 + i];
+            loss_acc += (a.mse_w * e * e + a.l1_w * fabsf(e)) * inv_n;
+            dy = (a.mse_w * 2.0f * e + a.l1_w * sgnf(e)) * inv_n;
+            if (lc.perceptual_weight > 0.f) {
+                const float w = lc.perceptual_weight * pg / (float)a.B;
+                loss_acc += w * e * e;
+                dy += w * 2.0f * e;
+            }
+            if (t_on || v_on) {
+                const float dd = (y - lc.prev_pred_dev[(int64_t)b * 52 + i]) -
+                                 (a.target[(int64_t)b * 52 + i] - lc.prev_target_dev[(int64_t)b * 52 + i]);
+                if (t_on) { loss_acc += lc.temporal_weight * dd * dd * inv_n; dy += lc.temporal_weight * 2.0f * dd * inv_n; }
+                if (v_on) { loss_acc += lc.velocity_weight * fabsf(dd) * inv_n; dy += lc.velocity_weight * sgnf(dd) * inv_n; }
+            }
+            if (lc.sparsity_weight > 0.f) { loss_acc += lc.sparsity_weight * fabsf(y) * inv_n; dy += lc.sparsity_weight * sgnf(y) * inv_n; }
+            if (lc.smoothness_weight > 0.f) {   // torch.diff along the 52 coefficients: 51 pairs per row
+                const float w = lc.smoothness_weight / (float)(a.B * 51);
+                if (i > 0) { const float dl = y - a.out[(int64_t)b * 52 + i - 1]; loss_acc += w * fabsf(dl); dy += w * sgnf(dl); }
+                if (i < 51) { const float dr = a.out[(int64_t)b * 52 + i + 1] - y; dy -= w * sgnf(dr); }
+            }
+            e_s[i] = e;
+        }
+        if (lm_on) {   // u = e W^T (136), loss = mean u^2, dL/de = 2/(B 136) u W
+            __syncthreads();
+            for (int k = i; k < 136; k += 64) {
+                float u = 0.f;
+                for (int jj = 0; jj < 52; ++jj) u += e_s[jj] * lc.landmark_w_dev[k * 52 + jj];
+                u_s[k] = u;
+            }
+            __syncthreads();
+            const float w = lc.landmark_weight / (float)(a.B * 136);
+            if (i < 52) {
+                float gsum = 0.f;
+                for (int k = 0; k < 136; ++k) gsum += u_s[k] * lc.landmark_w_dev[k * 52 + i];
+                dy += w * 2.0f * gsum;
+            }
+            if (i == 0) { float q = 0.f; for (int k = 0; k < 136; ++k) q += u_s[k] * u_s[k]; loss_acc += w * q; }
+            __syncthreads();
+        }
+        if (i < 52) {
+            if (ema_on) dal += dy * a.xp[(int64_t)b * 52 + i] * alpha * (1.0f - alpha);
+            const float df = dy * a.fac[(int64_t)b * 52 + i];
+            const float bs = a.bs[(int64_t)b * 52 + i];
+            dws += df * bs;
             a.dz[(int64_t)b * 52 + i] = df * wsum_s[i] * bs * (1.0f - bs);
         }
-        dws_s[i] = dws;
     }
+    if (i < 52) dws_s[i] = dws;
     red[i] = i < 52 ? loss_acc : 0.f;
     __syncthreads();
     if (i == 0) {
         float s = 0.f;
         for (int k = 0; k < 52; ++k) s += red[k];
-        a.loss[0] = s * inv_n;
+        a.loss[0] = s;
     }
     __syncthreads();
     red[i] = i < 52 ? dal : 0.f;
@@ -450,7 +514,7 @@ int64_t train_act_floats(Context* c) {
     return 2 * R * d /* Y0, Y */ + 2 * R /* mean, rstd */ + 2 * R * d /* KV */ + 2 * H * Rq * NKk /* P, dP */ +
            3 * Rq * d /* A, O1, O2 */ + Rq * DH /* H1 */ + 2 * R * d /* dKV */ + R * d /* dY */ + 2 * Rq * d /* ping-pong grads */ +
            Rq * DH /* dH1 */ + 5 * d /* E0, E, Ve, Oe1, Oe2 */ + 2 /* emo stats */ + DH /* He */ + 3 * d + DH /* emotion grads */ +
-           4 * 52 /* bs, out, dz, pad */ + 2 * (Rq + 1) /* zrows, row grads */;
+           6 * 52 /* bs, out, dz, two loss-tail scratch rows, pad */ + 2 * (Rq + 1) /* zrows, row grads */;
 }
 
 struct ParamView { const float* p; float* g; };
@@ -476,6 +540,7 @@ int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in
     float* emu = take(B); float* ers = take(B); float* He = take(B * DH);
     float* geA = take(B * d); float* geB = take(B * d); float* geC = take(B * d); float* dHe = take(B * DH);
     float* bs = take(B * 52); float* outb = take(B * 52); float* dz = take(B * 52);
+    float* tfac = take(B * 52); float* txp = take(B * 52);
     float* zrows = take(Rq + B); float* grow = take(Rq + B);
     float* Qb = c->tr_q;            // (28, d)
     float* dQb = c->tr_dq;          // (28, d)
@@ -536,7 +601,7 @@ int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in
         t.zrows = zrows; t.h1 = H1; t.he = He; t.w2 = P("blendshape_decoder.3.weight"); t.b2 = P("blendshape_decoder.3.bias");
         t.mel_w = P("mel_weights"); t.emo_w = P("emotion_weights"); t.temperature = c->cfg.temperature; t.target = target;
         t.bs = bs; t.out = outb; t.dz = dz; t.ema_state = ema_state; t.ema_first = ema_first; t.alpha_p = P("smoothing_alpha");
-        t.mse_w = mse_w; t.l1_w = l1_w; t.loss = loss_dev; t.d_melw = Gd("mel_weights"); t.d_emow = Gd("emotion_weights");
+        t.mse_w = mse_w; t.l1_w = l1_w; t.lc = c->tr_loss_cfg; t.fac = tfac; t.xp = txp; t.loss = loss_dev; t.d_melw = Gd("mel_weights"); t.d_emow = Gd("emotion_weights");
         t.d_alpha = Gd("smoothing_alpha"); t.B = (int)B; t.DH = (int)DH;
         hipLaunchKernelGGL(train_tail_kernel, dim3(1), dim3(64), 0, st, t);
         if (out_dev) HIP_TRY(hipMemcpyAsync(out_dev, outb, (size_t)B * 52 * sizeof(float), hipMemcpyDeviceToDevice, st));

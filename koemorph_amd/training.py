@@ -80,6 +80,28 @@ class Trainer:
     def reset_temporal_state(self):
         self._ema_batch = None
 
+    def set_loss_terms(self, perceptual_weight: float = 0.0, temporal_weight: float = 0.0, sparsity_weight: float = 0.0,
+                       smoothness_weight: float = 0.0, landmark_weight: float = 0.0, velocity_weight: float = 0.0,
+                       prev_pred: Optional[torch.Tensor] = None, prev_target: Optional[torch.Tensor] = None,
+                       landmark_weights: Optional[torch.Tensor] = None) -> None:
+        """The remaining terms of the reference's KoeMorphLoss (src/model/losses.py:29-178), added to mse/l1.
+        prev_pred / prev_target (B,52) and landmark_weights (136,52) are device tensors the trainer keeps alive;
+        call with no arguments to switch the extra terms off."""
+        from ._lib import KMLossConfig
+        keep = []
+        def dev(t, shape_tail):
+            if t is None:
+                return None
+            t = t.to(self.device, torch.float32).contiguous()
+            assert tuple(t.shape[-len(shape_tail):]) == shape_tail, (t.shape, shape_tail)
+            keep.append(t)
+            return _ptr(t)
+        cfg = KMLossConfig(perceptual_weight, temporal_weight, sparsity_weight, smoothness_weight, landmark_weight,
+                           velocity_weight, dev(prev_pred, (52,)), dev(prev_target, (52,)), dev(landmark_weights, (136, 52)))
+        self._loss_tensors = keep
+        import ctypes
+        check(self._lib.km_train_set_loss(self._h, ctypes.byref(cfg)))
+
     # ---- one optimisation step ------------------------------------------------------------------
     def _ema_args(self, B):
         if not self.use_smoothing:

@@ -137,6 +137,56 @@ def core_forward_np(params, mel, short, emo, **kw) -> Dict[str, np.ndarray]:
     return {k: v.detach().cpu().numpy() for k, v in o.items()}
 
 
+# perceptual groups and weights of PerceptualBlendshapeLoss (src/model/losses.py:306-330)
+PERCEPTUAL_GROUPS = (("mouth", range(12, 32), 2.0), ("eye", range(0, 12), 1.0), ("brow", range(32, 44), 1.0),
+                     ("jaw", range(44, 52), 1.5))
+
+
+def koemorph_loss(pred, target, mse_weight=1.0, l1_weight=0.1, perceptual_weight=0.5, temporal_weight=0.2,
+                  sparsity_weight=0.01, smoothness_weight=0.1, landmark_weight=0.3, velocity_weight=0.05,
+                  prev_pred=None, prev_target=None, landmark_w=None):
+    """KoeMorphLoss.forward restated (src/model/losses.py:89-178) for audio_features=None: the weighted sum of
+    mse (:113-117), l1 (:119-123), perceptual = group-weighted MSEs (:326-338), temporal (:185-200), velocity
+    (:202-217), sparsity (:219-224), smoothness = total variation along the 52 coefficients (:226-234) and landmark
+    consistency through the fixed (136,52) matrix (:397-412).  Terms whose inputs are missing are skipped, as there."""
+    total = pred.new_zeros(())
+    if mse_weight > 0:
+        total = total + mse_weight * F.mse_loss(pred, target)
+    if l1_weight > 0:
+        total = total + l1_weight * F.l1_loss(pred, target)
+    if perceptual_weight > 0:
+        per = pred.new_zeros(())
+        for _, idx, w in PERCEPTUAL_GROUPS:
+            idx = list(idx)
+            per = per + w * F.mse_loss(pred[:, idx], target[:, idx])
+        total = total + perceptual_weight * per
+    if prev_pred is not None and prev_target is not None:
+        if temporal_weight > 0:
+            total = total + temporal_weight * F.mse_loss(pred - prev_pred, target - prev_target)
+        if velocity_weight > 0:
+            total = total + velocity_weight * F.l1_loss(pred - prev_pred, target - prev_target)
+    if sparsity_weight > 0:
+        total = total + sparsity_weight * pred.abs().mean()
+    if smoothness_weight > 0:
+        total = total + smoothness_weight * torch.diff(pred, dim=1).abs().mean()
+    if landmark_weight > 0 and landmark_w is not None:
+        total = total + landmark_weight * F.mse_loss(pred @ landmark_w.T, target @ landmark_w.T)
+    return total
+
+
+def core_full_loss_and_grads(params, mel, short, emo, target, prev_pred, prev_target, landmark_w, weights=None,
+                             num_heads=8, mel_sequence_length=256, dtype=torch.float32):
+    """Full KoeMorphLoss (defaults of losses.py:36-47 unless `weights` overrides) of the core's prediction and
+    d loss / d param through torch.autograd on the restated forward (eval mode)."""
+    P = {k: _t(v, dtype).clone().requires_grad_(True) for k, v in params.items()}
+    out = core_forward(P, mel, short, emo, num_heads=num_heads, mel_sequence_length=mel_sequence_length, dtype=dtype)
+    loss = koemorph_loss(out["blendshapes"], _t(target, dtype), prev_pred=_t(prev_pred, dtype),
+                         prev_target=_t(prev_target, dtype), landmark_w=_t(landmark_w, dtype), **(weights or {}))
+    loss.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).detach().numpy() for k, v in P.items()}
+    return float(loss.detach()), grads, out["blendshapes"].detach().numpy()
+
+
 def core_loss_and_grads(params, mel, short, emo, target, num_heads=8,
                         mel_sequence_length=256, dtype=torch.float32):
     """MSE(blendshapes, target) and d loss / d param for every state-dict tensor, through

@@ -37,7 +37,16 @@ CASES = [
     dict(name="core_d512_T512_H16", d=512, T=512, H=16, B=2, t_in=513, pstyle="trained", istyle="mel01", seed=22, grads=False),
     dict(name="core_d64_T32_H4_small", d=64, T=32, H=4, B=5, t_in=33, pstyle="trained", istyle="randn", seed=31, grads=True),
     dict(name="core_d256_T256_H8_grads", d=256, T=256, H=8, B=8, t_in=257, pstyle="trained", istyle="mel01", seed=41, grads=True),
+    # full KoeMorphLoss (src/model/losses.py, default weights) with prev tensors and a seeded landmark matrix
+    dict(name="core_d64_T32_H4_fullloss", d=64, T=32, H=4, B=5, t_in=33, pstyle="trained", istyle="randn", seed=51, grads="full"),
+    dict(name="core_d256_T256_H8_fullloss", d=256, T=256, H=8, B=8, t_in=257, pstyle="trained", istyle="mel01", seed=52, grads="full"),
 ]
+
+
+def full_loss_inputs(synth, seed, B):
+    """target, prev_pred, prev_target (B,52) in [0,1] and the landmark matrix (136,52) ~ N(0, 0.01^2), all seeded."""
+    return (synth.uniform(seed * 3 + 1, (B, 52), 0.0, 1.0), synth.uniform(seed * 3 + 2, (B, 52), 0.0, 1.0),
+            synth.uniform(seed * 3 + 3, (B, 52), 0.0, 1.0), (0.01 * synth.normal(seed * 3 + 4, (136, 52))).astype(np.float32))
 
 
 def main():
@@ -52,6 +61,8 @@ def main():
     for c in CASES:
         params = synth.make_core_params(c["seed"], c["d"], c["T"], 256, c["pstyle"])
         mel, short, emo = synth.make_core_inputs(c["seed"], c["B"], c["t_in"], style=c["istyle"])
+        if os.environ.get("KM_GOLDEN_ONLY") and os.environ["KM_GOLDEN_ONLY"] not in c["name"]:
+            continue
         m = DualStreamCrossAttention(d_model=c["d"], num_heads=c["H"], mel_sequence_length=c["T"]).eval()
         m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
         with torch.no_grad():
@@ -66,10 +77,21 @@ def main():
             "emotion_blendshapes": o["emotion_blendshapes"].numpy(),
         }
         if c["grads"]:
-            target = synth.uniform(c["seed"] * 3 + 1, (c["B"], 52), 0.0, 1.0)
             m.zero_grad()
             out = m(torch.from_numpy(mel), torch.from_numpy(short), torch.from_numpy(emo))["blendshapes"]
-            loss = torch.nn.functional.mse_loss(out, torch.from_numpy(target))
+            if c["grads"] == "full":
+                from src.model.losses import KoeMorphLoss  # reference, read-only
+                target, prev_pred, prev_target, lw = full_loss_inputs(synth, c["seed"], c["B"])
+                crit = KoeMorphLoss()
+                with torch.no_grad():
+                    crit.landmark_loss.bs_to_landmark_weights.copy_(torch.from_numpy(lw))
+                loss, metrics = crit(out, torch.from_numpy(target), prev_pred=torch.from_numpy(prev_pred),
+                                     prev_target=torch.from_numpy(prev_target))
+                for mk in ("mse", "l1", "perceptual", "temporal", "velocity", "sparsity", "smoothness", "landmark"):
+                    rec["metric/" + mk] = np.float64(metrics[mk])
+            else:
+                target = synth.uniform(c["seed"] * 3 + 1, (c["B"], 52), 0.0, 1.0)
+                loss = torch.nn.functional.mse_loss(out, torch.from_numpy(target))
             loss.backward()
             rec["loss"] = np.float64(loss.item())
             for k, p in m.named_parameters():

@@ -41,6 +41,28 @@ def golden_case(name):
     return c, params, inputs, g
 
 
+def full_loss_inputs(seed, B):
+    """target, prev_pred, prev_target, landmark matrix of the full-KoeMorphLoss fixtures (oracle/gen_golden.py)."""
+    import numpy as np
+    from koemorph_amd import synth
+    return (synth.uniform(seed * 3 + 1, (B, 52), 0.0, 1.0), synth.uniform(seed * 3 + 2, (B, 52), 0.0, 1.0),
+            synth.uniform(seed * 3 + 3, (B, 52), 0.0, 1.0), (0.01 * synth.normal(seed * 3 + 4, (136, 52))).astype(np.float32))
+
+
+def assert_grads_match(grads, g, tol):
+    """grads vs a golden record holding grad/<key> (small tensors) or gradsample/<key> + gradnorm/<key>."""
+    import numpy as np
+    for k, v in grads.items():
+        if "grad/" + k in g:
+            ref = g["grad/" + k]
+            np.testing.assert_allclose(v, ref, atol=1e-7 + tol * np.abs(ref).max(), rtol=tol, err_msg=k)
+        else:
+            ref = g["gradsample/" + k]
+            np.testing.assert_allclose(v.ravel()[::97], ref, atol=1e-7 + tol * np.abs(ref).max(), rtol=tol, err_msg=k)
+            n = np.sqrt(np.sum(v.astype(np.float64) ** 2))
+            assert abs(n - float(g["gradnorm/" + k])) <= tol * float(g["gradnorm/" + k]) + 1e-9, k
+
+
 CORE_CASES_D256 = [
     "core_d256_T256_H8_init", "core_d256_T256_H8_trained", "core_d256_T256_H8_randn",
     "core_d256_pad_T100", "core_d256_trunc_T300", "core_d256_rt_T255",

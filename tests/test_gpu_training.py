@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_case
+from conftest import assert_grads_match, full_loss_inputs, golden_case
 from koemorph_amd import synth
 from koemorph_amd.engine import Engine
 from koemorph_amd.training import Trainer, cosine_warm_restarts_lr
@@ -43,6 +43,26 @@ def test_gradients_match_reference_autograd(name):
             np.testing.assert_allclose(v.ravel()[::97], ref, atol=1e-7 + 2e-4 * np.abs(ref).max(), rtol=2e-4, err_msg=k)
             n = np.sqrt(np.sum(v.astype(np.float64) ** 2))
             assert abs(n - float(g["gradnorm/" + k])) <= 2e-4 * float(g["gradnorm/" + k]) + 1e-9, k
+
+
+@pytest.mark.parametrize("name", ["core_d64_T32_H4_fullloss", "core_d256_T256_H8_fullloss"])
+def test_full_koemorph_loss_gradients_match_reference(name):
+    """All eight KoeMorphLoss terms (src/model/losses.py, default weights) in the HIP loss tail: loss value and the
+    gradient of every parameter against the reference's own KoeMorphLoss + autograd (golden fixtures)."""
+    c, params, (mel, short, emo), g = golden_case(name)
+    target, prev_pred, prev_target, lw = full_loss_inputs(c["seed"], c["B"])
+    e, tr = make(params, c, mse_weight=1.0, l1_weight=0.1)
+    tr.set_loss_terms(perceptual_weight=0.5, temporal_weight=0.2, sparsity_weight=0.01, smoothness_weight=0.1,
+                      landmark_weight=0.3, velocity_weight=0.05, prev_pred=dev(prev_pred), prev_target=dev(prev_target),
+                      landmark_weights=dev(lw))
+    loss = tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target))
+    assert abs(float(loss.item()) - float(g["loss"])) < 2e-6 * max(1.0, abs(float(g["loss"])))
+    assert_grads_match(tr.grads({k: v.shape for k, v in params.items()}), g, 2e-4)
+    # switching the extra terms off restores the plain mse + l1 loss
+    tr.set_loss_terms()
+    l2 = float(tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target)).item())
+    want = float(g["metric/mse"]) + 0.1 * float(g["metric/l1"])
+    assert abs(l2 - want) < 2e-6 * max(1.0, want)
 
 
 def test_training_loop_matches_torch_adamw_with_ema_and_l1():

@@ -59,3 +59,26 @@ def test_oracle_gradients_match_reference_autograd(name):
             np.testing.assert_allclose(v.ravel()[::97], ref, atol=1e-7 + 1e-4 * np.abs(ref).max(), rtol=1e-4)
             n = np.sqrt(np.sum(v.astype(np.float64) ** 2))
             assert abs(n - float(g["gradnorm/" + k])) <= 1e-4 * float(g["gradnorm/" + k]) + 1e-9
+
+
+@pytest.mark.parametrize("name", ["core_d64_T32_H4_fullloss", "core_d256_T256_H8_fullloss"])
+def test_oracle_full_koemorph_loss_matches_reference(name):
+    """The restated KoeMorphLoss (all eight terms, default weights) and its gradients through the restated core against
+    the reference's KoeMorphLoss + DualStreamCrossAttention autograd (fixtures from oracle/gen_golden.py)."""
+    from conftest import assert_grads_match, full_loss_inputs
+    c, params, (mel, short, emo), g = golden_case(name)
+    target, prev_pred, prev_target, lw = full_loss_inputs(c["seed"], c["B"])
+    loss, grads, out = core.core_full_loss_and_grads(params, mel, short, emo, target, prev_pred, prev_target, lw,
+                                                     num_heads=c["H"], mel_sequence_length=c["T"])
+    assert abs(loss - float(g["loss"])) < 1e-6 * max(1.0, abs(float(g["loss"])))
+    assert_grads_match(grads, g, 1e-4)
+    # every term, one at a time, against the reference's metrics dict
+    import torch
+    P, T = torch.from_numpy(out), torch.from_numpy(target)
+    kw = dict(mse_weight=0, l1_weight=0, perceptual_weight=0, temporal_weight=0, sparsity_weight=0, smoothness_weight=0,
+              landmark_weight=0, velocity_weight=0)
+    for term in ("mse", "l1", "perceptual", "temporal", "velocity", "sparsity", "smoothness", "landmark"):
+        k2 = dict(kw); k2[term + "_weight"] = 1.0
+        v = float(core.koemorph_loss(P, T, prev_pred=torch.from_numpy(prev_pred), prev_target=torch.from_numpy(prev_target),
+                                     landmark_w=torch.from_numpy(lw), **k2))
+        assert abs(v - float(g["metric/" + term])) <= 2e-6 * max(1.0, abs(float(g["metric/" + term]))), term
