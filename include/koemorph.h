@@ -190,7 +190,11 @@ int km_pipeline_flush(km_handle h, void* stream);
  * window with stride_frames over each clip, one output frame per position, EMA reset at the
  * clip start.  audio_dev (B, L) -> out_dev (B, N, 52), N = km_sequence_num_outputs().
  * Windows are addressed in place inside the clip (no (B*N, window) copy is materialised) and processed
- * in tiles of the reserved workspace size; every window's STFT is recomputed, as the reference does. */
+ * in tiles of the reserved workspace size.  The reference recomputes every window's STFT; here, because windows
+ * start at multiples of the hop, the clip's STFT is computed ONCE ((N-1)*stride + T+1 frames) plus the two
+ * zero-padded boundary frames of each window, and the core reads rows from both images -- bit-identical to the
+ * per-window evaluation (KM_SEQ_PER_WINDOW=1 selects that for comparison).  This entry point may allocate (grow-only
+ * clip-level buffers sized B*L) on first use, so capture it in a hipGraph only after a warm-up call. */
 int64_t km_sequence_num_outputs(km_handle h, int64_t L, int32_t stride_frames);
 int km_sequence_forward(km_handle h, const float* audio_dev, int64_t B, int64_t L,
                         const float* emotion_dev, int32_t stride_frames, int32_t smooth,

@@ -1,6 +1,8 @@
 // C-ABI entry points that touch the device (declared in include/koemorph.h).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <cstring>
 #include <vector>
 
@@ -112,6 +114,8 @@ int km_destroy(km_handle h) {
     (void)free_streams(c);
     (void)free_train(c);
     (void)free_pipeline(c);
+    for (void* q : {(void*)c->seq_pow, (void*)c->seq_fmax, (void*)c->seq_edge, (void*)c->seq_emax})
+        if (q) (void)hipFree(q);
     if (c->pipe_s1) {
         (void)hipStreamDestroy((hipStream_t)c->pipe_s1); (void)hipStreamDestroy((hipStream_t)c->pipe_s2);
         for (int i = 0; i < 2; ++i) {
@@ -622,6 +626,48 @@ int km_sequence_forward(km_handle h, const float* audio_dev, int64_t B, int64_t 
     // emotion features ONCE for the entire audio (:88): one logit per clip
     if (int rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, stream)) return rc;
     const int64_t total = B * N, tile = c->ws_windows;
+    // Shared-frame path.  Windows start at multiples of the hop (:101-117), so frame f of window i IS clip frame
+    // i*stride + f for f = 1 .. T-1; only frame 0 and frame T see the zero padding at the window boundary.  The STFT
+    // of the clip is computed once (N-1)*stride + T + 1 frames instead of N * (T+1)), the two edge frames per window
+    // separately, and the core reads its rows from both images.  Results are bit-identical to the per-window path.
+    const bool dedup = std::getenv("KM_SEQ_PER_WINDOW") == nullptr;       // read per call: tests compare both paths
+    if (c->fused_ok && dedup && c->cfg.mel.n_fft == 1024 && std::getenv("KM_MEL_TWO_FRAME") == nullptr && N < (1 << 24)) {
+        hipStream_t st = (hipStream_t)stream;
+        const int64_t nfc = (N - 1) * stride_frames + n_frames;                 // clip frames any window touches
+        if (B * nfc > c->seq_pow_cap) {                                           // grow-only; may allocate (not capturable)
+            if (c->seq_pow) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(c->seq_pow)); HIP_TRY(hipFree(c->seq_fmax)); }
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->seq_pow), (size_t)B * nfc * c->NK * sizeof(float)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->seq_fmax), (size_t)B * nfc * sizeof(unsigned)));
+            c->seq_pow_cap = B * nfc;
+        }
+        if (total > c->seq_edge_cap) {
+            if (c->seq_edge) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(c->seq_edge)); HIP_TRY(hipFree(c->seq_emax)); }
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->seq_edge), (size_t)total * 2 * c->NK * sizeof(float)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->seq_emax), (size_t)total * 2 * sizeof(unsigned)));
+            c->seq_edge_cap = total;
+        }
+        HIP_TRY(hipMemsetAsync(c->seq_fmax, 0, (size_t)B * nfc * sizeof(unsigned), st));
+        HIP_TRY(hipMemsetAsync(c->seq_emax, 0, (size_t)total * 2 * sizeof(unsigned), st));
+        // (1) every clip as one long "window" of nfc frames, zero beyond the clip end
+        SeqFrames clip_img{c->seq_pow, c->seq_fmax, nfc, 1};
+        if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, (nfc - 1) * hop, stream, L, 0, 0, 1, nullptr, nullptr,
+                                      nullptr, nullptr, &clip_img)) return rc;
+        // (2) the first and last frame of every window (rows 0 and 1 = frames 0 and T of the window)
+        SeqFrames edge_img{c->seq_edge, c->seq_emax, 2, (int)(n_frames - 1)};
+        if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, total, W, stream, L, step, 0, (int)N, nullptr, nullptr,
+                                      nullptr, nullptr, &edge_img)) return rc;
+        // (3) per tile: window maxima, then the fused core reading rows from both images
+        SeqCore sc{c->seq_pow, c->seq_edge, (int)nfc, (int)stride_frames, (int)N};
+        for (int64_t w0 = 0; w0 < total; w0 += tile) {
+            const int64_t nw = (total - w0) < tile ? (total - w0) : tile;
+            if (int rc = launch_seq_window_max(c, c->seq_fmax, c->seq_emax, nw, w0, (int)nfc, (int)stride_frames, (int)N,
+                                               (int)n_frames, stream)) return rc;
+            if (int rc = launch_core_fused_db(c, c->mel_plans[0], nw, n_frames, c->ws_zemo, out_dev + w0 * c->NB, nullptr, 1,
+                                              stream, w0, (int)N, 0, nullptr, nullptr, &sc)) return rc;
+        }
+        if (smooth) return launch_ema_scan(c, out_dev, B, N, stream);
+        return KM_OK;
+    }
     for (int64_t w0 = 0; w0 < total; w0 += tile) {
         const int64_t nw = (total - w0) < tile ? (total - w0) : tile;
         if (c->fused_ok) {

@@ -99,6 +99,9 @@ struct Context {
     int* tr_steps = nullptr;         // device-side AdamW step counters (graph replay safe)
     bool tr_alpha_live = false;      // smoothing_alpha was in the last step's graph (see adamw_kernel)
     km_loss_config tr_loss_cfg{};    // extra KoeMorphLoss terms (all weights 0 = off)
+    // shared-frame sequence mode buffers (grow-only, allocated by km_sequence_forward)
+    float* seq_pow = nullptr; unsigned* seq_fmax = nullptr; float* seq_edge = nullptr; unsigned* seq_emax = nullptr;
+    int64_t seq_pow_cap = 0, seq_edge_cap = 0;
     int64_t tr_alpha_steps = 0;
     bool stage_timing = false;
     void* stage_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // hipEvent_t: emo b/e, mel e, core b/e
@@ -125,9 +128,18 @@ int launch_core_fused(Context* c, const float* mel, int64_t B, int64_t T_in, con
                       const float* zemo, float* out, float* raw, float* attn, float* state, int first,
                       void* stream);
 // fused variant: reads the workspace power-mel + window maxima, applies the log/dB conversion on load
+// Shared-frame sequence mode, core side (see CoreArgs in km_core.hip)
+struct SeqCore {
+    const float* pow;     // (clips, nfc, 80) clip-level power-mel
+    const float* edge;    // (clips * n_per_clip, 2, 80) first / last frame of every window
+    int nfc, stride, n_per_clip;
+};
 int launch_core_fused_db(Context* c, MelPlan* p, int64_t B, int64_t n_frames, const float* zemo, float* out,
                          float* state, int first, void* stream, int64_t win0 = 0, int zemo_div = 1, int64_t n_use = 0,
-                         const unsigned char* ready = nullptr, unsigned char* started = nullptr);
+                         const unsigned char* ready = nullptr, unsigned char* started = nullptr,
+                         const struct SeqCore* seq = nullptr);
+int launch_seq_window_max(Context* c, const unsigned* fmax, const unsigned* emax, int64_t nw, int64_t win0, int nfc, int stride,
+                          int n_per_clip, int n_frames, void* stream);
 int launch_ema_scan(Context* c, float* x, int64_t B, int64_t N, void* stream);
 int launch_smooth(Context* c, float* x, float* state, int64_t B, int first, void* stream);
 
@@ -149,10 +161,18 @@ int launch_core_generic(Context* c, const float* mel, int64_t B, int64_t T_in, c
                         float* out, float* raw, float* attn, void* stream);
 
 // km_mel.hip
+// Shared-frame sequence mode: the front end writes n_rows rows per window (row r = STFT frame r * frame_mul) into
+// `pow` and the per-row maxima (float bits, zero-initialised by the caller) into `fmax`, instead of the workspace.
+struct SeqFrames {
+    float* pow;        // (B, n_rows, n_mels)
+    unsigned* fmax;    // (B, n_rows)
+    int64_t n_rows;
+    int frame_mul;
+};
 int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, void* stream,
                      int64_t clip_len = 0, int64_t win_step = 0, int64_t win0 = 0, int wins_per_clip = 1,
                      const int* ring_start = nullptr, const unsigned char* ready = nullptr,
-                     const float* emotion = nullptr, float* zemo = nullptr);
+                     const float* emotion = nullptr, float* zemo = nullptr, const SeqFrames* seq = nullptr);
 bool mel_fuses_emotion(Context* c, MelPlan* p);
 int launch_ring_push(Context* c, const float* samples, int64_t n_per_stream, void* stream);
 int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, int64_t out_frames,

@@ -77,6 +77,11 @@ struct CoreArgs {
     // streaming mode: frames kept by the truncate / repeat-last policy (255 of 256, mel_sliding_window.py:300-307),
     // per-stream readiness (ring full) and per-stream 'EMA started' flags
     int n_use;
+    // shared-frame sequence mode: frames 1 .. n_frames-2 of window (clip, i) are rows i*seq_stride + fr of the clip's
+    // power-mel image, frames 0 and n_frames-1 (zero-padded at the window boundary) come from seq_edge (2 rows/window)
+    const float* seq_pow;    // (clips, seq_nfc, 80) or null
+    const float* seq_edge;   // (clips * seq_n, 2, 80)
+    int seq_nfc, seq_stride, seq_n;
     const unsigned char* ready;   // (B) or null: windows with ready[b] == 0 are skipped entirely
     unsigned char* started;       // (B) or null: first = !started[b], then started[b] = 1
 };
@@ -128,6 +133,16 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
         const int U = a.n_use;             // rows kept: truncated, or padded by repeating the last frame
         const int tv = U < T ? U : T;
         const float4* src = reinterpret_cast<const float4*>(a.melpow + (int64_t)b * F * NK);
+        const float4 *seq_rows = nullptr, *seq_e = nullptr;
+        if (a.seq_pow) {
+            const int64_t gw = a.win0 + b, clip = gw / a.seq_n, wi = gw - clip * a.seq_n;
+            seq_rows = reinterpret_cast<const float4*>(a.seq_pow + (clip * a.seq_nfc + wi * a.seq_stride) * NK);
+            seq_e = reinterpret_cast<const float4*>(a.seq_edge + gw * 2 * NK);
+        }
+        auto row4 = [&](int fr) -> const float4* {     // the 20 float4 of power-mel row fr of this window
+            if (!seq_rows) return src + fr * 20;
+            return fr == 0 ? seq_e : (fr == F - 1 ? seq_e + 20 : seq_rows + fr * 20);
+        };
         float4* dst = reinterpret_cast<float4*>(R1);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         // all T*20/NT = 10 row loads of a thread (and the short-row load) are in flight before the first conversion
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
             int fr = i / 20;
             const int c4 = i - fr * 20;
             fr = fr < F ? fr : F - 1;
-            xv[u] = i < tv * 20 ? src[fr * 20 + c4] : z4;
+            xv[u] = i < tv * 20 ? row4(fr)[c4] : z4;
         }
         float4 sv = z4;
         bool s_ok = false;
@@ -150,7 +165,7 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
             if (U >= 3) fr = U - 3 + r; else if (r < U) fr = r;
             if (fr >= F) fr = F - 1;
             s_ok = fr >= 0;
-            if (s_ok) sv = src[fr * 20 + (tid - r * 20)];
+            if (s_ok) sv = row4(fr)[tid - r * 20];
         }
         auto convert = [&](auto mode) {          // the conversion mode is uniform: one branch, not one per value
             constexpr int MODE = decltype(mode)::value;
@@ -763,9 +778,33 @@ int launch_core_fused(Context* c, const float* mel, int64_t B, int64_t T_in, con
 
 LogParams plan_log_params(MelPlan* p);
 
+// per-window maximum for the shared-frame sequence mode: max over the window's rows of the per-frame maxima
+// (one wave per window; values are float bits of non-negative numbers, so unsigned max == float max)
+__global__ __launch_bounds__(64) void seq_window_max_kernel(const unsigned* __restrict__ fmax, const unsigned* __restrict__ emax,
+                                                            unsigned* __restrict__ melmax, int64_t win0, int nfc, int stride,
+                                                            int n_per_clip, int n_frames) {
+    const int64_t gw = win0 + blockIdx.x, clip = gw / n_per_clip, wi = gw - clip * n_per_clip;
+    const unsigned* f = fmax + clip * nfc + wi * stride;
+    unsigned m = 0;
+    for (int r = 1 + threadIdx.x; r < n_frames - 1; r += 64) m = max(m, f[r]);
+    if (threadIdx.x < 2) m = max(m, emax[gw * 2 + threadIdx.x]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if (threadIdx.x == 0) melmax[blockIdx.x] = m;
+}
+
+int launch_seq_window_max(Context* c, const unsigned* fmax, const unsigned* emax, int64_t nw, int64_t win0, int nfc, int stride,
+                          int n_per_clip, int n_frames, void* stream) {
+    hipLaunchKernelGGL(seq_window_max_kernel, dim3((unsigned)nw), dim3(64), 0, (hipStream_t)stream, fmax, emax, c->ws_melmax,
+                       win0, nfc, stride, n_per_clip, n_frames);
+    HIP_TRY(hipGetLastError());
+    c->melmax_dirty = false;     // every slot the following core launch reads was just written (and is re-zeroed by it)
+    return KM_OK;
+}
+
 int launch_core_fused_db(Context* c, MelPlan* p, int64_t B, int64_t n_frames, const float* zemo, float* out,
                          float* state, int first, void* stream, int64_t win0, int zemo_div, int64_t n_use,
-                         const unsigned char* ready, unsigned char* started) {
+                         const unsigned char* ready, unsigned char* started, const SeqCore* seq) {
     if (int rc = core_attrs()) return rc;
     CoreArgs a{};
     core_weights(c, a);
@@ -773,6 +812,7 @@ int launch_core_fused_db(Context* c, MelPlan* p, int64_t B, int64_t n_frames, co
     a.out = out; a.state = state; a.first = first; a.win0 = win0; a.zemo_div = zemo_div > 0 ? zemo_div : 1;
     a.melpow = c->ws_melpow; a.melmax = c->ws_melmax; a.n_frames = (int)n_frames; a.lp = plan_log_params(p);
     a.n_use = (int)(n_use > 0 ? n_use : n_frames); a.ready = ready; a.started = started;
+    if (seq) { a.seq_pow = seq->pow; a.seq_edge = seq->edge; a.seq_nfc = seq->nfc; a.seq_stride = seq->stride; a.seq_n = seq->n_per_clip; }
     hipLaunchKernelGGL((core_fused_kernel<false, true>), dim3((unsigned)B), dim3(fused::NT), fused::LDS_BYTES, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return KM_OK;

@@ -120,6 +120,10 @@ struct MelArgs {
     float* melpow;        // (B, n_frames, n_mels)
     unsigned* melmax;     // (B) float bits, zero-initialised
     EmoArgs emo;          // optional: the window's emotion logit, computed by the last workgroup of each window
+    // shared-frame sequence mode (km_sequence_forward): output row r of a window is STFT frame r * frame_mul, and the
+    // maxima go per row into frame_max[(window, row)] instead of per window into melmax
+    int frame_mul;
+    unsigned* frame_max;  // (B, n_frames) float bits, zero-initialised, or null
 };
 
 // raw samples of the frame pair (fa, fa+1) into z[i] = (x_a[lane + 64 i], x_b[lane + 64 i]); wave-uniform fa
@@ -582,7 +586,8 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
     // it every workgroup stalls on HBM latency after each barrier: the kernel is latency bound, not VALU bound.
     v2f zn[8];
     bool zn_ok = false;                                                  // wave-uniform: zn holds the next frame
-    if (blockIdx.x * FPB + wave < a.n_frames) zn_ok = load_frame_rp_fast<RING>(x, Lv, rs, a.hop, blockIdx.x * FPB + wave, lane, zn);
+    const int fmul = a.frame_mul;
+    if (blockIdx.x * FPB + wave < a.n_frames) zn_ok = load_frame_rp_fast<RING>(x, Lv, rs, a.hop, (blockIdx.x * FPB + wave) * fmul, lane, zn);
     for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const int f0 = chunk * FPB;
 #pragma unroll 1
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
             const int f = f0 + fl;
             if (f < a.n_frames) {   // wave-uniform
                 if (!zn_ok) {       // edge frame (padding / ring wrap): 2 of 257 in the batch shape
-                    load_frame_rp_slow(x, Lv, rs, RING ? 1 : 0, a.hop, a.pad_mode == KM_PAD_REFLECT ? 1 : 0, f, lane,
+                    load_frame_rp_slow(x, Lv, rs, RING ? 1 : 0, a.hop, a.pad_mode == KM_PAD_REFLECT ? 1 : 0, f * fmul, lane,
                                        reinterpret_cast<float2*>(buf));
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -609,7 +614,7 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
                 __builtin_amdgcn_wave_barrier();
                 {
                     const int fnext = pi + 1 < FPB / WAVES ? f + WAVES : (chunk + (int)gridDim.x) * FPB + wave;
-                    zn_ok = fnext < a.n_frames && load_frame_rp_fast<RING>(x, Lv, rs, a.hop, fnext, lane, zn);
+                    zn_ok = fnext < a.n_frames && load_frame_rp_fast<RING>(x, Lv, rs, a.hop, fnext * fmul, lane, zn);
                 }
                 // ---- pass 2: radix-8 over n1 (lane = 8 n1 + n2); this lane: n2 = lane & 7, k0 = lane >> 3 ----
                 v2f y[8];
@@ -663,7 +668,7 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
             float* dst = a.melpow + ((int64_t)b * a.n_frames + f0 + flm) * a.n_mels + wave;
             // After the quad reduction all four phase lanes of a frame hold the filter's sum: phase p keeps the results of
             // filters j = p (mod 4) and one store per four filters writes them (4 x fewer, fuller store instructions).
-            float keep = 0.f;
+            float keep = 0.f, fmx = 0.f;
             for (int j = 0; j < n_my; ++j) {
                 const int desc = __builtin_amdgcn_readlane(my_desc, j);
                 const int trips = (desc >> 10) & 63;
@@ -680,12 +685,15 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
                 r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
                 r = fvalid ? r : 0.f;
                 asm("v_max_f32 %0, %0, %1" : "+v"(vmax) : "v"(r));
+                asm("v_max_f32 %0, %0, %1" : "+v"(fmx) : "v"(r));
                 keep = ph == (j & 3) ? r : keep;
                 if ((j & 3) == 3 || j == n_my - 1) {                                   // wave-uniform
                     const int jm = (j & ~3) + ph;
                     if (fvalid && jm < n_my) dst[WAVES * jm] = keep;
                 }
             }
+            if (a.frame_max && ph == 0 && fvalid)                         // this wave's filters of frame f0 + flm
+                atomicMax(a.frame_max + (int64_t)b * a.n_frames + f0 + flm, __float_as_uint(fmx));
         }
         __syncthreads();                                                 // the power rows are free again
     }
@@ -693,7 +701,7 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
     if (lane == 0) redmax[wave] = vmax;
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && !a.frame_max) {
         float mx = redmax[0];
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) mx = fmaxf(mx, redmax[w]);
@@ -792,14 +800,16 @@ bool mel_fuses_emotion(Context* c, MelPlan* p) {
 
 int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, void* stream,
                      int64_t clip_len, int64_t win_step, int64_t win0, int wins_per_clip, const int* ring_start,
-                     const unsigned char* ready, const float* emotion, float* zemo) {
+                     const unsigned char* ready, const float* emotion, float* zemo, const SeqFrames* seq) {
     const km_mel_config& m = p->cfg;
-    const int64_t n_frames = 1 + L / m.hop_length;
+    const int64_t n_frames = seq ? seq->n_rows : 1 + L / m.hop_length;
     if (m.pad_mode == KM_PAD_REFLECT && L <= m.n_fft / 2)
         return fail(KM_ERR_INVALID_ARG, "reflect padding needs more than n_fft/2 = %d samples (got %lld)", m.n_fft / 2, (long long)L);
-    if (B > c->ws_windows || n_frames > c->ws_frames)
+    if (!seq && (B > c->ws_windows || n_frames > c->ws_frames))
         return fail(KM_ERR_WORKSPACE, "workspace holds %lld windows x %lld frames, need %lld x %lld: call km_reserve",
                     (long long)c->ws_windows, (long long)c->ws_frames, (long long)B, (long long)n_frames);
+    if (seq && !(m.n_fft == 1024 && std::getenv("KM_MEL_TWO_FRAME") == nullptr))
+        return fail(KM_ERR_UNSUPPORTED, "shared-frame sequence mode needs the 1024-point front end");
     if (!p->uploaded) return fail(KM_ERR_NOT_FINALIZED, "mel plan not uploaded (km_finalize / km_reserve first)");
     static bool attr_set = false;
     if (!attr_set) {
@@ -820,7 +830,7 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     hipStream_t st = (hipStream_t)stream;
     // ws_melmax is all-zero on entry unless a previous non-fused call left its maxima behind
     // (the fused core kernel re-zeroes the entry it consumes)
-    if (c->melmax_dirty) {
+    if (!seq && c->melmax_dirty) {
         HIP_TRY(hipMemsetAsync(c->ws_melmax, 0, (size_t)c->ws_windows * sizeof(unsigned), st));
         c->melmax_dirty = false;
     }
@@ -833,6 +843,8 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     a.fb_nnz = (int)p->fb_weight.size();
     a.fb4_desc = p->d_fb4_desc; a.fb4_weight = p->d_fb4_weight; a.fb4_nnz = (int)p->fb4_weight.size();
     a.melpow = c->ws_melpow; a.melmax = c->ws_melmax;
+    a.frame_mul = 1; a.frame_max = nullptr;
+    if (seq) { a.melpow = seq->pow; a.frame_max = seq->fmax; a.frame_mul = seq->frame_mul; a.melmax = nullptr; }
     if (emotion) {
         if (!mel_fuses_emotion(c, p) || !zemo || wins_per_clip > 1)
             return fail(KM_ERR_UNSUPPORTED, "launch_mel_power: emotion fusion requested for an unsupported configuration");

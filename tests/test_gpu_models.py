@@ -110,6 +110,27 @@ def test_sequence_tiling_is_invisible():
     assert a.shape == (3, 21, 52) and torch.equal(a, b)
 
 
+@pytest.mark.parametrize("extra_hops,stride,clips", [(20, 1, 3), (33, 3, 2), (-40, 1, 2), (0, 1, 1)])
+def test_shared_frame_sequence_path_is_bit_identical_to_per_window(extra_hops, stride, clips):
+    """km_sequence_forward computes the clip's STFT once and the two boundary frames of every window separately;
+    the per-window evaluation (the reference's schedule, KM_SEQ_PER_WINDOW=1) must give the same bits."""
+    import os
+    params = synth.make_core_params(54, style="trained")
+    audio = dev(synth.make_audio(94, clips, 136448 + 533 * extra_hops + 77))
+    emo = dev(synth.normal(95, (clips, 256)))
+    m = DualStreamCrossAttention().cuda().eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    eng = m.engine()
+    shared = eng.sequence_forward(audio, emo, stride, True, max_tile=16)
+    os.environ["KM_SEQ_PER_WINDOW"] = "1"
+    try:
+        per_window = eng.sequence_forward(audio, emo, stride, True, max_tile=16)
+    finally:
+        del os.environ["KM_SEQ_PER_WINDOW"]
+    assert shared.shape[0] == clips and shared.shape[2] == 52
+    assert torch.equal(shared, per_window)
+
+
 def test_mel_spectrogram_extractor_mirror():
     ex = MelSpectrogramExtractor().cuda()
     assert ex.hop_length == 533 and ex.get_output_length(16000) == 31
