@@ -314,6 +314,18 @@ int km_stage_times(km_handle h, float* ms3);
  * length in floats via *n when out == NULL. */
 int km_debug_buffer(km_handle h, const char* name, float* out, int64_t* n);
 
+/* ---- wire encoding (host only, no GPU) -----------------------------------------------------------------
+ * Byte-identical replacement for the per-frame json.dumps of the reference's output side (scripts/rt.py:209-231:
+ * UDP datagrams and JSONL lines; src/data/io.py:119-131: dataset labels):
+ *     {"timestamp": <float>, "blendshapes": [<n_values floats>]}
+ * frames_host (n_frames, n_values) fp32 on the host, timestamps (n_frames) as time.time() doubles; floats are printed as
+ * CPython prints ndarray.tolist() values (shortest round-trip repr of the float32 widened to double, 'Infinity' /
+ * 'NaN' as json.dumps spells them).  Frame f occupies out[offsets[f] .. offsets[f+1]) (offsets has n_frames + 1 entries,
+ * may be NULL); newline != 0 appends '\n' to every frame (JSONL).  Returns the number of bytes written, or a negative
+ * number -(n) when `capacity` is too small (n bytes are certainly enough), or KM_ERR_INVALID_ARG. */
+int64_t km_format_frames(const float* frames_host, int64_t n_frames, int32_t n_values, const double* timestamps,
+                         int32_t newline, char* out, int64_t capacity, int64_t* offsets);
+
 #ifdef __cplusplus
 }
 #endif

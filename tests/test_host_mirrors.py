@@ -104,3 +104,37 @@ def test_cli_flags_match_reference():
             "--host", "--port", "--output_file", "--device", "--duration", "--no_audio"} <= flags
     with pytest.raises(SystemExit):
         p.parse_args([])                                              # --model_path is required
+
+
+def test_streamer_batch_is_byte_identical_to_per_frame_json_dumps(tmp_path):
+    """A tick of many streams encoded by one C call: the same bytes the reference's per-frame json.dumps produces,
+    over UDP (one datagram per stream, optional per-stream ports) and as JSONL."""
+    frames = synth.uniform(6, (16, 52), 0, 0.03)
+    want = [json.dumps({"timestamp": 99.25, "blendshapes": r.tolist()}) for r in frames]
+    p = tmp_path / "tick.jsonl"
+    s = rt.BlendshapeStreamer("file", output_file=str(p))
+    s.send_batch(frames, 99.25); s.close()
+    assert p.read_text() == "".join(w + "\n" for w in want)
+    rx = [socket.socket(socket.AF_INET, socket.SOCK_DGRAM) for _ in range(2)]
+    for r in rx:
+        r.bind(("127.0.0.1", 0)); r.settimeout(2.0)
+    u = rt.BlendshapeStreamer("udp", port=rx[0].getsockname()[1])
+    u.send_batch(frames[:3], 99.25)
+    assert [rx[0].recv(65536).decode() for _ in range(3)] == want[:3]
+    u.send_batch(frames[:2], 99.25, ports=[r.getsockname()[1] for r in rx])
+    assert rx[0].recv(65536).decode() == want[0] and rx[1].recv(65536).decode() == want[1]
+    u.close()
+    for r in rx:
+        r.close()
+
+
+def test_audio_file_reader_and_readme_flags(tmp_path):
+    from scipy.io import wavfile
+    x = (synth.uniform(7, (2500,), -0.5, 0.5) * 32767).astype(np.int16)
+    wavfile.write(tmp_path / "a.wav", 16000, x)
+    chunks = list(rt.AudioFileReader(str(tmp_path / "a.wav"), 16000, 1024))
+    assert len(chunks) == 3 and all(c.shape == (1024,) and c.dtype == np.float32 for c in chunks)
+    np.testing.assert_allclose(np.concatenate(chunks)[:2500], x.astype(np.float32) / 32768.0)
+    assert not np.concatenate(chunks)[2500:].any()                      # last chunk zero padded (rt_simplified.py:134-136)
+    a = rt.build_parser().parse_args(["--model_path", "m.pt", "--input_audio", "a.wav", "--output_json", "o.jsonl"])
+    assert a.input_audio == "a.wav" and a.output_json == "o.jsonl"      # README.md:128-131
