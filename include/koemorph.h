@@ -314,6 +314,22 @@ int km_stage_times(km_handle h, float* ms3);
  * length in floats via *n when out == NULL. */
 int km_debug_buffer(km_handle h, const char* name, float* out, int64_t* n);
 
+/* ---- window producer for sequence training -------------------------------------------------------------
+ * Replaces the per-window host slicing + H2D copies of KoeMorphSequentialDataset (src/data/sequential_dataset.py:
+ * 136-209) for clips and labels resident in HBM.
+ *   km_resample_labels  labels recorded at another frame rate -> target rate, exactly as _resample_blendshapes
+ *                       (:136-154): dst[t,k] = float32(np.interp(np.linspace(0, n_src-1, n_dst)[t], arange(n_src),
+ *                       src[:,k])) evaluated in float64 like numpy (bit-identical); n_dst = int(n_src * target/source)
+ *                       is the caller's (host) computation
+ *   km_gather_windows   window b starts at frame start_frames[b]: audio_out (B, window_samples) =
+ *                       clip[start*hop : +window_samples] (zero beyond the clip), labels_out (B, window_frames, dims) =
+ *                       labels[start : +window_frames] (:181-188), target_out (B, dims) = the label of the window's
+ *                       last frame; any of the three outputs may be NULL */
+int km_resample_labels(const float* src_dev, int64_t n_src, int32_t dims, int64_t n_dst, float* dst_dev, void* stream);
+int km_gather_windows(const float* clip_dev, int64_t clip_len, const int32_t* start_frames_dev, int64_t B, int32_t hop,
+                      int64_t window_samples, float* audio_out_dev, const float* labels_dev, int64_t n_label_frames,
+                      int32_t window_frames, int32_t dims, float* labels_out_dev, float* target_out_dev, void* stream);
+
 /* ---- wire encoding (host only, no GPU) -----------------------------------------------------------------
  * Byte-identical replacement for the per-frame json.dumps of the reference's output side (scripts/rt.py:209-231:
  * UDP datagrams and JSONL lines; src/data/io.py:119-131: dataset labels):

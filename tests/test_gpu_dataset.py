@@ -1,0 +1,88 @@
+"""Device-side window producer against the restated reference pipeline in oracle/dataset.py (numpy's own
+linspace / interp, i.e. the library the reference calls): bit-exact labels and windows."""
+import json
+
+import numpy as np
+import pytest
+import torch
+from scipy.io import wavfile
+
+from koemorph_amd import synth
+from koemorph_amd.data import SequentialKoeMorphDataset, detect_source_fps
+from oracle import dataset as od
+
+pytestmark = pytest.mark.gpu
+
+
+def write_pair(d, name, seconds, label_fps, seed, extra_label_frames=0):
+    n = int(seconds * 16000)
+    audio = synth.uniform(seed, (n,), -0.5, 0.5).astype(np.float32)
+    wavfile.write(d / f"{name}.wav", 16000, audio)
+    F = int(seconds * label_fps) + extra_label_frames
+    labels = synth.uniform(seed + 1, (F, 52), 0, 1).astype(np.float32)
+    with open(d / f"{name}.jsonl", "w") as f:
+        for i in range(F):
+            f.write(json.dumps({"timestamp": i / label_fps, "blendshapes": labels[i].tolist()}) + "\n")
+    return audio, labels
+
+
+@pytest.mark.parametrize("n_src,n_dst", [(600, 300), (601, 300), (2, 7), (1, 3), (977, 488), (300, 600)])
+def test_label_resampling_is_bit_identical_to_numpy(n_src, n_dst, tmp_path):
+    write_pair(tmp_path, "x", 9.0, 30, 1)
+    ds = SequentialKoeMorphDataset(tmp_path, shuffle_files=False, loop_dataset=False)
+    src = synth.uniform(3 + n_src, (n_src, 52), 0, 1).astype(np.float32)
+    ratio = n_dst / n_src
+    ds.target_fps = 30.0
+    source_fps = 30.0 / ratio
+    want = od.resample_blendshapes(src, source_fps, 30.0)
+    got = ds.resample_labels(torch.from_numpy(src).cuda(), source_fps).cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_windows_match_reference_pipeline(tmp_path):
+    """Two clips: 30 fps labels (aligned) and 60 fps labels with a frame-count mismatch (resampling + truncation)."""
+    a0, l0 = write_pair(tmp_path, "a_first", 9.3, 30, 10)
+    a1, l1 = write_pair(tmp_path, "b_second", 9.0, 60, 20, extra_label_frames=9)
+    ds = SequentialKoeMorphDataset(tmp_path, stride_frames=3, shuffle_files=False, loop_dataset=False, batch_size=5)
+    assert ds.hop_length == 533 and ds.window_samples == 136448 and [p[0].stem for p in ds.file_pairs] == ["a_first", "b_second"]
+    assert detect_source_fps([i / 60 for i in range(50)]) == 60.0 and detect_source_fps([0.0]) == 30.0
+    ref = []
+    for fi, (a, l, fps) in enumerate([(a0, l0, 30.0), (a1, l1, 60.0)]):
+        lab = od.resample_blendshapes(l, fps, 30)
+        # the int16 WAV round trip quantises the audio: compare against what the file holds
+        a = wavfile.read(tmp_path / (["a_first", "b_second"][fi] + ".wav"))[1].astype(np.float32)
+        for i, sf, aw, bw in od.windows(a, lab, 256, 3, 533):
+            ref.append((fi, i, sf, aw, bw))
+    got = []
+    for batch in ds:
+        B = batch["audio"].shape[0]
+        assert B <= 5 and batch["blendshapes"].shape == (B, 256, 52) and batch["target"].shape == (B, 52)
+        for b in range(B):
+            got.append((int(batch["file_indices"][b]), int(batch["window_indices"][b]), int(batch["start_frames"][b]),
+                        batch["audio"][b].cpu().numpy(), batch["blendshapes"][b].cpu().numpy(), batch["target"][b].cpu().numpy(),
+                        batch["file_names"][b]))
+    assert len(got) == len(ref) == ds.get_num_windows() and len(ref) > 10
+    for g, r in zip(got, ref):
+        assert g[:3] == r[:3]
+        assert np.array_equal(g[3], r[3]) and np.array_equal(g[4], r[4]) and np.array_equal(g[5], r[4][-1])
+    assert got[0][6] == "a_first" and got[-1][6] == "b_second"
+
+
+def test_float_wav_is_kept_exact_and_feeds_the_train_step(tmp_path):
+    from koemorph_amd.engine import Engine
+    from koemorph_amd.training import Trainer
+    audio = synth.uniform(30, (int(9.0 * 16000),), -0.5, 0.5).astype(np.float32)
+    wavfile.write(tmp_path / "c.wav", 16000, audio)
+    labels = synth.uniform(31, (270, 52), 0, 1).astype(np.float32)
+    with open(tmp_path / "c.jsonl", "w") as f:
+        for i in range(270):
+            f.write(json.dumps({"timestamp": i / 30.0, "blendshapes": labels[i].tolist()}) + "\n")
+    ds = SequentialKoeMorphDataset(tmp_path, shuffle_files=False, loop_dataset=False, batch_size=4)
+    batch = next(iter(ds))
+    assert np.array_equal(batch["audio"][1].cpu().numpy(), audio[533:533 + 136448])
+    eng = Engine(); eng.load_state_dict(synth.make_core_params(0)); eng.finalize(); eng.reserve(4, 136448)
+    tr = Trainer(eng, max_windows=4)
+    emo = torch.from_numpy(synth.normal(32, (4, 256))).cuda()
+    l0 = float(tr.step(batch["audio"], emo, batch["target"]).item())
+    l1 = float(tr.step(batch["audio"], emo, batch["target"]).item())
+    assert np.isfinite(l0) and np.isfinite(l1) and l1 < l0          # one optimisation step on a device-made batch

@@ -138,3 +138,25 @@ def test_audio_file_reader_and_readme_flags(tmp_path):
     assert not np.concatenate(chunks)[2500:].any()                      # last chunk zero padded (rt_simplified.py:134-136)
     a = rt.build_parser().parse_args(["--model_path", "m.pt", "--input_audio", "a.wav", "--output_json", "o.jsonl"])
     assert a.input_audio == "a.wav" and a.output_json == "o.jsonl"      # README.md:128-131
+
+
+def test_dataset_host_helpers_and_oracle_windows(tmp_path):
+    """Host-side pieces of the sequential dataset mirror (the window producer itself is a GPU test)."""
+    from koemorph_amd.data import SequentialKoeMorphDataset, detect_source_fps, load_jsonl_labels
+    from oracle import dataset as od
+    labels = synth.uniform(8, (40, 52), 0, 1)
+    with open(tmp_path / "l.jsonl", "w") as f:
+        for i, row in enumerate(labels):
+            f.write(json.dumps({"timestamp": i / 60.0, "blendshapes": row.tolist()}) + "\n")
+    rows, ts = load_jsonl_labels(tmp_path / "l.jsonl")
+    assert rows.dtype == np.float32 and np.array_equal(rows, labels) and detect_source_fps(ts) == 60.0
+    assert detect_source_fps([0.0, 1 / 29.0, 2 / 29.0]) == 30.0 and detect_source_fps([]) == 30.0
+    assert abs(detect_source_fps([0.0, 0.04, 0.08]) - 25.0) < 1e-9             # non-standard rates are kept
+    r = od.resample_blendshapes(labels, 60.0, 30)
+    assert r.shape == (20, 52) and np.array_equal(r[0], labels[0]) and np.array_equal(r[-1], labels[-1])
+    a = np.arange(300 * 533 + 17, dtype=np.float32)
+    b = synth.uniform(9, (304, 52), 0, 1)                                       # 4 frames more than the audio has
+    w = list(od.windows(a, b, 256, 10, 533))
+    assert [x[0] for x in w] == [0, 1, 2, 3, 4] and w[4][1] == 40 and w[4][2][0] == 40 * 533 and len(w[4][2]) == 136448
+    with pytest.raises(RuntimeError):
+        SequentialKoeMorphDataset(tmp_path, device="cpu")                       # clips live in HBM: no CPU fallback
