@@ -157,6 +157,9 @@ int64_t legacy_ws_floats(Context* c, int64_t frames);
 int finalize_host_legacy(Context* c);
 int launch_legacy(Context* c, const float* mel, int64_t B, int64_t T_mel, float* out, void* stream);
 int launch_gather_clip_logits(Context* c, const float* zclip, float* zwin, int64_t nw, int64_t w0, int wins_per_clip, void* stream);
+int launch_core_generic_packed(Context* c, const float* xp, int64_t B, const float* zemo, float* out, float* raw, float* attn,
+                               void* stream);
+float* generic_packed_x(Context* c, int64_t B);
 int launch_core_generic(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short, const float* zemo,
                         float* out, float* raw, float* attn, void* stream);
 
@@ -178,6 +181,7 @@ int launch_ring_push(Context* c, const float* samples, int64_t n_per_stream, voi
 int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, int64_t out_frames,
                float* mel_long, float* mel_short, void* stream, int64_t clip_len = 0, int64_t win_step = 0,
                int64_t win0 = 0, int wins_per_clip = 1);
+int launch_mel_packed(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, float* xp, int T, int KP, void* stream);
 int upload_mel_plan(MelPlan* p);
 void free_mel_plan(MelPlan* p);
 

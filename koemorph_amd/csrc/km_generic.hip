@@ -21,6 +21,9 @@
 // (= 16 banks mod 32, so the two k rows of a ds_read_b32 half-wave are conflict free).
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+#include <cstdlib>
+
 #include "km_context.h"
 #include "km_device.h"
 #include "km_gemm.h"
@@ -133,7 +136,148 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
 int launch_softmax_rows(float* x, int64_t rows, int w, void* stream);
 
+// ---------------------------------------------------------------------------------------------------------
+// gemm_nt_kernel: the fast path for C = alpha A B^T (+ bias[n], ReLU, + beta C) when BOTH operands are K-contiguous
+// (A row-major M x K, B stored N x K like an nn.Linear weight), K a multiple of 16 and rows 16-byte aligned -- every
+// large product of the generic inference chain.  128 x (32 NT) tile per 256 threads, 2 x 2 waves, each wave 64 x (16 NT):
+// 4 x NT accumulators, BK = 16.
+//   * LDS layout [k / 4][row][k % 4]: a lane's fragment for FOUR consecutive MFMAs is one ds_read_b128 (lane group g
+//     contracts k = 4 g + s in MFMA s: any partition of the 16 k into 4 MFMAs is valid as long as A and B agree), and
+//     the 16 lanes of a b128 beat always hold 16 different rows = all 64 banks: (4 + NT) reads per 16 NT MFMAs
+//     instead of one ds_read_b32 per MFMA.
+//   * global -> LDS: one float4 along k per ds_write_b128, no transposition; consecutive lanes take consecutive rows
+//     (conflict-free stores).  Register-staged double buffer: the next tile's loads fly under the current MFMAs, one
+//     barrier per k tile.
+// ---------------------------------------------------------------------------------------------------------
+namespace gnt {
+constexpr int BM = 128, BK = 16;
+}
+
+// out-of-range rows read row 0 (valid memory) and are zeroed by value: the loads stay unconditional
+template <int E>
+__device__ __forceinline__ void nt_stage(const float* const (&p)[E], const bool (&ok)[E], int k0, float4 (&r)[E]) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const float4 v = *reinterpret_cast<const float4*>(p[e] + k0);
+        r[e] = ok[e] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int E>
+__device__ __forceinline__ void nt_commit(float* dst, int tid, const float4 (&r)[E]) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) *reinterpret_cast<float4*>(dst + (tid + 256 * e) * 4) = r[e];
+}
+
+template <int NT>   // 16-column MFMA tiles per wave: 4 -> BN 128, 2 -> BN 64
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
+    using namespace gnt;
+    constexpr int BN = 32 * NT;
+    __shared__ __attribute__((aligned(16))) float As[2][4 * BM * 4];
+    __shared__ __attribute__((aligned(16))) float Bs[2][4 * BN * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lg = lane >> 4, lj = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int z1 = blockIdx.z / g.batch2, z2 = blockIdx.z - z1 * g.batch2;
+    const float* A = g.A + z1 * g.a_bs1 + z2 * g.a_bs2;
+    const float* Bp = g.B + z1 * g.b_bs1 + z2 * g.b_bs2;
+    float* C = g.C + z1 * g.c_bs1 + z2 * g.c_bs2;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    // staging map: element e of this thread is row (tid + 256 e) & (rows - 1), k group (tid + 256 e) / rows
+    constexpr int EA = BM * 4 / 256, EB = BN * 4 / 256;
+    static_assert(EA >= 1 && EB >= 1, "tile too small for 256 threads");
+    const float* ap[EA];
+    const float* bp[EB];
+    bool aok[EA], bok[EB];
+#pragma unroll
+    for (int e = 0; e < EA; ++e) {
+        const int idx = tid + 256 * e, m = idx & (BM - 1), kg = idx / BM;
+        aok[e] = m0 + m < g.M;
+        ap[e] = A + (int64_t)(aok[e] ? m0 + m : 0) * g.a_rs + 4 * kg;
+    }
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+        const int idx = tid + 256 * e, n = idx & (BN - 1), kg = idx / BN;
+        bok[e] = n0 + n < g.N;
+        bp[e] = Bp + (int64_t)(bok[e] ? n0 + n : 0) * g.b_cs + 4 * kg;
+    }
+    float4 ra[EA], rb[EB];
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn) acc[i][jn] = f32x4{0, 0, 0, 0};
+
+    const int kt = g.K / BK;
+    nt_stage<EA>(ap, aok, 0, ra);
+    nt_stage<EB>(bp, bok, 0, rb);
+    nt_commit<EA>(As[0], tid, ra);
+    nt_commit<EB>(Bs[0], tid, rb);
+    __syncthreads();
+    for (int it = 0; it < kt; ++it) {
+        const int buf = it & 1;
+        const int knext = (it + 1 < kt ? it + 1 : it) * BK;      // last iteration: a harmless reload of the current tile
+        nt_stage<EA>(ap, aok, knext, ra);
+        nt_stage<EB>(bp, bok, knext, rb);
+        const float* as = As[buf];
+        const float* bs = Bs[buf];
+        f32x4 af[4], bf[NT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + (lg * BM + 64 * wm + 16 * i + lj) * 4);
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn) bf[jn] = *reinterpret_cast<const f32x4*>(bs + (lg * BN + 16 * NT * wn + 16 * jn + lj) * 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jn = 0; jn < NT; ++jn) acc[i][jn] = KM_MFMA(af[i][s], bf[jn][s], acc[i][jn]);
+        // the other buffer: its last readers passed the previous barrier (after the last tile: written, never read)
+        nt_commit<EA>(As[buf ^ 1], tid, ra);
+        nt_commit<EB>(Bs[buf ^ 1], tid, rb);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 64 * wm + 16 * i + 4 * lg + r, n = n0 + 16 * NT * wn + 16 * jn + lj;
+                if (m < g.M && n < g.N) {
+                    float v = g.alpha * acc[i][jn][r];
+                    if (g.bias_mode == 1) v += g.bias[n];
+                    else if (g.bias_mode == 2) v += g.bias[m];
+                    float* cp = C + (int64_t)m * g.c_rs + n;
+                    if (g.beta != 0.f) v += g.beta * (*cp);
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    *cp = v;
+                }
+            }
+}
+
+static bool gemm_nt_ok(const GemmArgs& g) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return g.a_cs == 1 && g.b_rs == 1 && g.K >= 16 && g.K % 16 == 0 && g.kb_count <= 1 && g.M >= 64 && al(g.A) && al(g.B) &&
+           g.a_rs % 4 == 0 && g.b_cs % 4 == 0 && g.a_bs1 % 4 == 0 && g.a_bs2 % 4 == 0 && g.b_bs1 % 4 == 0 && g.b_bs2 % 4 == 0;
+}
+
 int launch_gemm(const GemmArgs& g, int batch, void* stream) {
+    static const bool fast = std::getenv("KM_GEMM_GENERIC_ONLY") == nullptr;
+    // the 128-row tiles only pay off when they still fill the chip (training-sized products stay on 64 x 64 tiles)
+    const int64_t nt_wgs = (int64_t)batch * ((g.M + 127) / 128) * (g.N > 64 ? (g.N + 127) / 128 : 1);
+    if (fast && gemm_nt_ok(g) && nt_wgs >= 192) {
+        if (g.N > 64) {
+            const dim3 grid((unsigned)((g.N + 127) / 128), (unsigned)((g.M + gnt::BM - 1) / gnt::BM), (unsigned)batch);
+            hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, g);
+        } else {
+            const dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + gnt::BM - 1) / gnt::BM), (unsigned)batch);
+            hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g);
+        }
+        HIP_TRY(hipGetLastError());
+        return KM_OK;
+    }
     const dim3 grid((unsigned)((g.N + gg::BN - 1) / gg::BN), (unsigned)((g.M + gg::BM - 1) / gg::BM), (unsigned)batch);
     hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
     HIP_TRY(hipGetLastError());
@@ -269,18 +413,125 @@ static const float* dv(Context* c, const char* name) { return c->packed.at(name)
 // workspace floats per window for the generic forward
 int64_t generic_ws_floats(Context* c) {
     const int64_t d = c->d, H = c->H, NKk = c->NK;
-    return 2 * NKk * d /* Y, V */ + H * 28 * NKk /* S */ + 28 * d /* O */ + 28 * (d / 2) /* Hd */;
+    const int64_t KP = (c->KT + 15) / 16 * 16;
+    return 2 * NKk * d /* Y, V */ + H * 28 * NKk /* S */ + 28 * d /* O */ + 28 * (d / 2) /* Hd */ + KP * NKk /* packed X */;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// encoder_tn_kernel: Y_b (80 x d) = Xp_b^T Wce_pad^T + b for the packed input image Xp (B, KP, 80) that the
+// front end writes (rows = frames: T long rows, 3 short-term rows, zero rows up to KP = multiple of 16) and the
+// zero-padded weight (d, KP).  A is k-major (a frame's 80 channels are contiguous): a thread loads a 4 x 4 block
+// (4 frames x 4 channels) and stores its transpose as four ds_write_b128 into the [k/4][row][k%4] layout of
+// gemm_nt_kernel; the 80 rows are exactly 5 MFMA tiles, so nothing is padded (a 64- or 128-row tile wastes 37 %).
+// 80 x 128 tile per 256 threads, wave w owns columns 32 w .. +31: 10 accumulators, 7 ds_read_b128 per 40 MFMAs.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void encoder_tn_kernel(const float* __restrict__ xp, const float* __restrict__ wpad,
+                                                         const float* __restrict__ bias, float* __restrict__ Y, int d, int KP) {
+    constexpr int NKc = 80, BN = 128;
+    __shared__ __attribute__((aligned(16))) float As[2][4 * NKc * 4];
+    __shared__ __attribute__((aligned(16))) float Bs[2][4 * BN * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lg = lane >> 4, lj = lane & 15;
+    const int b = blockIdx.y, n0 = blockIdx.x * BN;
+    const float* X = xp + (int64_t)b * KP * NKc;
+    // A staging: threads 0..79 -> (k group, channel quad); B staging: two (row, k group) float4 per thread
+    const bool a_thr = tid < 80;
+    const int akg = tid / 20, am4 = tid - akg * 20;
+    const float* apt = X + (int64_t)(4 * akg) * NKc + 4 * am4;
+    const float* bpt[2];
+    bool bok[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int idx = tid + 256 * e, n = idx & (BN - 1), kg = idx >> 7;
+        bok[e] = n0 + n < d;
+        bpt[e] = wpad + (int64_t)(bok[e] ? n0 + n : 0) * KP + 4 * kg;
+    }
+    float4 ra[4], rb[2];
+    auto stage = [&](int k0, float4 (&a4)[4], float4 (&b2)[2]) {
+        if (a_thr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(apt + (int64_t)(k0 + i) * NKc);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float4 v = *reinterpret_cast<const float4*>(bpt[e] + k0);
+            b2[e] = bok[e] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&](int buf, const float4 (&a4)[4], const float4 (&b2)[2]) {
+        if (a_thr) {   // transpose the 4 x 4 block: row (channel 4 am4 + j) gets the 4 frames of k group akg
+            float* dst = &As[buf][(akg * NKc + 4 * am4) * 4];
+            *reinterpret_cast<float4*>(dst + 0) = make_float4(a4[0].x, a4[1].x, a4[2].x, a4[3].x);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(a4[0].y, a4[1].y, a4[2].y, a4[3].y);
+            *reinterpret_cast<float4*>(dst + 8) = make_float4(a4[0].z, a4[1].z, a4[2].z, a4[3].z);
+            *reinterpret_cast<float4*>(dst + 12) = make_float4(a4[0].w, a4[1].w, a4[2].w, a4[3].w);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) *reinterpret_cast<float4*>(&Bs[buf][(tid + 256 * e) * 4]) = b2[e];
+    };
+    f32x4 acc[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { acc[i][0] = f32x4{0, 0, 0, 0}; acc[i][1] = f32x4{0, 0, 0, 0}; }
+    const int kt = KP / 16;
+    stage(0, ra, rb);
+    commit(0, ra, rb);
+    __syncthreads();
+    for (int it = 0; it < kt; ++it) {
+        const int buf = it & 1;
+        stage((it + 1 < kt ? it + 1 : it) * 16, ra, rb);
+        f32x4 af[5], bf[2];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[buf][(lg * NKc + 16 * i + lj) * 4]);
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) bf[jn] = *reinterpret_cast<const f32x4*>(&Bs[buf][(lg * BN + 32 * wave + 16 * jn + lj) * 4]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                acc[i][0] = KM_MFMA(af[i][s], bf[0][s], acc[i][0]);
+                acc[i][1] = KM_MFMA(af[i][s], bf[1][s], acc[i][1]);
+            }
+        commit(buf ^ 1, ra, rb);
+        __syncthreads();
+    }
+    float* Yb = Y + (int64_t)b * NKc * d;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const int n = n0 + 32 * wave + 16 * jn + lj;
+            if (n < d) {
+                const float bb = bias[n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Yb[(int64_t)(16 * i + 4 * lg + r) * d + n] = acc[i][jn][r] + bb;
+            }
+        }
+}
+
+static int core_generic_after_encoder(Context* c, int64_t B, const float* zemo, float* out, float* raw, float* attn, void* stream);
+
+// the generic core fed by the packed image of the front end (km_forward_audio on generic shapes)
+int launch_core_generic_packed(Context* c, const float* xp, int64_t B, const float* zemo, float* out, float* raw, float* attn,
+                               void* stream) {
+    const int d = c->d, NKk = c->NK, KP = (c->KT + 15) / 16 * 16;
+    if (NKk != 80) return fail(KM_ERR_UNSUPPORTED, "packed encoder path needs 80 mel channels");
+    float* Y = c->ws_generic;
+    hipLaunchKernelGGL(encoder_tn_kernel, dim3((unsigned)((d + 127) / 128), (unsigned)B), dim3(256), 0, (hipStream_t)stream, xp,
+                       dv(c, "wce_pad"), dv(c, "bce"), Y, d, KP);
+    HIP_TRY(hipGetLastError());
+    return core_generic_after_encoder(c, B, zemo, out, raw, attn, stream);
+}
+
+float* generic_packed_x(Context* c, int64_t B) {     // the packed-X slot behind the other intermediates of B windows
+    const int64_t d = c->d, H = c->H, NKk = c->NK;
+    return c->ws_generic + B * (2 * NKk * d + H * 28 * NKk + 28 * d + 28 * (d / 2));
 }
 
 int launch_core_generic(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short, const float* zemo,
                         float* out, float* raw, float* attn, void* stream) {
-    const int d = c->d, H = c->H, hd = c->hd, T = c->T, KT = c->KT, DH = c->DH, NKk = c->NK;
+    const int d = c->d, T = c->T, KT = c->KT, NKk = c->NK;
     if (NKk > 128) return fail(KM_ERR_UNSUPPORTED, "more than 128 mel channels");
     float* Y = c->ws_generic;
-    float* V = Y + B * NKk * d;
-    float* S = V + B * NKk * d;
-    float* O = S + B * H * 28 * NKk;
-    float* Hd = O + B * 28 * d;
     const float* Wce = dv(c, "wce_raw");
     GemmArgs g{};
     g.alpha = 1.f; g.batch2 = 1;
@@ -294,15 +545,27 @@ int launch_core_generic(Context* c, const float* mel, int64_t B, int64_t T_in, c
     // ... plus the 3 short-term rows (:205-208)
     g.A = mel_short; g.a_bs1 = 3 * NKk; g.B = Wce + T; g.K = 3; g.bias_mode = 0; g.beta = 1.f;
     if (int rc = launch_gemm(g, (int)B, stream)) return rc;
+    return core_generic_after_encoder(c, B, zemo, out, raw, attn, stream);
+}
+
+static int core_generic_after_encoder(Context* c, int64_t B, const float* zemo, float* out, float* raw, float* attn, void* stream) {
+    const int d = c->d, H = c->H, hd = c->hd, DH = c->DH, NKk = c->NK;
+    float* Y = c->ws_generic;
+    float* V = Y + B * NKk * d;
+    float* S = V + B * NKk * d;
+    float* O = S + B * H * 28 * NKk;
+    float* Hd = O + B * 28 * d;
+    GemmArgs g{};
     hipLaunchKernelGGL(ln_rows_kernel, dim3((unsigned)((B * NKk + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Y,
                        B * NKk, d, dv(c, "ln_g"), dv(c, "ln_b"), (float*)nullptr, (float*)nullptr);
-    // S[b,h] = Qk_h Y_b^T
-    g = GemmArgs{}; g.alpha = 1.f;
-    g.A = dv(c, "qk"); g.a_rs = d; g.a_cs = 1; g.a_bs1 = 0; g.a_bs2 = (int64_t)28 * d;
-    g.B = Y; g.b_rs = 1; g.b_cs = d; g.b_bs1 = (int64_t)NKk * d; g.b_bs2 = 0;
-    g.C = S; g.c_rs = NKk; g.c_bs1 = (int64_t)H * 28 * NKk; g.c_bs2 = (int64_t)28 * NKk;
-    g.M = 28; g.N = NKk; g.K = d; g.batch2 = H;
-    if (int rc = launch_gemm(g, (int)(B * H), stream)) return rc;
+    // S[b] (H*28 x 80) = Qk (H*28 x d) Y_b^T: all heads of a window in ONE product -- the folded query matrix of every
+    // head spans the full d, so the heads are just row blocks (28-row tiles would waste 56 % of a 64-row MFMA tile)
+    g = GemmArgs{}; g.alpha = 1.f; g.batch2 = 1;
+    g.A = dv(c, "qk"); g.a_rs = d; g.a_cs = 1; g.a_bs1 = 0;
+    g.B = Y; g.b_rs = 1; g.b_cs = d; g.b_bs1 = (int64_t)NKk * d;
+    g.C = S; g.c_rs = NKk; g.c_bs1 = (int64_t)H * 28 * NKk;
+    g.M = H * 28; g.N = NKk; g.K = d;
+    if (int rc = launch_gemm(g, (int)B, stream)) return rc;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((B * H * 28 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S,
                        B * H * 28, NKk);
     if (attn) {
@@ -326,7 +589,7 @@ int launch_core_generic(Context* c, const float* mel, int64_t B, int64_t T_in, c
     // Hd = relu(O Wf + bf)
     g = GemmArgs{}; g.alpha = 1.f; g.batch2 = 1;
     g.A = O; g.a_rs = d; g.a_cs = 1;
-    g.B = dv(c, "wf"); g.b_rs = DH; g.b_cs = 1;
+    g.B = dv(c, "wf_t"); g.b_rs = 1; g.b_cs = d;
     g.C = Hd; g.c_rs = DH; g.M = (int)(B * 28); g.N = DH; g.K = d; g.bias = dv(c, "bf"); g.bias_mode = 1; g.relu = 1;
     if (int rc = launch_gemm(g, 1, stream)) return rc;
     hipLaunchKernelGGL(decoder_tail_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, Hd, DH, dv(c, "w2"),

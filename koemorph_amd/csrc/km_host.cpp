@@ -185,6 +185,15 @@ int finalize_host(Context* c) {
     // ---- plain (unpacked) folded buffers: used by the generic kernels and by the tests ----
     put(c, "qk", to_f(Qk));                                        // (H, 28, d)
     put(c, "wf", to_f(Wf));                                        // (d, DH)
+    put(c, "wf_t", to_f(transpose(Wf, d, DH)));                    // (DH, d): K-contiguous for gemm_nt_kernel
+    {   // channel encoder weight with K padded to a multiple of 16 (zeros): rows stay 16-byte aligned and the long
+        // and short-term columns form ONE contraction for encoder_tn_kernel (km_generic.hip)
+        const int KT = c->KT, KP = (KT + 15) / 16 * 16;
+        const std::vector<float>& w = P(c, "mel_channel_encoder.weight");          // (d, KT)
+        std::vector<float> wp((size_t)d * KP, 0.0f);
+        for (int n = 0; n < d; ++n) std::copy(w.begin() + (size_t)n * KT, w.begin() + (size_t)(n + 1) * KT, wp.begin() + (size_t)n * KP);
+        put(c, "wce_pad", std::move(wp));
+    }
     put(c, "bf", to_f(bf));                                        // (DH)
     put(c, "we2", to_f(We2));                                      // (d, DH)
     put(c, "be2", to_f(bfE));                                      // (DH)

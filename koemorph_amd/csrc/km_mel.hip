@@ -743,6 +743,27 @@ __global__ __launch_bounds__(256) void mel_log_kernel(LogArgs a) {
     }
 }
 
+// Log conversion straight into the packed encoder input of the generic core (km_generic.hip encoder_tn_kernel):
+// xp (B, KP, n_mels) with rows 0 .. T-1 = the first min(n_frames, T) frames (zero rows if the window is shorter,
+// dual_stream_attention.py:193-202), rows T .. T+2 = the last three computed frames
+// (simplified_dual_stream_model.py:205-214), rows up to KP zero.  One pass replaces mel_log_kernel + the K=3 GEMM.
+__global__ __launch_bounds__(256) void mel_log_packed_kernel(LogArgs a, float* __restrict__ xp, int T, int KP) {
+    const int b = blockIdx.y;
+    float ref_db, floor_db;
+    log_window_consts(a.lp, __uint_as_float(a.melmax[b]), ref_db, floor_db);
+    const float* src = a.melpow + (int64_t)b * a.n_frames * a.n_mels;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= KP * a.n_mels) return;
+    const int r = i / a.n_mels, m = i - r * a.n_mels;
+    int f = -1;
+    if (r < T) f = r < a.n_frames ? r : -1;
+    else if (r < T + 3) {
+        const int q = r - T;
+        if (a.n_frames >= 3) f = a.n_frames - 3 + q; else if (q < a.n_frames) f = q;
+    }
+    xp[(int64_t)b * KP * a.n_mels + i] = f >= 0 ? log_one(a.lp, src[f * a.n_mels + m], ref_db, floor_db) : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------
 template <typename Tv>
 static int upload(Tv** dst, const std::vector<Tv>& src) {
@@ -873,6 +894,20 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     else if (m.n_fft == 1024) hipLaunchKernelGGL((mel_power_kernel<1024, true>), grid, dim3(256), lds, st, a);
     else if (!ring_start) hipLaunchKernelGGL((mel_power_kernel<512, false>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((mel_power_kernel<512, true>), grid, dim3(256), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+// front end for the generic core: power-mel, then the packed log-mel image (B, KP, n_mels)
+int launch_mel_packed(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, float* xp, int T, int KP, void* stream) {
+    if (int rc = launch_mel_power(c, p, audio, B, L, stream)) return rc;
+    const km_mel_config& m = p->cfg;
+    c->melmax_dirty = true;
+    LogArgs g;
+    g.melpow = c->ws_melpow; g.melmax = c->ws_melmax; g.n_frames = (int)(1 + L / m.hop_length);
+    g.out_frames = g.n_frames; g.n_mels = m.n_mels; g.lp = log_params(m); g.mel_long = nullptr; g.mel_short = nullptr;
+    const dim3 grid((unsigned)((KP * m.n_mels + 255) / 256), (unsigned)B);
+    hipLaunchKernelGGL(mel_log_packed_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, xp, T, KP);
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }

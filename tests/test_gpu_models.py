@@ -228,6 +228,29 @@ def test_60fps_long_context_configuration_end_to_end():
     assert np.abs(g["blendshapes"].cpu().numpy() - w["blendshapes"]).max() < 5e-6
 
 
+@pytest.mark.parametrize("d,T,H,fps,L", [(512, 512, 16, 60, 512 * 266), (512, 512, 8, 60, 300 * 266 + 5), (64, 32, 4, 30, 33 * 533),
+                                         (64, 32, 4, 30, 2 * 533 + 1)])
+def test_generic_packed_encoder_path_matches_staged_path(d, T, H, fps, L):
+    """km_forward_audio on generic shapes: log-mel written straight into the packed encoder input + encoder_tn_kernel,
+    against the staged path (mel_log_kernel + strided GEMM + K=3 accumulate), incl. windows shorter than T (zero rows)
+    and shorter than 3 frames' worth of context."""
+    import os
+    from koemorph_amd.engine import Engine, MelConfig
+    eng = Engine(d_model=d, num_heads=H, mel_sequence_length=T, mel=MelConfig.model_batch(target_fps=fps))
+    eng.load_state_dict(synth.make_core_params(56, d, T, 256, "trained"))
+    eng.finalize()
+    B = 5
+    eng.reserve(B, L)
+    audio, emo = dev(synth.make_audio(101, B, L)), dev(synth.normal(102, (B, 256)))
+    packed = eng.forward_audio(audio, emo).clone()
+    os.environ["KM_GENERIC_STAGED"] = "1"
+    try:
+        staged = eng.forward_audio(audio, emo).clone()
+    finally:
+        del os.environ["KM_GENERIC_STAGED"]
+    assert packed.shape == (B, 52) and float((packed - staged).abs().max()) < 1e-6
+
+
 def test_legacy_simplified_koemorph_model():
     """the legacy single-stream model (52 queries over 257 encoded mel frames)."""
     from koemorph_amd.model import SimplifiedKoeMorphModel
