@@ -265,9 +265,12 @@ static bool gemm_nt_ok(const GemmArgs& g) {
 
 int launch_gemm(const GemmArgs& g, int batch, void* stream) {
     static const bool fast = std::getenv("KM_GEMM_GENERIC_ONLY") == nullptr;
+#ifndef KM_NT_MIN_WGS
+#define KM_NT_MIN_WGS 192
+#endif
     // the 128-row tiles only pay off when they still fill the chip (training-sized products stay on 64 x 64 tiles)
     const int64_t nt_wgs = (int64_t)batch * ((g.M + 127) / 128) * (g.N > 64 ? (g.N + 127) / 128 : 1);
-    if (fast && gemm_nt_ok(g) && nt_wgs >= 192) {
+    if (fast && gemm_nt_ok(g) && nt_wgs >= KM_NT_MIN_WGS) {
         if (g.N > 64) {
             const dim3 grid((unsigned)((g.N + 127) / 128), (unsigned)((g.M + gnt::BM - 1) / gnt::BM), (unsigned)batch);
             hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, g);
@@ -527,10 +530,33 @@ float* generic_packed_x(Context* c, int64_t B) {     // the packed-X slot behind
     return c->ws_generic + B * (2 * NKk * d + H * 28 * NKk + 28 * d + 28 * (d / 2));
 }
 
+// caller-provided log-mel (B, T_in, 80) + short-term rows (B, 3, 80) -> packed encoder input (B, KP, 80):
+// zero-pad / truncate the time axis to T (dual_stream_attention.py:193-202), then the 3 short rows, then zero rows
+__global__ __launch_bounds__(256) void pack_x_kernel(const float* __restrict__ mel, const float* __restrict__ mel_short, int T_in,
+                                                     int T, int KP, float* __restrict__ xp) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;        // float4 index inside the window's image
+    if (i >= KP * 20) return;
+    const int r = i / 20, c4 = i - r * 20;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < T) { if (r < T_in) v = reinterpret_cast<const float4*>(mel + ((int64_t)b * T_in + r) * 80)[c4]; }
+    else if (r < T + 3) v = reinterpret_cast<const float4*>(mel_short + ((int64_t)b * 3 + (r - T)) * 80)[c4];
+    reinterpret_cast<float4*>(xp + (int64_t)b * KP * 80)[i] = v;
+}
+
 int launch_core_generic(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short, const float* zemo,
                         float* out, float* raw, float* attn, void* stream) {
     const int d = c->d, T = c->T, KT = c->KT, NKk = c->NK;
     if (NKk > 128) return fail(KM_ERR_UNSUPPORTED, "more than 128 mel channels");
+    if (NKk == 80 && std::getenv("KM_GENERIC_STAGED") == nullptr && (reinterpret_cast<uintptr_t>(mel) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(mel_short) & 15) == 0) {
+        const int KP = (KT + 15) / 16 * 16;
+        float* xp = generic_packed_x(c, B);
+        hipLaunchKernelGGL(pack_x_kernel, dim3((unsigned)((KP * 20 + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, mel,
+                           mel_short, (int)T_in, T, KP, xp);
+        HIP_TRY(hipGetLastError());
+        return launch_core_generic_packed(c, xp, B, zemo, out, raw, attn, stream);
+    }
     float* Y = c->ws_generic;
     const float* Wce = dv(c, "wce_raw");
     GemmArgs g{};
