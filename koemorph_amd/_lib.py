@@ -128,6 +128,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     if not os.path.exists(path):
         raise KoeMorphError(KM_ERR_HIP, f"{path} is missing: run `python -m koemorph_amd.build` "
                                         "(there is no CPU fallback)")
+    # The library links the ROCm runtime by SONAME.  PyTorch ships its own copy of that runtime: if ours is loaded
+    # first, the process ends up with two HIP runtimes and the one behind this library cannot open the device
+    # ("no HIP device").  Importing torch first makes both resolve to the same, already loaded runtime.
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
