@@ -111,6 +111,33 @@ def test_end_to_end_from_audio(eng):
         assert err < 5e-6, err
 
 
+def test_full_c2_batch_from_audio_properties(eng):
+    """BASELINE config 2 at full size (256 windows x 136 448 samples) through km_forward_audio: the batch result is
+    independent of how the windows are batched (bit for bit, including the workgroup that also computes the emotion
+    logit), equivariant under a permutation of the windows, the EMA recursion holds across calls, and a sample of
+    windows matches the CPU oracle."""
+    B = 256
+    audio = dev(synth.make_audio(70, B, 136448, "uniform"))
+    emo = dev(synth.normal(71, (B, 256)))
+    eng.reserve(B, 136448)
+    full = eng.forward_audio(audio, emo).clone()
+    assert full.shape == (B, 52) and bool(torch.isfinite(full).all()) and float(full.min()) >= 0.0 and float(full.max()) <= 1.0
+    for lo, hi in ((0, 1), (37, 101), (250, 256)):
+        assert torch.equal(eng.forward_audio(audio[lo:hi].contiguous(), emo[lo:hi].contiguous()), full[lo:hi])
+    perm = torch.from_numpy(np.random.default_rng(0).permutation(B)).cuda()
+    assert torch.equal(eng.forward_audio(audio[perm].contiguous(), emo[perm].contiguous()), full[perm])
+    state = torch.zeros(B, 52, device="cuda")
+    y0 = eng.forward_audio(audio, emo, state=state, first=True).clone()
+    y1 = eng.forward_audio(audio.flip(0).contiguous(), emo.flip(0).contiguous(), state=state, first=False).clone()
+    alpha = 1.0 / (1.0 + np.exp(-0.8))        # smoothing_alpha keeps its init value 0.8 (simplified_dual_stream_model.py:163)
+    want1 = alpha * full.flip(0) + (1.0 - alpha) * full
+    assert torch.equal(y0, full) and float((y1 - want1).abs().max()) < 1e-7
+    pick = [3, 128, 255]
+    orc = models.SimplifiedOracle(synth.make_core_params(7, style="trained"))
+    want = orc.forward(audio[pick].cpu().numpy(), emo[pick].cpu().numpy(), smooth=False)["blendshapes"]
+    assert np.abs(full[pick].cpu().numpy() - want).max() < 5e-6
+
+
 def test_fused_pipeline_is_bit_identical_to_staged_pipeline(eng):
     """km_forward_audio (dB conversion fused into the core kernel's load, window maxima recycled in place)
     must equal km_mel_batch -> km_core_forward bit for bit, also when the two are interleaved."""
