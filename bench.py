@@ -72,6 +72,12 @@ def main():
 
     B, L = args.batch, 136448
     params = synth.make_core_params(0, style="init")
+    if dist is not None:
+        # the library is prebuilt in-tree; should it look stale on this box, let ONE rank rebuild it
+        from koemorph_amd import _lib
+        if rank == 0:
+            _lib.load()
+        dist.barrier()
     eng = Engine()
     eng.load_state_dict(params)
     eng.finalize(dev)
