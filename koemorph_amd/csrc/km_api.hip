@@ -205,6 +205,10 @@ static int free_train(Context* c) {
         if (p) HIP_TRY(hipFree(p));
     c->tr_params = c->tr_m = c->tr_v = c->tr_act = c->tr_q = c->tr_dq = c->tr_part = c->tr_gnorm = c->tr_loss = c->tr_red = nullptr;
     c->tr_steps = nullptr;
+    if (c->tr_red2) { HIP_TRY(hipFree(c->tr_red2)); c->tr_red2 = nullptr; }
+    if (c->tr_s2) { (void)hipStreamDestroy((hipStream_t)c->tr_s2); c->tr_s2 = nullptr; }
+    for (auto& e : c->tr_ev)
+        if (e) { (void)hipEventDestroy((hipEvent_t)e); e = nullptr; }
     c->tr_windows = 0;
     return KM_OK;
 }
@@ -246,6 +250,17 @@ int km_train_init(km_handle h, int64_t max_windows, void* stream) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_gnorm), sizeof(float)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_loss), sizeof(float)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_red), (size_t)32 * 2 * 2 * c->d * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_red2), (size_t)32 * 2 * 2 * c->d * sizeof(float)));
+    {
+        hipStream_t s2;
+        HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        c->tr_s2 = s2;
+        for (auto& e : c->tr_ev) {
+            hipEvent_t ev;
+            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            e = ev;
+        }
+    }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_steps), 2 * sizeof(int)));
     HIP_TRY(hipMemsetAsync(c->tr_steps, 0, 2 * sizeof(int), (hipStream_t)stream));
     c->tr_windows = max_windows;

@@ -99,6 +99,8 @@ struct Context {
     int* tr_steps = nullptr;         // device-side AdamW step counters (graph replay safe)
     bool tr_alpha_live = false;      // smoothing_alpha was in the last step's graph (see adamw_kernel)
     km_loss_config tr_loss_cfg{};    // extra KoeMorphLoss terms (all weights 0 = off)
+    // side stream of the training step (emotion stream + decoder weight gradients run beside the mel chain)
+    void* tr_s2 = nullptr; void* tr_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; float* tr_red2 = nullptr;
     // shared-frame sequence mode buffers (grow-only, allocated by km_sequence_forward)
     float* seq_pow = nullptr; unsigned* seq_fmax = nullptr; float* seq_edge = nullptr; unsigned* seq_emax = nullptr;
     int64_t seq_pow_cap = 0, seq_edge_cap = 0;

@@ -244,10 +244,15 @@ struct TailArgs {
 // dL/dy -- the smoothness and landmark terms need the whole row of y, hence two passes.
 __device__ __forceinline__ float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }   // torch: d|x|/dx = sign(x)
 
-__global__ __launch_bounds__(64) void train_tail_kernel(TailArgs a) {
-    __shared__ float wsum_s[52], wm_s[52], we_s[52], dws_s[52], red[64], e_s[52], u_s[136];
-    const int i = threadIdx.x;
-    if (i == 0) {   // stream weight softmaxes (dual_stream_attention.py:252-253)
+// 8 waves: wave w owns windows w, w + 8, ...; lane i < 52 owns coefficient i (lanes up to 63 help with the landmark
+// products).  Per-thread partial sums run over a wave's windows in order and are combined across waves in wave order,
+// so the result does not depend on timing.
+constexpr int TAIL_NW = 8;
+
+__global__ __launch_bounds__(64 * TAIL_NW) void train_tail_kernel(TailArgs a) {
+    __shared__ float wsum_s[52], wm_s[52], we_s[52], dws_p[TAIL_NW][52], red[TAIL_NW][64], e_s[TAIL_NW][52], u_s[TAIL_NW][136];
+    const int i = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {   // stream weight softmaxes (dual_stream_attention.py:252-253)
         float mm = -INFINITY, me = -INFINITY;
         for (int k = 0; k < 52; ++k) { mm = fmaxf(mm, a.mel_w[k] / a.temperature); me = fmaxf(me, a.emo_w[k] / a.temperature); }
         float sm = 0.f, se = 0.f;
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(64) void train_tail_kernel(TailArgs a) {
     // ---- pass A: y = EMA(clamp(wsum * sigmoid(z))) ----
     if (i < 52) {
         const int slot = tr_mouth_slot(i);
-        for (int b = 0; b < a.B; ++b) {
+        for (int b = w; b < a.B; b += TAIL_NW) {
             const float z = slot >= 0 ? a.zrows[(int64_t)b * 28 + slot] : a.zrows[(int64_t)a.B * 28 + b];
             const float bs = 1.0f / (1.0f + expf(-z));
             const float f = wsum_s[i] * bs;
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(64) void train_tail_kernel(TailArgs a) {
     float pg = 0.f;
     if (i < 52) pg = i < 12 ? 1.0f / 12.f : (i < 32 ? 2.0f / 20.f : (i < 44 ? 1.0f / 12.f : 1.5f / 8.f));
     float loss_acc = 0.f, dws = 0.f, dal = 0.f;
-    for (int b = 0; b < a.B; ++b) {
+    for (int b = w; b < a.B; b += TAIL_NW) {
         float y = 0.f, e = 0.f, dy = 0.f;
         if (i < 52) {
             y = a.out[(int64_t)b * 52 + i];
@@ -305,9 +310,9 @@ __global__ __launch_bounds__(64) void train_tail_kernel(TailArgs a) {
             loss_acc += (a.mse_w * e * e + a.l1_w * fabsf(e)) * inv_n;
             dy = (a.mse_w * 2.0f * e + a.l1_w * sgnf(e)) * inv_n;
             if (lc.perceptual_weight > 0.f) {
-                const float w = lc.perceptual_weight * pg / (float)a.B;
-                loss_acc += w * e * e;
-                dy += w * 2.0f * e;
+                const float wgt = lc.perceptual_weight * pg / (float)a.B;
+                loss_acc += wgt * e * e;
+                dy += wgt * 2.0f * e;
             }
             if (t_on || v_on) {
                 const float dd = (y - lc.prev_pred_dev[(int64_t)b * 52 + i]) -
@@ -317,28 +322,28 @@ __global__ __launch_bounds__(64) void train_tail_kernel(TailArgs a) {
             }
             if (lc.sparsity_weight > 0.f) { loss_acc += lc.sparsity_weight * fabsf(y) * inv_n; dy += lc.sparsity_weight * sgnf(y) * inv_n; }
             if (lc.smoothness_weight > 0.f) {   // torch.diff along the 52 coefficients: 51 pairs per row
-                const float w = lc.smoothness_weight / (float)(a.B * 51);
-                if (i > 0) { const float dl = y - a.out[(int64_t)b * 52 + i - 1]; loss_acc += w * fabsf(dl); dy += w * sgnf(dl); }
-                if (i < 51) { const float dr = a.out[(int64_t)b * 52 + i + 1] - y; dy -= w * sgnf(dr); }
+                const float wgt = lc.smoothness_weight / (float)(a.B * 51);
+                if (i > 0) { const float dl = y - a.out[(int64_t)b * 52 + i - 1]; loss_acc += wgt * fabsf(dl); dy += wgt * sgnf(dl); }
+                if (i < 51) { const float dr = a.out[(int64_t)b * 52 + i + 1] - y; dy -= wgt * sgnf(dr); }
             }
-            e_s[i] = e;
+            e_s[w][i] = e;
         }
-        if (lm_on) {   // u = e W^T (136), loss = mean u^2, dL/de = 2/(B 136) u W
-            __syncthreads();
+        if (lm_on) {   // u = e W^T (136), loss = mean u^2, dL/de = 2/(B 136) u W; only this wave touches e_s[w], u_s[w]
+            __builtin_amdgcn_wave_barrier();
             for (int k = i; k < 136; k += 64) {
                 float u = 0.f;
-                for (int jj = 0; jj < 52; ++jj) u += e_s[jj] * lc.landmark_w_dev[k * 52 + jj];
-                u_s[k] = u;
+                for (int jj = 0; jj < 52; ++jj) u += e_s[w][jj] * lc.landmark_w_dev[k * 52 + jj];
+                u_s[w][k] = u;
             }
-            __syncthreads();
-            const float w = lc.landmark_weight / (float)(a.B * 136);
+            __builtin_amdgcn_wave_barrier();
+            const float wgt = lc.landmark_weight / (float)(a.B * 136);
             if (i < 52) {
                 float gsum = 0.f;
-                for (int k = 0; k < 136; ++k) gsum += u_s[k] * lc.landmark_w_dev[k * 52 + i];
-                dy += w * 2.0f * gsum;
+                for (int k = 0; k < 136; ++k) gsum += u_s[w][k] * lc.landmark_w_dev[k * 52 + i];
+                dy += wgt * 2.0f * gsum;
             }
-            if (i == 0) { float q = 0.f; for (int k = 0; k < 136; ++k) q += u_s[k] * u_s[k]; loss_acc += w * q; }
-            __syncthreads();
+            if (i == 0) { float q = 0.f; for (int k = 0; k < 136; ++k) q += u_s[w][k] * u_s[w][k]; loss_acc += wgt * q; }
+            __builtin_amdgcn_wave_barrier();
         }
         if (i < 52) {
             if (ema_on) dal += dy * a.xp[(int64_t)b * 52 + i] * alpha * (1.0f - alpha);
@@ -348,27 +353,31 @@ __global__ __launch_bounds__(64) void train_tail_kernel(TailArgs a) {
             a.dz[(int64_t)b * 52 + i] = df * wsum_s[i] * bs * (1.0f - bs);
         }
     }
-    if (i < 52) dws_s[i] = dws;
-    red[i] = i < 52 ? loss_acc : 0.f;
+    if (i < 52) dws_p[w][i] = dws;
+    red[w][i] = i < 52 ? loss_acc : 0.f;
     __syncthreads();
-    if (i == 0) {
+    if (threadIdx.x == 0) {
         float s = 0.f;
-        for (int k = 0; k < 52; ++k) s += red[k];
+        for (int ww = 0; ww < TAIL_NW; ++ww)
+            for (int k = 0; k < 52; ++k) s += red[ww][k];
         a.loss[0] = s;
     }
     __syncthreads();
-    red[i] = i < 52 ? dal : 0.f;
+    red[w][i] = i < 52 ? dal : 0.f;
     __syncthreads();
-    if (i == 0) {
+    if (threadIdx.x == 0) {
         float s = 0.f;
-        for (int k = 0; k < 52; ++k) s += red[k];
+        for (int ww = 0; ww < TAIL_NW; ++ww)
+            for (int k = 0; k < 52; ++k) s += red[ww][k];
         a.d_alpha[0] = s;
         // softmax backward for both stream-weight vectors: d w_j = (1/tau) w_j (g_j - sum_k g_k w_k), g = 0.5 dwsum
+        float dws_t[52];
+        for (int k = 0; k < 52; ++k) { float t = 0.f; for (int ww = 0; ww < TAIL_NW; ++ww) t += dws_p[ww][k]; dws_t[k] = t; }
         float dm = 0.f, de = 0.f;
-        for (int k = 0; k < 52; ++k) { dm += 0.5f * dws_s[k] * wm_s[k]; de += 0.5f * dws_s[k] * we_s[k]; }
+        for (int k = 0; k < 52; ++k) { dm += 0.5f * dws_t[k] * wm_s[k]; de += 0.5f * dws_t[k] * we_s[k]; }
         for (int k = 0; k < 52; ++k) {
-            a.d_melw[k] = wm_s[k] * (0.5f * dws_s[k] - dm) / a.temperature;
-            a.d_emow[k] = we_s[k] * (0.5f * dws_s[k] - de) / a.temperature;
+            a.d_melw[k] = wm_s[k] * (0.5f * dws_t[k] - dm) / a.temperature;
+            a.d_emow[k] = we_s[k] * (0.5f * dws_t[k] - de) / a.temperature;
         }
     }
 }
@@ -475,29 +484,32 @@ static int split_of(int64_t rows, int64_t& chunk) {
     return S;
 }
 
-static int colsum(Context* c, const float* m, int64_t rows, int64_t rs, int n, float* out, int accumulate, void* stream) {
+static int colsum(Context* c, const float* m, int64_t rows, int64_t rs, int n, float* out, int accumulate, void* stream,
+                  float* red = nullptr) {
+    if (!red) red = c->tr_red;
     int64_t chunk;
     const int S = split_of(rows, chunk);
     hipStream_t st = (hipStream_t)stream;
     if (S == 1) {
         hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((n + 63) / 64), 1), dim3(256), 0, st, m, rows, rs, n, out, accumulate, chunk);
     } else {
-        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)S), dim3(256), 0, st, m, rows, rs, n, c->tr_red, 0, chunk);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->tr_red, S, n, out, accumulate);
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)S), dim3(256), 0, st, m, rows, rs, n, red, 0, chunk);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, red, S, n, out, accumulate);
     }
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }
 
 static int ln_param_grad(Context* c, const float* dy, const float* x, int64_t rows, int d, const float* mean, const float* rstd,
-                         float* dgam, float* dbet, void* stream) {
+                         float* dgam, float* dbet, void* stream, float* red = nullptr) {
+    if (!red) red = c->tr_red;
     int64_t chunk;
     const int S = split_of(rows, chunk);
     hipStream_t st = (hipStream_t)stream;
     if (S == 1) {
         hipLaunchKernelGGL(ln_param_grad_kernel, dim3((unsigned)((d + 63) / 64), 1), dim3(256), 0, st, dy, x, rows, d, mean, rstd, dgam, dbet, chunk);
     } else {
-        float* pg = c->tr_red; float* pb = c->tr_red + (int64_t)kRedSplit * d;
+        float* pg = red; float* pb = red + (int64_t)kRedSplit * d;
         hipLaunchKernelGGL(ln_param_grad_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)S), dim3(256), 0, st, dy, x, rows, d, mean, rstd, pg, pb, chunk);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, pg, S, d, dgam, 0);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, pb, S, d, dbet, 0);
@@ -512,7 +524,7 @@ int64_t train_act_floats(Context* c) {
     const int64_t d = c->d, H = c->H, NKk = c->NK, DH = c->DH;
     const int64_t R = NKk, Rq = 28;
     return 2 * R * d /* Y0, Y */ + 2 * R /* mean, rstd */ + 2 * R * d /* KV */ + 2 * H * Rq * NKk /* P, dP */ +
-           3 * Rq * d /* A, O1, O2 */ + Rq * DH /* H1 */ + 2 * R * d /* dKV */ + R * d /* dY */ + 2 * Rq * d /* ping-pong grads */ +
+           3 * Rq * d /* A, O1, O2 */ + Rq * DH /* H1 */ + 2 * R * d /* dKV */ + R * d /* dY */ + 3 * Rq * d /* dO2, dO1, dA */ +
            Rq * DH /* dH1 */ + 5 * d /* E0, E, Ve, Oe1, Oe2 */ + 2 /* emo stats */ + DH /* He */ + 3 * d + DH /* emotion grads */ +
            6 * 52 /* bs, out, dz, two loss-tail scratch rows, pad */ + 2 * (Rq + 1) /* zrows, row grads */;
 }
@@ -534,7 +546,7 @@ int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in
     float* Y0 = take(R * d); float* Y = take(R * d); float* mu = take(R); float* rs = take(R);
     float* KV = take(R * 2 * d); float* Pm = take(B * H * 28 * NKk); float* dP = take(B * H * 28 * NKk);
     float* A = take(Rq * d); float* O1 = take(Rq * d); float* O2 = take(Rq * d); float* H1 = take(Rq * DH);
-    float* dKV = take(R * 2 * d); float* dY = take(R * d); float* gA = take(Rq * d); float* gB = take(Rq * d);
+    float* dKV = take(R * 2 * d); float* dY = take(R * d); float* gA = take(Rq * d); float* gB = take(Rq * d); float* gC = take(Rq * d);
     float* dH1 = take(Rq * DH);
     float* E0 = take(B * d); float* E = take(B * d); float* Ve = take(B * d); float* Oe1 = take(B * d); float* Oe2 = take(B * d);
     float* emu = take(B); float* ers = take(B); float* He = take(B * DH);
@@ -551,6 +563,15 @@ int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in
     const float scale = 1.0f / std::sqrt((float)hd);
     const int64_t tv = T_in < T ? T_in : T;
 
+    // Two streams: the emotion stream (forward and backward) and the decoder weight gradients depend on nothing the
+    // mel chain produces in between, so they run on an internal side stream next to it -- one fork and one join per
+    // half of the step (events only: capturable in a hipGraph) take ~25 small launches off the critical path.
+    hipStream_t s2 = (hipStream_t)c->tr_s2;
+    void* stream2 = c->tr_s2;
+    float* red2 = c->tr_red2;
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((c->tr_nparams + 255) / 256)), dim3(256), 0, st, flat_grad, c->tr_nparams);
+    HIP_TRY(hipEventRecord((hipEvent_t)c->tr_ev[0], st));
+    HIP_TRY(hipStreamWaitEvent(s2, (hipEvent_t)c->tr_ev[0], 0));
     // ================= forward (unfolded, dual_stream_attention.py:189-270) =================
     {   // Y0 = X^T Wce^T + b: long rows then the 3 short-term rows
         GemmArgs g = G(mel, 1, NKk, Wce, 1, KT, Y0, d, NKk, d, tv);
@@ -580,30 +601,30 @@ int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in
     RUN(launch_gemm(NT(A, d, P("mel_attention.out_proj.weight"), d, O1, d, Rq, d, P("mel_attention.out_proj.bias"), 0), 1, stream));
     RUN(launch_gemm(NT(O1, d, P("mel_output_proj.weight"), d, O2, d, Rq, d, P("mel_output_proj.bias"), 0), 1, stream));
     RUN(launch_gemm(NT(O2, d, P("blendshape_decoder.0.weight"), d, H1, DH, Rq, DH, P("blendshape_decoder.0.bias"), 1), 1, stream));
-    // emotion stream: one token, softmax == 1 (:216-218, :234-240)
-    RUN(launch_gemm(NT(emo, ED, P("emotion_encoder.weight"), ED, E0, d, B, d, P("emotion_encoder.bias"), 0), 1, stream));
-    hipLaunchKernelGGL(ln_fwd_save_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, E0, E, B, (int)d, P("emotion_norm.weight"),
+    // emotion stream: one token, softmax == 1 (:216-218, :234-240) -- side stream
+    RUN(launch_gemm(NT(emo, ED, P("emotion_encoder.weight"), ED, E0, d, B, d, P("emotion_encoder.bias"), 0), 1, stream2));
+    hipLaunchKernelGGL(ln_fwd_save_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s2, E0, E, B, (int)d, P("emotion_norm.weight"),
                        P("emotion_norm.bias"), emu, ers);
-    RUN(launch_gemm(NT(E, d, einw + 2 * d * d, d, Ve, d, B, d, einb + 2 * d, 0), 1, stream));
-    RUN(launch_gemm(NT(Ve, d, P("emotion_attention.out_proj.weight"), d, Oe1, d, B, d, P("emotion_attention.out_proj.bias"), 0), 1, stream));
-    RUN(launch_gemm(NT(Oe1, d, P("emotion_output_proj.weight"), d, Oe2, d, B, d, P("emotion_output_proj.bias"), 0), 1, stream));
-    RUN(launch_gemm(NT(Oe2, d, P("blendshape_decoder.0.weight"), d, He, DH, B, DH, P("blendshape_decoder.0.bias"), 1), 1, stream));
+    RUN(launch_gemm(NT(E, d, einw + 2 * d * d, d, Ve, d, B, d, einb + 2 * d, 0), 1, stream2));
+    RUN(launch_gemm(NT(Ve, d, P("emotion_attention.out_proj.weight"), d, Oe1, d, B, d, P("emotion_attention.out_proj.bias"), 0), 1, stream2));
+    RUN(launch_gemm(NT(Oe1, d, P("emotion_output_proj.weight"), d, Oe2, d, B, d, P("emotion_output_proj.bias"), 0), 1, stream2));
+    RUN(launch_gemm(NT(Oe2, d, P("blendshape_decoder.0.weight"), d, He, DH, B, DH, P("blendshape_decoder.0.bias"), 1), 1, stream2));
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s2, He, B, (int)DH,
+                       P("blendshape_decoder.3.weight"), P("blendshape_decoder.3.bias"), zrows + Rq);
+    HIP_TRY(hipEventRecord((hipEvent_t)c->tr_ev[1], s2));
+    HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)c->tr_ev[1], 0));
 
     // ================= loss and dL/dz =================
     {
-        const int64_t n = c->tr_nparams;
-        hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flat_grad, n);
         hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((Rq + 3) / 4)), dim3(256), 0, st, H1, Rq, (int)DH,
                            P("blendshape_decoder.3.weight"), P("blendshape_decoder.3.bias"), zrows);
-        hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, He, B, (int)DH,
-                           P("blendshape_decoder.3.weight"), P("blendshape_decoder.3.bias"), zrows + Rq);
         TailArgs t{};
         t.zrows = zrows; t.h1 = H1; t.he = He; t.w2 = P("blendshape_decoder.3.weight"); t.b2 = P("blendshape_decoder.3.bias");
         t.mel_w = P("mel_weights"); t.emo_w = P("emotion_weights"); t.temperature = c->cfg.temperature; t.target = target;
         t.bs = bs; t.out = outb; t.dz = dz; t.ema_state = ema_state; t.ema_first = ema_first; t.alpha_p = P("smoothing_alpha");
         t.mse_w = mse_w; t.l1_w = l1_w; t.lc = c->tr_loss_cfg; t.fac = tfac; t.xp = txp; t.loss = loss_dev; t.d_melw = Gd("mel_weights"); t.d_emow = Gd("emotion_weights");
         t.d_alpha = Gd("smoothing_alpha"); t.B = (int)B; t.DH = (int)DH;
-        hipLaunchKernelGGL(train_tail_kernel, dim3(1), dim3(64), 0, st, t);
+        hipLaunchKernelGGL(train_tail_kernel, dim3(1), dim3(64 * TAIL_NW), 0, st, t);
         if (out_dev) HIP_TRY(hipMemcpyAsync(out_dev, outb, (size_t)B * 52 * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
 
@@ -613,38 +634,65 @@ int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in
         const float* w2p = P("blendshape_decoder.3.weight");
         hipLaunchKernelGGL(relu_outer_bwd_kernel, dim3((unsigned)((Rq * DH + 255) / 256)), dim3(256), 0, st, grow, H1, w2p, Rq, (int)DH, dH1);
         hipLaunchKernelGGL(relu_outer_bwd_kernel, dim3((unsigned)((B * DH + 255) / 256)), dim3(256), 0, st, grow + Rq, He, w2p, B, (int)DH, dHe);
+        HIP_TRY(hipEventRecord((hipEvent_t)c->tr_ev[2], st));
+        HIP_TRY(hipStreamWaitEvent(s2, (hipEvent_t)c->tr_ev[2], 0));
+        // ---- side stream: decoder output / decoder[0] parameter gradients, then the whole emotion stream backward ----
         int64_t chunk;
         const int S = split_of(Rq, chunk);
         float* dw2 = Gd("blendshape_decoder.3.weight");
         if (S == 1) {
-            hipLaunchKernelGGL(wcolsum_kernel, dim3((unsigned)((DH + 63) / 64), 1), dim3(256), 0, st, H1, grow, Rq, (int)DH, dw2, 0, chunk);
+            hipLaunchKernelGGL(wcolsum_kernel, dim3((unsigned)((DH + 63) / 64), 1), dim3(256), 0, s2, H1, grow, Rq, (int)DH, dw2, 0, chunk);
         } else {
-            hipLaunchKernelGGL(wcolsum_kernel, dim3((unsigned)((DH + 63) / 64), (unsigned)S), dim3(256), 0, st, H1, grow, Rq, (int)DH, c->tr_red, 0, chunk);
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((DH + 255) / 256)), dim3(256), 0, st, c->tr_red, S, (int)DH, dw2, 0);
+            hipLaunchKernelGGL(wcolsum_kernel, dim3((unsigned)((DH + 63) / 64), (unsigned)S), dim3(256), 0, s2, H1, grow, Rq, (int)DH, red2, 0, chunk);
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((DH + 255) / 256)), dim3(256), 0, s2, red2, S, (int)DH, dw2, 0);
         }
-        hipLaunchKernelGGL(wcolsum_kernel, dim3((unsigned)((DH + 63) / 64), 1), dim3(256), 0, st, He, grow + Rq, B, (int)DH, dw2, 1, B);
+        hipLaunchKernelGGL(wcolsum_kernel, dim3((unsigned)((DH + 63) / 64), 1), dim3(256), 0, s2, He, grow + Rq, B, (int)DH, dw2, 1, B);
     }
-    // decoder[0] (shared by both streams): dW1 = dH1^T O2 + dHe^T Oe2, db1, dO2 = dH1 W1, dOe2 = dHe W1
-    RUN(launch_gemm(TN(dH1, DH, O2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, Rq), 1, stream));
-    { GemmArgs g = TN(dHe, DH, Oe2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, B); g.beta = 1.f; RUN(launch_gemm(g, 1, stream)); }
-    RUN(colsum(c, dH1, Rq, DH, (int)DH, Gd("blendshape_decoder.0.bias"), 0, stream));
-    RUN(colsum(c, dHe, B, DH, (int)DH, Gd("blendshape_decoder.0.bias"), 1, stream));
+    // decoder[0] (shared by both streams): dW1 = dH1^T O2 + dHe^T Oe2, db1 (side stream); dO2 = dH1 W1 (main), dOe2 = dHe W1 (side)
+    RUN(launch_gemm(TN(dH1, DH, O2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, Rq), 1, stream2));
+    { GemmArgs g = TN(dHe, DH, Oe2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, B); g.beta = 1.f; RUN(launch_gemm(g, 1, stream2)); }
+    RUN(colsum(c, dH1, Rq, DH, (int)DH, Gd("blendshape_decoder.0.bias"), 0, stream2, red2));
+    RUN(colsum(c, dHe, B, DH, (int)DH, Gd("blendshape_decoder.0.bias"), 1, stream2, red2));
+    RUN(launch_gemm(NN(dHe, DH, P("blendshape_decoder.0.weight"), d, geA, d, B, d, DH), 1, stream2));              // dOe2
+    RUN(launch_gemm(TN(geA, d, Oe1, d, Gd("emotion_output_proj.weight"), d, d, d, B), 1, stream2));
+    RUN(colsum(c, geA, B, d, (int)d, Gd("emotion_output_proj.bias"), 0, stream2, red2));
+    RUN(launch_gemm(NN(geA, d, P("emotion_output_proj.weight"), d, geB, d, B, d, d), 1, stream2));                    // dOe1
+    RUN(launch_gemm(TN(geB, d, Ve, d, Gd("emotion_attention.out_proj.weight"), d, d, d, B), 1, stream2));
+    RUN(colsum(c, geB, B, d, (int)d, Gd("emotion_attention.out_proj.bias"), 0, stream2, red2));
+    RUN(launch_gemm(NN(geB, d, P("emotion_attention.out_proj.weight"), d, geC, d, B, d, d), 1, stream2));             // dVe
+    RUN(launch_gemm(TN(geC, d, E, d, Gd("emotion_attention.in_proj_weight") + 2 * d * d, d, d, d, B), 1, stream2));   // only the V third
+    RUN(colsum(c, geC, B, d, (int)d, Gd("emotion_attention.in_proj_bias") + 2 * d, 0, stream2, red2));
+    RUN(launch_gemm(NN(geC, d, einw + 2 * d * d, d, geA, d, B, d, d), 1, stream2));                                   // dE
+    RUN(ln_param_grad(c, geA, E0, B, (int)d, emu, ers, Gd("emotion_norm.weight"), Gd("emotion_norm.bias"), stream2, red2));
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s2, geA, E0, B, (int)d, P("emotion_norm.weight"), emu, ers);
+    RUN(launch_gemm(TN(geA, d, emo, ED, Gd("emotion_encoder.weight"), ED, d, ED, B), 1, stream2));
+    RUN(colsum(c, geA, B, d, (int)d, Gd("emotion_encoder.bias"), 0, stream2, red2));
+    // ---- main stream: the mel chain ----
     RUN(launch_gemm(NN(dH1, DH, P("blendshape_decoder.0.weight"), d, gA, d, Rq, d, DH), 1, stream));               // dO2
-    RUN(launch_gemm(NN(dHe, DH, P("blendshape_decoder.0.weight"), d, geA, d, B, d, DH), 1, stream));               // dOe2
+    // Every activation gradient of the mel chain has its own buffer (gA = dO2, gB = dO1, gC = dA, dKV, dQb, dY), so the
+    // parameter gradients that hang off it (TN products and column sums) go to the side stream as soon as their input
+    // exists, and the main stream only carries the chain of input gradients.
+    auto to_side = [&](int ev) -> int {      // side stream continues after what the main stream has produced so far
+        HIP_TRY(hipEventRecord((hipEvent_t)c->tr_ev[ev], st));
+        HIP_TRY(hipStreamWaitEvent(s2, (hipEvent_t)c->tr_ev[ev], 0));
+        return KM_OK;
+    };
     // mel_output_proj
-    RUN(launch_gemm(TN(gA, d, O1, d, Gd("mel_output_proj.weight"), d, d, d, Rq), 1, stream));
-    RUN(colsum(c, gA, Rq, d, (int)d, Gd("mel_output_proj.bias"), 0, stream));
+    RUN(to_side(4));
+    RUN(launch_gemm(TN(gA, d, O1, d, Gd("mel_output_proj.weight"), d, d, d, Rq), 1, stream2));
+    RUN(colsum(c, gA, Rq, d, (int)d, Gd("mel_output_proj.bias"), 0, stream2, red2));
     RUN(launch_gemm(NN(gA, d, P("mel_output_proj.weight"), d, gB, d, Rq, d, d), 1, stream));                        // dO1
     // out_proj
-    RUN(launch_gemm(TN(gB, d, A, d, Gd("mel_attention.out_proj.weight"), d, d, d, Rq), 1, stream));
-    RUN(colsum(c, gB, Rq, d, (int)d, Gd("mel_attention.out_proj.bias"), 0, stream));
-    RUN(launch_gemm(NN(gB, d, P("mel_attention.out_proj.weight"), d, gA, d, Rq, d, d), 1, stream));                 // dA
+    RUN(to_side(5));
+    RUN(launch_gemm(TN(gB, d, A, d, Gd("mel_attention.out_proj.weight"), d, d, d, Rq), 1, stream2));
+    RUN(colsum(c, gB, Rq, d, (int)d, Gd("mel_attention.out_proj.bias"), 0, stream2, red2));
+    RUN(launch_gemm(NN(gB, d, P("mel_attention.out_proj.weight"), d, gC, d, Rq, d, d), 1, stream));                 // dA
     float* gin_w = Gd("mel_attention.in_proj_weight"); float* gin_b = Gd("mel_attention.in_proj_bias");
     {   // dP = dA_h V_h^T ; dV_h = P^T dA_h
-        GemmArgs g = G(gA, d, 1, KV + d, 1, 2 * d, dP, NKk, 28, NKk, hd);
+        GemmArgs g = G(gC, d, 1, KV + d, 1, 2 * d, dP, NKk, 28, NKk, hd);
         g.batch2 = (int)H; g.a_bs1 = 28 * d; g.a_bs2 = hd; g.b_bs1 = NKk * 2 * d; g.b_bs2 = hd; g.c_bs1 = H * 28 * NKk; g.c_bs2 = 28 * NKk;
         RUN(launch_gemm(g, (int)(B * H), stream));
-        g = G(Pm, 1, NKk, gA, d, 1, dKV + d, 2 * d, NKk, hd, 28);
+        g = G(Pm, 1, NKk, gC, d, 1, dKV + d, 2 * d, NKk, hd, 28);
         g.batch2 = (int)H; g.a_bs1 = H * 28 * NKk; g.a_bs2 = 28 * NKk; g.b_bs1 = 28 * d; g.b_bs2 = hd; g.c_bs1 = NKk * 2 * d; g.c_bs2 = hd;
         RUN(launch_gemm(g, (int)(B * H), stream));
     }
@@ -658,39 +706,29 @@ int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in
         g.alpha = scale; g.batch2 = (int)H; g.a_bs1 = H * 28 * NKk; g.a_bs2 = 28 * NKk; g.b_bs2 = hd; g.c_bs1 = NKk * 2 * d; g.c_bs2 = hd;
         RUN(launch_gemm(g, (int)(B * H), stream));
     }
-    // in_proj: rows [0,d) = Wq, [d,3d) = [Wk; Wv]
-    RUN(launch_gemm(TN(dQb, d, P("mouth_queries"), d, gin_w, d, d, d, 28), 1, stream));
-    RUN(colsum(c, dQb, 28, d, (int)d, gin_b, 0, stream));
-    RUN(launch_gemm(NN(dQb, d, inw, d, Gd("mouth_queries"), d, 28, d, d), 1, stream));
-    RUN(launch_gemm(TN(dKV, 2 * d, Y, d, gin_w + d * d, d, 2 * d, d, R), 1, stream));
-    RUN(colsum(c, dKV, R, 2 * d, (int)(2 * d), gin_b + d, 0, stream));
+    // in_proj: rows [0,d) = Wq, [d,3d) = [Wk; Wv] -- parameter gradients on the side stream
+    RUN(to_side(6));
+    RUN(launch_gemm(TN(dQb, d, P("mouth_queries"), d, gin_w, d, d, d, 28), 1, stream2));
+    RUN(colsum(c, dQb, 28, d, (int)d, gin_b, 0, stream2, red2));
+    RUN(launch_gemm(NN(dQb, d, inw, d, Gd("mouth_queries"), d, 28, d, d), 1, stream2));
+    RUN(launch_gemm(TN(dKV, 2 * d, Y, d, gin_w + d * d, d, 2 * d, d, R), 1, stream2));
+    RUN(colsum(c, dKV, R, 2 * d, (int)(2 * d), gin_b + d, 0, stream2, red2));
     RUN(launch_gemm(NN(dKV, 2 * d, inw + d * d, d, dY, d, R, d, 2 * d), 1, stream));                                 // dY
-    // LayerNorm
+    // LayerNorm (its parameter gradients read dY before ln_bwd_kernel rewrites it in place: same stream)
     RUN(ln_param_grad(c, dY, Y0, R, (int)d, mu, rs, Gd("mel_norm.weight"), Gd("mel_norm.bias"), stream));
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, dY, Y0, R, (int)d, P("mel_norm.weight"), mu, rs);
-    {   // channel encoder: dWce = sum_b dY0_b^T X_b (long columns, then the 3 short-term columns), db
+    {   // channel encoder: dWce = sum_b dY0_b^T X_b (long columns on the main stream; the 3 short-term columns and db beside it)
+        RUN(to_side(7));
         GemmArgs g = G(dY, 1, d, mel, 1, NKk, Gd("mel_channel_encoder.weight"), KT, d, tv, NKk);
         g.kb_count = (int)B; g.a_kbs = NKk * d; g.b_kbs = T_in * NKk;
         RUN(launch_gemm(g, 1, stream));
         g = G(dY, 1, d, mel_short, 1, NKk, Gd("mel_channel_encoder.weight") + T, KT, d, 3, NKk);
         g.kb_count = (int)B; g.a_kbs = NKk * d; g.b_kbs = 3 * NKk;
-        RUN(launch_gemm(g, 1, stream));
-        RUN(colsum(c, dY, R, d, (int)d, Gd("mel_channel_encoder.bias"), 0, stream));
+        RUN(launch_gemm(g, 1, stream2));
+        RUN(colsum(c, dY, R, d, (int)d, Gd("mel_channel_encoder.bias"), 0, stream2, red2));
     }
-    // emotion stream
-    RUN(launch_gemm(TN(geA, d, Oe1, d, Gd("emotion_output_proj.weight"), d, d, d, B), 1, stream));
-    RUN(colsum(c, geA, B, d, (int)d, Gd("emotion_output_proj.bias"), 0, stream));
-    RUN(launch_gemm(NN(geA, d, P("emotion_output_proj.weight"), d, geB, d, B, d, d), 1, stream));                     // dOe1
-    RUN(launch_gemm(TN(geB, d, Ve, d, Gd("emotion_attention.out_proj.weight"), d, d, d, B), 1, stream));
-    RUN(colsum(c, geB, B, d, (int)d, Gd("emotion_attention.out_proj.bias"), 0, stream));
-    RUN(launch_gemm(NN(geB, d, P("emotion_attention.out_proj.weight"), d, geC, d, B, d, d), 1, stream));              // dVe
-    RUN(launch_gemm(TN(geC, d, E, d, Gd("emotion_attention.in_proj_weight") + 2 * d * d, d, d, d, B), 1, stream));    // only the V third
-    RUN(colsum(c, geC, B, d, (int)d, Gd("emotion_attention.in_proj_bias") + 2 * d, 0, stream));
-    RUN(launch_gemm(NN(geC, d, einw + 2 * d * d, d, geA, d, B, d, d), 1, stream));                                    // dE
-    RUN(ln_param_grad(c, geA, E0, B, (int)d, emu, ers, Gd("emotion_norm.weight"), Gd("emotion_norm.bias"), stream));
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, geA, E0, B, (int)d, P("emotion_norm.weight"), emu, ers);
-    RUN(launch_gemm(TN(geA, d, emo, ED, Gd("emotion_encoder.weight"), ED, d, ED, B), 1, stream));
-    RUN(colsum(c, geA, B, d, (int)d, Gd("emotion_encoder.bias"), 0, stream));
+    HIP_TRY(hipEventRecord((hipEvent_t)c->tr_ev[3], s2));
+    HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)c->tr_ev[3], 0));      // join: every gradient is in the bucket
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }
