@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Determinism soak: the same batch through km_forward_audio (and the stream tick, the sequence path, the train step)
+many times; every repetition must reproduce the first result bit for bit."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from koemorph_amd import synth
+from koemorph_amd.engine import Engine
+from koemorph_amd.training import Trainer
+
+n = int(os.environ.get("REPS", 300))
+eng = Engine(); eng.load_state_dict(synth.make_core_params(0, style="trained")); eng.finalize()
+B = 256
+audio = torch.from_numpy(synth.make_audio(1, B, 136448, "uniform")).cuda()
+emo = torch.from_numpy(synth.normal(2, (B, 256))).cuda()
+eng.reserve(B, 136448)
+first = eng.forward_audio(audio, emo).clone()
+bad = sum(int(not torch.equal(eng.forward_audio(audio, emo), first)) for _ in range(n))
+print(f"forward_audio: {n} repetitions, {bad} differ")
+seq_a = torch.from_numpy(synth.make_audio(3, 2, 136448 + 533 * 40)).cuda()
+s0 = eng.sequence_forward(seq_a, emo[:2], 1, True, max_tile=16).clone()
+bad_s = sum(int(not torch.equal(eng.sequence_forward(seq_a, emo[:2], 1, True, max_tile=16), s0)) for _ in range(50))
+print(f"sequence_forward: 50 repetitions, {bad_s} differ")
+tr = Trainer(eng, max_windows=8, use_smoothing=False)
+tgt = torch.from_numpy(synth.uniform(4, (8, 52), 0, 1)).cuda()
+tr.forward_backward(audio[:8], emo[:8], tgt); g0 = tr.flat_grad.clone(); l0 = float(tr.loss.item())
+bad_t = 0
+for _ in range(100):
+    tr.forward_backward(audio[:8], emo[:8], tgt)
+    bad_t += int(not torch.equal(tr.flat_grad, g0) or float(tr.loss.item()) != l0)
+print(f"train forward_backward (two streams): 100 repetitions, {bad_t} differ")
+sys.exit(1 if bad or bad_s or bad_t else 0)
