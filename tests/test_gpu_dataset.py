@@ -86,3 +86,25 @@ def test_float_wav_is_kept_exact_and_feeds_the_train_step(tmp_path):
     l0 = float(tr.step(batch["audio"], emo, batch["target"]).item())
     l1 = float(tr.step(batch["audio"], emo, batch["target"]).item())
     assert np.isfinite(l0) and np.isfinite(l1) and l1 < l0          # one optimisation step on a device-made batch
+
+
+def test_window_producer_argument_errors():
+    import ctypes
+    from koemorph_amd._lib import KoeMorphError, check, load
+    lib = load()
+    x = torch.zeros(1000, device="cuda"); starts = torch.zeros(4, dtype=torch.int32, device="cuda"); out = torch.zeros(4, 100, device="cuda")
+    with pytest.raises(KoeMorphError):
+        check(lib.km_gather_windows(x.data_ptr(), 1000, None, 4, 10, 100, out.data_ptr(), None, 0, 0, 0, None, None, None))
+    with pytest.raises(KoeMorphError):
+        check(lib.km_gather_windows(x.data_ptr(), 1000, starts.data_ptr(), 70000, 10, 100, out.data_ptr(), None, 0, 0, 0, None, None, None))
+    with pytest.raises(KoeMorphError):      # label outputs requested without a label track
+        check(lib.km_gather_windows(x.data_ptr(), 1000, starts.data_ptr(), 4, 10, 100, out.data_ptr(), None, 0, 8, 52, out.data_ptr(), None, None))
+    with pytest.raises(KoeMorphError):
+        check(lib.km_resample_labels(x.data_ptr(), 0, 52, 10, out.data_ptr(), None))
+    check(lib.km_resample_labels(x.data_ptr(), 10, 52, 0, out.data_ptr(), None))               # nothing to do is fine
+    # windows starting past the end of the clip are zero filled, not out-of-bounds reads
+    starts[:] = torch.tensor([0, 50, 99, 200], dtype=torch.int32)
+    clip = torch.arange(1000, dtype=torch.float32, device="cuda")
+    check(lib.km_gather_windows(clip.data_ptr(), 1000, starts.data_ptr(), 4, 10, 100, out.data_ptr(), None, 0, 0, 0, None, None, None))
+    torch.cuda.synchronize()
+    assert torch.equal(out[1], clip[500:600]) and torch.equal(out[2, :10], clip[990:]) and not out[2, 10:].any() and not out[3].any()

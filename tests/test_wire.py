@@ -52,3 +52,20 @@ def test_empty_and_one_dimensional_inputs():
     assert format_frames(np.zeros((0, 52), np.float32), []) == []
     one = format_frames(np.full(52, 0.25, np.float32), 3.0)
     assert one == ref(np.full((1, 52), 0.25, np.float32), [3.0])
+
+
+def test_capacity_and_argument_errors():
+    import ctypes
+    from koemorph_amd._lib import load
+    lib = load()
+    frames = np.linspace(0, 1, 104, dtype=np.float32).reshape(2, 52)
+    ts = np.array([1.0, 2.0])
+    small = ctypes.create_string_buffer(100)
+    rc = lib.km_format_frames(frames.ctypes.data, 2, 52, ts.ctypes.data, 0, small, 100, None)
+    assert rc < -100                                   # -(bytes that certainly suffice)
+    big = ctypes.create_string_buffer(-rc)
+    n = lib.km_format_frames(frames.ctypes.data, 2, 52, ts.ctypes.data, 0, big, -rc, None)
+    assert 0 < n <= -rc and big.raw[:n] == b"".join(ref(frames, ts))
+    assert lib.km_format_frames(None, 2, 52, ts.ctypes.data, 0, big, -rc, None) == -1        # KM_ERR_INVALID_ARG
+    assert lib.km_format_frames(frames.ctypes.data, 2, 52, None, 0, big, -rc, None) == -1
+    assert lib.km_format_frames(frames.ctypes.data, 0, 52, ts.ctypes.data, 0, big, -rc, None) == 0
