@@ -129,6 +129,14 @@ class Engine:
         for k, v in state.items():
             self.load_param(k, v)
 
+    def state_dict_shapes(self):
+        """Keys and shapes of the model's parameters in state-dict order (DualStreamCrossAttention + smoothing_alpha)."""
+        from . import synth
+        shapes = synth.core_param_shapes(self.d_model, self.mel_sequence_length, 3, self.emotion_dim, self.num_blendshapes)
+        out = {k: np.empty(v, np.float32) for k, v in shapes.items()}
+        out["smoothing_alpha"] = np.empty((), np.float32)
+        return out
+
     def get_param(self, key: str, shape) -> np.ndarray:
         out = np.empty(shape, np.float32)
         check(self._lib.km_get_param(self._h, key.encode(), out.ctypes.data_as(C.c_void_p), out.size))

@@ -77,6 +77,16 @@ class Trainer:
         return {k: flat[self.offset(k):self.offset(k) + int(np.prod(s, dtype=np.int64))].reshape(s).copy()
                 for k, s in shapes.items()}
 
+    def load_params(self, state: Dict[str, np.ndarray]) -> None:
+        """Overwrite the fp32 master weights (e.g. from a checkpoint); moments and step counters are kept."""
+        flat = np.empty(self.n_params, np.float32)
+        check(self._lib.km_train_get_params(self._h, flat.ctypes.data, self.n_params))
+        for k, v in state.items():
+            a = np.asarray(v, np.float32).ravel()
+            off = self.offset(k)
+            flat[off:off + a.size] = a
+        check(self._lib.km_train_set_params(self._h, flat.ctypes.data, self.n_params))
+
     def reset_temporal_state(self):
         self._ema_batch = None
 

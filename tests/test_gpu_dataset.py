@@ -108,3 +108,42 @@ def test_window_producer_argument_errors():
     check(lib.km_gather_windows(clip.data_ptr(), 1000, starts.data_ptr(), 4, 10, 100, out.data_ptr(), None, 0, 0, 0, None, None, None))
     torch.cuda.synchronize()
     assert torch.equal(out[1], clip[500:600]) and torch.equal(out[2, :10], clip[990:]) and not out[2, 10:].any() and not out[3].any()
+
+
+def test_sequential_trainer_script_end_to_end(tmp_path):
+    """koemorph_amd.scripts.train_sequential: two epochs over a tiny two-clip data set, validation, checkpoint in the
+    reference's format (loads into the model mirror with strict=True), resume."""
+    from koemorph_amd.engine import Engine
+    from koemorph_amd.model import SimplifiedDualStreamModel
+    from koemorph_amd.scripts import train_sequential as ts
+    for name, seed in (("a", 40), ("b", 50)):
+        write_pair(tmp_path, name, 8.9, 30, seed)
+    eng = Engine(); eng.load_state_dict(synth.make_core_params(0)); eng.finalize()
+    kw = dict(stride_frames=4, shuffle_files=False, loop_dataset=False, batch_size=4)
+    st = ts.SequentialTrainer(eng, SequentialKoeMorphDataset(tmp_path, **kw), SequentialKoeMorphDataset(tmp_path, **kw),
+                              learning_rate=1e-3, l1_weight=0.1,
+                              extra_loss_terms=dict(sparsity_weight=0.01, smoothness_weight=0.1))
+    v0 = st.validate()["total"]
+    m1 = st.train_epoch(); m2 = st.train_epoch()
+    v2 = st.validate()["total"]
+    assert m1["batches"] == m2["batches"] >= 2 and m2["total"] < m1["total"] and v2 < v0 and st.epoch == 2
+    ck = tmp_path / "ck" / "checkpoint_epoch_2.pth"
+    st.save_checkpoint(ck, is_best=True)
+    assert (tmp_path / "ck" / "best_model.pth").exists()
+    ckpt = torch.load(ck, weights_only=True)
+    assert {"epoch", "global_step", "model_state_dict", "best_val_loss"} <= set(ckpt)
+    model = SimplifiedDualStreamModel().cuda().eval()
+    model.load_state_dict(ckpt["model_state_dict"], strict=True)
+    batch = next(iter(SequentialKoeMorphDataset(tmp_path, **kw)))
+    emo = st._emotion(batch)
+    st.trainer.sync_inference_weights()
+    model.reset_temporal_state()
+    a = model(batch["audio"], emotion_features=emo)["blendshapes"]
+    b = eng.forward_audio(batch["audio"], emo)
+    assert float((a - b).abs().max()) < 1e-6                                   # the checkpoint IS the trained model
+    eng2 = Engine(); eng2.load_state_dict(synth.make_core_params(0)); eng2.finalize()
+    st2 = ts.SequentialTrainer(eng2, SequentialKoeMorphDataset(tmp_path, **kw))
+    st2.load_checkpoint(ck)
+    assert st2.epoch == 2 and st2.global_step == st.global_step
+    for k, v in st2.state_dict().items():
+        assert torch.equal(v, ckpt["model_state_dict"][k]), k

@@ -160,3 +160,12 @@ def test_dataset_host_helpers_and_oracle_windows(tmp_path):
     assert [x[0] for x in w] == [0, 1, 2, 3, 4] and w[4][1] == 40 and w[4][2][0] == 40 * 533 and len(w[4][2]) == 136448
     with pytest.raises(RuntimeError):
         SequentialKoeMorphDataset(tmp_path, device="cpu")                       # clips live in HBM: no CPU fallback
+
+
+def test_train_sequential_cli():
+    from koemorph_amd.scripts import train_sequential as ts
+    a = ts.build_parser().parse_args(["--data_dir", "d"])
+    assert (a.epochs, a.batch_size, a.window_frames, a.stride_frames, a.learning_rate, a.weight_decay, a.gradient_clip) == \
+        (10, 8, 256, 1, 1e-4, 1e-5, 1.0)                               # train_sequential.py:73-86 defaults
+    with pytest.raises(SystemExit):
+        ts.build_parser().parse_args([])
