@@ -234,6 +234,12 @@ int km_train_adamw(km_handle h, const float* flat_grad_dev, float lr, float beta
 int km_train_get_params(km_handle h, float* flat_host, int64_t n);
 int km_train_set_params(km_handle h, const float* flat_host, int64_t n);
 int km_train_sync(km_handle h, void* stream);
+/* AdamW state for checkpoints (the optimizer_state_dict of src/train_sequential.py:303-339): first and second moments as
+ * flat vectors laid out like the parameters, and the two device-side step counters (all parameters, smoothing_alpha).
+ * Both calls synchronise the device. */
+int km_train_get_optimizer_state(km_handle h, float* exp_avg_host, float* exp_avg_sq_host, int64_t n, int32_t* steps2_host);
+int km_train_set_optimizer_state(km_handle h, const float* exp_avg_host, const float* exp_avg_sq_host, int64_t n,
+                                 const int32_t* steps2_host);
 
 /* The remaining terms of KoeMorphLoss (src/model/losses.py:29-178), ADDED to the mse/l1 terms of km_train_step*:
  *   perceptual  four group-weighted MSEs: mouth cols 12..31 x2.0, eye 0..11 x1.0, brow 32..43 x1.0, jaw 44..51 x1.5

@@ -94,6 +94,8 @@ SIGNATURES = {
     "km_train_set_params": (C.c_int, [_h, _p, _i64]),
     "km_train_sync": (C.c_int, [_h, _p]),
     "km_train_set_loss": (C.c_int, [_h, C.POINTER(KMLossConfig)]),
+    "km_train_get_optimizer_state": (C.c_int, [_h, _p, _p, _i64, _p]),
+    "km_train_set_optimizer_state": (C.c_int, [_h, _p, _p, _i64, _p]),
     "km_resample_labels": (C.c_int, [_p, C.c_int64, C.c_int32, C.c_int64, _p, _p]),
     "km_gather_windows": (C.c_int, [_p, C.c_int64, _p, C.c_int64, C.c_int32, C.c_int64, _p, _p, C.c_int64, C.c_int32,
                                     C.c_int32, _p, _p, _p]),

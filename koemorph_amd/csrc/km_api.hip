@@ -337,6 +337,29 @@ int km_train_set_params(km_handle h, const float* flat_host, int64_t n) {
     return KM_OK;
 }
 
+int km_train_get_optimizer_state(km_handle h, float* exp_avg_host, float* exp_avg_sq_host, int64_t n, int32_t* steps2_host) {
+    if (int rc = need_train(h, 1)) return rc;
+    if (!exp_avg_host || !exp_avg_sq_host || !steps2_host || n != h->tr_nparams)
+        return fail(KM_ERR_INVALID_ARG, "km_train_get_optimizer_state: bad argument");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(exp_avg_host, h->tr_m, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(exp_avg_sq_host, h->tr_v, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(steps2_host, h->tr_steps, 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return KM_OK;
+}
+
+int km_train_set_optimizer_state(km_handle h, const float* exp_avg_host, const float* exp_avg_sq_host, int64_t n,
+                                 const int32_t* steps2_host) {
+    if (int rc = need_train(h, 1)) return rc;
+    if (!exp_avg_host || !exp_avg_sq_host || !steps2_host || n != h->tr_nparams)
+        return fail(KM_ERR_INVALID_ARG, "km_train_set_optimizer_state: bad argument");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h->tr_m, exp_avg_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->tr_v, exp_avg_sq_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->tr_steps, steps2_host, 2 * sizeof(int32_t), hipMemcpyHostToDevice));
+    return KM_OK;
+}
+
 int km_train_sync(km_handle h, void* stream) {
     if (int rc = need_train(h, 1)) return rc;
     Context* c = h;

@@ -119,7 +119,8 @@ class SequentialTrainer:
         path = Path(path)
         path.parent.mkdir(parents=True, exist_ok=True)
         ckpt = {"epoch": self.epoch, "global_step": self.global_step, "model_state_dict": self.state_dict(),
-                "best_val_loss": self.best_val_loss, "optimizer_step": self.trainer.step_count,
+                "best_val_loss": self.best_val_loss, "optimizer_state_dict": self.trainer.optimizer_state(),
+                "current_file_idx": -1 if self.current_file_idx is None else int(self.current_file_idx),
                 "model_config": {"d_model": self.engine.d_model, "num_heads": self.engine.num_heads,
                                  "mel_sequence_length": self.engine.mel_sequence_length}}
         if self.rank == 0:
@@ -133,8 +134,9 @@ class SequentialTrainer:
         self.trainer.load_params(sd)
         self.epoch = int(ckpt["epoch"]); self.global_step = int(ckpt["global_step"])
         self.best_val_loss = float(ckpt.get("best_val_loss", float("inf")))
-        self.trainer.epoch = self.epoch
-        self.trainer.lr = __import__("koemorph_amd.training", fromlist=["x"]).cosine_warm_restarts_lr(self.epoch, self.trainer.base_lr)
+        self.trainer.load_optimizer_state(ckpt["optimizer_state_dict"])
+        cf = int(ckpt.get("current_file_idx", -1))
+        self.current_file_idx = None if cf < 0 else cf
 
 
 def build_parser() -> argparse.ArgumentParser:

@@ -87,6 +87,24 @@ class Trainer:
             flat[off:off + a.size] = a
         check(self._lib.km_train_set_params(self._h, flat.ctypes.data, self.n_params))
 
+    def optimizer_state(self) -> Dict[str, object]:
+        """AdamW moments + step counters (host copies) for a checkpoint."""
+        m, v = np.empty(self.n_params, np.float32), np.empty(self.n_params, np.float32)
+        steps = np.zeros(2, np.int32)
+        check(self._lib.km_train_get_optimizer_state(self._h, m.ctypes.data, v.ctypes.data, self.n_params, steps.ctypes.data))
+        return {"exp_avg": torch.from_numpy(m), "exp_avg_sq": torch.from_numpy(v), "steps": torch.from_numpy(steps),
+                "step_count": self.step_count, "epoch": self.epoch, "ema_state": self.ema_state.cpu(),
+                "ema_batch": -1 if self._ema_batch is None else int(self._ema_batch)}
+
+    def load_optimizer_state(self, st: Dict[str, object]) -> None:
+        m = np.ascontiguousarray(st["exp_avg"].numpy(), np.float32); v = np.ascontiguousarray(st["exp_avg_sq"].numpy(), np.float32)
+        steps = np.ascontiguousarray(st["steps"].numpy(), np.int32)
+        check(self._lib.km_train_set_optimizer_state(self._h, m.ctypes.data, v.ctypes.data, self.n_params, steps.ctypes.data))
+        self.step_count = int(st["step_count"]); self.epoch = int(st["epoch"])
+        self.lr = cosine_warm_restarts_lr(self.epoch, self.base_lr)
+        self.ema_state.copy_(st["ema_state"].to(self.device))
+        self._ema_batch = None if int(st["ema_batch"]) < 0 else int(st["ema_batch"])
+
     def reset_temporal_state(self):
         self._ema_batch = None
 

@@ -142,8 +142,14 @@ def test_sequential_trainer_script_end_to_end(tmp_path):
     b = eng.forward_audio(batch["audio"], emo)
     assert float((a - b).abs().max()) < 1e-6                                   # the checkpoint IS the trained model
     eng2 = Engine(); eng2.load_state_dict(synth.make_core_params(0)); eng2.finalize()
-    st2 = ts.SequentialTrainer(eng2, SequentialKoeMorphDataset(tmp_path, **kw))
+    st2 = ts.SequentialTrainer(eng2, SequentialKoeMorphDataset(tmp_path, **kw), learning_rate=1e-3, l1_weight=0.1,
+                               extra_loss_terms=dict(sparsity_weight=0.01, smoothness_weight=0.1))
     st2.load_checkpoint(ck)
     assert st2.epoch == 2 and st2.global_step == st.global_step
     for k, v in st2.state_dict().items():
         assert torch.equal(v, ckpt["model_state_dict"][k]), k
+    # resuming continues exactly where the uninterrupted run goes: weights, AdamW moments, step counters, schedule
+    m3a = st.train_epoch(); m3b = st2.train_epoch()
+    assert m3a["total"] == m3b["total"] and m3a["lr"] == m3b["lr"]
+    for (k, a), (_, b) in zip(st.state_dict().items(), st2.state_dict().items()):
+        assert torch.equal(a, b), k
