@@ -1,0 +1,73 @@
+"""Data-parallel training step on a real GPU: two processes (one share of the batch each, gloo all-reduce of the flat
+gradient bucket -- on a node it is RCCL; the code path is the same `parallel.allreduce_gradients`) must take the same
+optimisation step as one process on the whole batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup(B):
+    from koemorph_amd import synth
+    from koemorph_amd.engine import Engine
+    from koemorph_amd.training import Trainer
+    eng = Engine(); eng.load_state_dict(synth.make_core_params(3, style="trained")); eng.finalize("cuda:0")
+    tr = Trainer(eng, max_windows=B, lr=1e-3, use_smoothing=False, l1_weight=0.1)
+    audio = torch.from_numpy(synth.make_audio(5, 8, 136448)).cuda()
+    emo = torch.from_numpy(synth.normal(6, (8, 256))).cuda()
+    target = torch.from_numpy(synth.uniform(7, (8, 52), 0, 1)).cuda()
+    return synth, eng, tr, audio, emo, target
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from koemorph_amd import parallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    synth, eng, tr, audio, emo, target = _setup(4)
+    lo, hi = parallel.shard_range(8, rank, world)
+    losses = []
+    for _ in range(3):
+        losses.append(float(tr.step(audio[lo:hi], emo[lo:hi], target[lo:hi]).item()))
+    shapes = {k: v.shape for k, v in synth.make_core_params(3, style="trained").items()}
+    q.put((rank, losses, {k: v for k, v in tr.params(shapes).items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    synth, eng, tr, audio, emo, target = _setup(8)
+    ref_losses = [float(tr.step(audio, emo, target).item()) for _ in range(3)]
+    shapes = {k: v.shape for k, v in synth.make_core_params(3, style="trained").items()}
+    ref = tr.params(shapes)
+    # both ranks hold identical weights after every step (same reduced gradient, same update)
+    for k in ref:
+        assert np.array_equal(res[0][2][k], res[1][2][k]), k
+    # the mean of the two half-batch losses is the full-batch loss; the weights follow the single-process trajectory
+    for s in range(3):
+        assert abs(0.5 * (res[0][1][s] + res[1][1][s]) - ref_losses[s]) < 2e-6 * max(1.0, abs(ref_losses[s]))
+    worst = max(float(np.abs(res[0][2][k] - ref[k]).max()) for k in ref)
+    assert worst < 2e-5, worst          # 3 AdamW steps at lr 1e-3 move weights by ~3e-3; summation order differs between the runs
