@@ -33,6 +33,8 @@ CASES = [
     dict(name="core_d256_pad_T100", d=256, T=256, H=8, B=2, t_in=100, pstyle="trained", istyle="mel01", seed=14, grads=False),
     dict(name="core_d256_trunc_T300", d=256, T=256, H=8, B=2, t_in=300, pstyle="trained", istyle="mel01", seed=15, grads=False),
     dict(name="core_d256_rt_T255", d=256, T=256, H=8, B=2, t_in=255, pstyle="init", istyle="mel01", seed=16, grads=False),
+    dict(name="core_d256_pad_T1", d=256, T=256, H=8, B=1, t_in=1, pstyle="trained", istyle="randn", seed=17, grads=False),
+    dict(name="core_d256_trunc_T700", d=256, T=256, H=8, B=3, t_in=700, pstyle="init", istyle="randn", seed=18, grads=False),
     dict(name="core_d512_T512_H8", d=512, T=512, H=8, B=2, t_in=513, pstyle="trained", istyle="mel01", seed=21, grads=False),
     dict(name="core_d512_T512_H16", d=512, T=512, H=16, B=2, t_in=513, pstyle="trained", istyle="mel01", seed=22, grads=False),
     dict(name="core_d64_T32_H4_small", d=64, T=32, H=4, B=5, t_in=33, pstyle="trained", istyle="randn", seed=31, grads=True),

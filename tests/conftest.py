@@ -65,7 +65,7 @@ def assert_grads_match(grads, g, tol):
 
 CORE_CASES_D256 = [
     "core_d256_T256_H8_init", "core_d256_T256_H8_trained", "core_d256_T256_H8_randn",
-    "core_d256_pad_T100", "core_d256_trunc_T300", "core_d256_rt_T255",
+    "core_d256_pad_T100", "core_d256_trunc_T300", "core_d256_rt_T255", "core_d256_pad_T1", "core_d256_trunc_T700",
 ]
 CORE_CASES_OTHER = ["core_d512_T512_H8", "core_d512_T512_H16", "core_d64_T32_H4_small"]
 
