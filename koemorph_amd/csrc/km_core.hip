@@ -90,16 +90,6 @@ struct CoreArgs {
 // or -1 for the 24 expression rows
 __device__ __forceinline__ int mouth_slot_of(int i) { return (i >= 14 && i <= 40) ? i - 14 : (i == 51 ? 27 : -1); }
 
-// Sum over the 16 lanes of a DPP row, result in every lane: the same pairing (hence bit-identical sums) as the
-// xor-1/2/4/8 butterfly, but four v_add_f32_dpp instead of four ds_bpermute round trips through the LDS crossbar.
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
-    return v;
-}
-
 template <bool ATTN, bool FUSE_DB>
 __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
     using namespace fused;

@@ -47,6 +47,16 @@ __device__ __forceinline__ float4 log_four_t(const LogParams& p, float4 v, float
                        log_one_t<MODE>(p, v.z, ref_db, floor_db), log_one_t<MODE>(p, v.w, ref_db, floor_db));
 }
 
+// Sum over the 16 lanes of a DPP row, result in every lane: the same pairing (hence bit-identical sums) as the
+// xor-1/2/4/8 butterfly, but four v_add_f32_dpp instead of four ds_bpermute round trips through the LDS crossbar.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Emotion stream of ONE window by one 512-thread workgroup (production shape: d_model 256, decoder hidden 128,
 // emotion_dim <= 256), for workgroups of another kernel that have slack (the front end's second workgroup of a

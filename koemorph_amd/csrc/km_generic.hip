@@ -511,7 +511,140 @@ __global__ __launch_bounds__(256) void encoder_tn_kernel(const float* __restrict
         }
 }
 
-static int core_generic_after_encoder(Context* c, int64_t B, const float* zemo, float* out, float* raw, float* attn, void* stream);
+// ---------------------------------------------------------------------------------------------------------
+// encoder_ln_kernel<NW>: the same product as encoder_tn_kernel with ONE workgroup of NW = d / 32 waves per window, so
+// that a row's d columns are all in the workgroup and LayerNorm (two-pass, DPP row sums + a [row][wave] exchange, as in
+// the fused d=256 kernel) runs in the epilogue: no Y0 round trip, no separate ln_rows launch.
+// ---------------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void encoder_ln_kernel(const float* __restrict__ xp, const float* __restrict__ wpad,
+                                                             const float* __restrict__ bias, const float* __restrict__ gam,
+                                                             const float* __restrict__ bet, float* __restrict__ Y, int KP) {
+    constexpr int NKc = 80, BN = 32 * NW, NTHR = 64 * NW, D = BN;
+    constexpr int EB = 4 * BN / NTHR;                                  // float4 of the weight tile per thread (= 2)
+    __shared__ __attribute__((aligned(16))) float As[2][4 * NKc * 4];
+    __shared__ __attribute__((aligned(16))) float Bs[2][4 * BN * 4];
+    __shared__ __attribute__((aligned(16))) float Ps[2][NKc * NW];      // LayerNorm partial sums [pass][row][wave]
+    __shared__ __attribute__((aligned(16))) float Ts[2][NKc];           // LayerNorm row totals [pass][row]
+    static_assert(NKc % NW == 0, "rows must divide evenly among the waves");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lg = lane >> 4, lj = lane & 15;
+    const int b = blockIdx.x;
+    const float* X = xp + (int64_t)b * KP * NKc;
+    const bool a_thr = tid < 80;
+    const int akg = tid / 20, am4 = tid - akg * 20;
+    const float* apt = X + (int64_t)(4 * akg) * NKc + 4 * am4;
+    const float* bpt[EB];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+        const int idx = tid + NTHR * e, kg = idx / BN, n = idx - kg * BN;
+        bpt[e] = wpad + (int64_t)n * KP + 4 * kg;
+    }
+    float4 ra[4], rb[EB];
+    auto stage = [&](int k0, float4 (&a4)[4], float4 (&b2)[EB]) {
+        if (a_thr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const float4*>(apt + (int64_t)(k0 + i) * NKc);
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) b2[e] = *reinterpret_cast<const float4*>(bpt[e] + k0);
+    };
+    auto commit = [&](int buf, const float4 (&a4)[4], const float4 (&b2)[EB]) {
+        if (a_thr) {
+            float* dst = &As[buf][(akg * NKc + 4 * am4) * 4];
+            *reinterpret_cast<float4*>(dst + 0) = make_float4(a4[0].x, a4[1].x, a4[2].x, a4[3].x);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(a4[0].y, a4[1].y, a4[2].y, a4[3].y);
+            *reinterpret_cast<float4*>(dst + 8) = make_float4(a4[0].z, a4[1].z, a4[2].z, a4[3].z);
+            *reinterpret_cast<float4*>(dst + 12) = make_float4(a4[0].w, a4[1].w, a4[2].w, a4[3].w);
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) *reinterpret_cast<float4*>(&Bs[buf][(tid + NTHR * e) * 4]) = b2[e];
+    };
+    f32x4 acc[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { acc[i][0] = f32x4{0, 0, 0, 0}; acc[i][1] = f32x4{0, 0, 0, 0}; }
+    const int kt = KP / 16;
+    stage(0, ra, rb);
+    commit(0, ra, rb);
+    __syncthreads();
+    for (int it = 0; it < kt; ++it) {
+        const int buf = it & 1;
+        stage((it + 1 < kt ? it + 1 : it) * 16, ra, rb);
+        f32x4 af[5], bf[2];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[buf][(lg * NKc + 16 * i + lj) * 4]);
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) bf[jn] = *reinterpret_cast<const f32x4*>(&Bs[buf][(lg * BN + 32 * wave + 16 * jn + lj) * 4]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                acc[i][0] = KM_MFMA(af[i][s], bf[0][s], acc[i][0]);
+                acc[i][1] = KM_MFMA(af[i][s], bf[1][s], acc[i][1]);
+            }
+        commit(buf ^ 1, ra, rb);
+        __syncthreads();
+    }
+    // bias, then LayerNorm over the D columns of each of the 80 rows (this lane: rows 16 i + 4 lg + r, columns n0, n0 + 16)
+    const int n0 = 32 * wave + lj;
+    {
+        const float bb0 = bias[n0], bb1 = bias[n0 + 16];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc[i][0][r] += bb0; acc[i][1][r] += bb1; }
+    }
+    float mean[5][4], rstd[5][4];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float* P = Ps[pass];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v;
+                if (pass == 0) v = acc[i][0][r] + acc[i][1][r];
+                else {
+                    const float d0 = acc[i][0][r] - mean[i][r], d1 = acc[i][1][r] - mean[i][r];
+                    v = d0 * d0 + d1 * d1;
+                }
+                v = row16_sum(v);
+                if (lj == 0) P[(16 * i + 4 * lg + r) * NW + wave] = v;
+            }
+        __syncthreads();
+        // row totals: wave w adds up the NW partials (in wave order) of rows w * RPW .. + RPW - 1, one row per lane
+        constexpr int RPW = NKc / NW;
+        if (lane < RPW) {
+            const int row = wave * RPW + lane;
+            float s = 0.f;
+            for (int w = 0; w < NW; ++w) s += P[row * NW + w];
+            Ts[pass][row] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(&Ts[pass][16 * i + 4 * lg]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (pass == 0) mean[i][r] = t[r] * (1.0f / D);
+                else rstd[i][r] = 1.0f / sqrtf(t[r] * (1.0f / D) + 1e-5f);
+            }
+        }
+    }
+    const float g0 = gam[n0], g1 = gam[n0 + 16], be0 = bet[n0], be1 = bet[n0 + 16];
+    float* Yb = Y + (int64_t)b * NKc * D;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* yr = Yb + (int64_t)(16 * i + 4 * lg + r) * D + n0;
+            yr[0] = (acc[i][0][r] - mean[i][r]) * rstd[i][r] * g0 + be0;
+            yr[16] = (acc[i][1][r] - mean[i][r]) * rstd[i][r] * g1 + be1;
+        }
+}
+
+static int core_generic_after_encoder(Context* c, int64_t B, const float* zemo, float* out, float* raw, float* attn, void* stream,
+                                      bool ln_done = false);
 
 // the generic core fed by the packed image of the front end (km_forward_audio on generic shapes)
 int launch_core_generic_packed(Context* c, const float* xp, int64_t B, const float* zemo, float* out, float* raw, float* attn,
@@ -519,10 +652,25 @@ int launch_core_generic_packed(Context* c, const float* xp, int64_t B, const flo
     const int d = c->d, NKk = c->NK, KP = (c->KT + 15) / 16 * 16;
     if (NKk != 80) return fail(KM_ERR_UNSUPPORTED, "packed encoder path needs 80 mel channels");
     float* Y = c->ws_generic;
-    hipLaunchKernelGGL(encoder_tn_kernel, dim3((unsigned)((d + 127) / 128), (unsigned)B), dim3(256), 0, (hipStream_t)stream, xp,
-                       dv(c, "wce_pad"), dv(c, "bce"), Y, d, KP);
+    static const bool fuse_ln = std::getenv("KM_GENERIC_NO_LN_FUSION") == nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    bool ln_done = fuse_ln;
+    if (fuse_ln && d == 512)
+        hipLaunchKernelGGL(encoder_ln_kernel<16>, dim3((unsigned)B), dim3(1024), 0, st, xp, dv(c, "wce_pad"), dv(c, "bce"), dv(c, "ln_g"),
+                           dv(c, "ln_b"), Y, KP);
+    else if (fuse_ln && d == 256)
+        hipLaunchKernelGGL(encoder_ln_kernel<8>, dim3((unsigned)B), dim3(512), 0, st, xp, dv(c, "wce_pad"), dv(c, "bce"), dv(c, "ln_g"),
+                           dv(c, "ln_b"), Y, KP);
+    else if (fuse_ln && d == 64)
+        hipLaunchKernelGGL(encoder_ln_kernel<2>, dim3((unsigned)B), dim3(128), 0, st, xp, dv(c, "wce_pad"), dv(c, "bce"), dv(c, "ln_g"),
+                           dv(c, "ln_b"), Y, KP);
+    else {
+        ln_done = false;
+        hipLaunchKernelGGL(encoder_tn_kernel, dim3((unsigned)((d + 127) / 128), (unsigned)B), dim3(256), 0, st, xp,
+                           dv(c, "wce_pad"), dv(c, "bce"), Y, d, KP);
+    }
     HIP_TRY(hipGetLastError());
-    return core_generic_after_encoder(c, B, zemo, out, raw, attn, stream);
+    return core_generic_after_encoder(c, B, zemo, out, raw, attn, stream, ln_done);
 }
 
 float* generic_packed_x(Context* c, int64_t B) {     // the packed-X slot behind the other intermediates of B windows
@@ -574,7 +722,8 @@ int launch_core_generic(Context* c, const float* mel, int64_t B, int64_t T_in, c
     return core_generic_after_encoder(c, B, zemo, out, raw, attn, stream);
 }
 
-static int core_generic_after_encoder(Context* c, int64_t B, const float* zemo, float* out, float* raw, float* attn, void* stream) {
+static int core_generic_after_encoder(Context* c, int64_t B, const float* zemo, float* out, float* raw, float* attn, void* stream,
+                                      bool ln_done) {
     const int d = c->d, H = c->H, hd = c->hd, DH = c->DH, NKk = c->NK;
     float* Y = c->ws_generic;
     float* V = Y + B * NKk * d;
@@ -582,8 +731,9 @@ static int core_generic_after_encoder(Context* c, int64_t B, const float* zemo, 
     float* O = S + B * H * 28 * NKk;
     float* Hd = O + B * 28 * d;
     GemmArgs g{};
-    hipLaunchKernelGGL(ln_rows_kernel, dim3((unsigned)((B * NKk + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Y,
-                       B * NKk, d, dv(c, "ln_g"), dv(c, "ln_b"), (float*)nullptr, (float*)nullptr);
+    if (!ln_done)
+        hipLaunchKernelGGL(ln_rows_kernel, dim3((unsigned)((B * NKk + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Y,
+                           B * NKk, d, dv(c, "ln_g"), dv(c, "ln_b"), (float*)nullptr, (float*)nullptr);
     // S[b] (H*28 x 80) = Qk (H*28 x d) Y_b^T: all heads of a window in ONE product -- the folded query matrix of every
     // head spans the full d, so the heads are just row blocks (28-row tiles would waste 56 % of a 64-row MFMA tile)
     g = GemmArgs{}; g.alpha = 1.f; g.batch2 = 1;
