@@ -398,6 +398,129 @@ __global__ __launch_bounds__(64) void decoder_tail_kernel(const float* __restric
     out[(int64_t)b * 52 + i] = fminf(fmaxf(wsum[i] * bs, 0.f), 1.f);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// attn_out_kernel<D>: everything after the softmax for one window in one workgroup (8 waves): O = P V per head straight
+// from the softmaxed scores and the value projection in L2 (A fragments as one b128 per 16 keys, B as four coalesced
+// dword rows), O -> LDS [32 q][D + 8], hidden^T = Wf^T O^T with the packed fold (wf_pg), ReLU . w2, cross-wave sum in
+// wave order, sigmoid, stream weights, clamp.  Replaces the batched P V product (windows x heads tiny GEMMs), the fold
+// GEMM and decoder_tail_kernel: 9.6 MFLOP per window that the three launches spent 107 us of latency on at C4.
+// D = 512 (decoder hidden 256 = 8 waves x 32 units); heads of 64 or 32 columns.
+// ---------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(512) void attn_out_kernel(const float* __restrict__ S, const float* __restrict__ V,
+                                                       const float* __restrict__ wf_pg, const float* __restrict__ bf,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       const float* __restrict__ zemo, const float* __restrict__ wsum,
+                                                       float* __restrict__ out, float* __restrict__ raw, int H) {
+    constexpr int NKc = 80, OS = D + 8, KB = D / 16, NWv = 8;
+    static_assert(D / 2 == 32 * NWv && D == 64 * NWv, "one wave per 64 output columns and per 32 hidden units");
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    float* Os = gsm;                   // [32][OS]
+    float* R2 = Os + 32 * OS;          // [NWv][32]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lg = lane >> 4, lj = lane & 15;
+    const int hd = D / H, tph = hd / 16;                   // column tiles per head: 4 (hd 64) or 2 (hd 32)
+    const float* Pb = S + (int64_t)b * H * 28 * NKc;
+    const float* Vb = V + (int64_t)b * NKc * D;
+    // ---- O[:, 64 w .. 64 w + 63] = P_h V_h for the head(s) that own these columns ----
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[mt][ct] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                 // two passes of two column tiles; a head spans one or both
+        const int h = (64 * wave + 32 * half) / hd;
+        f32x4 a[2][5];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int q = 16 * mt + lj;
+#pragma unroll
+            for (int kb = 0; kb < 5; ++kb)
+                a[mt][kb] = q < 28 ? *reinterpret_cast<const f32x4*>(Pb + ((int64_t)h * 28 + q) * NKc + 16 * kb + 4 * lg)
+                                   : f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int ct = 2 * half + c2;
+            const float* vcol = Vb + 64 * wave + 16 * ct + lj;
+#pragma unroll
+            for (int kb = 0; kb < 5; ++kb) {
+                float bv[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) bv[s] = vcol[(int64_t)(16 * kb + 4 * lg + s) * D];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc[0][ct] = KM_MFMA(a[0][kb][s], bv[s], acc[0][ct]);
+                    acc[1][ct] = KM_MFMA(a[1][kb][s], bv[s], acc[1][ct]);
+                }
+            }
+        }
+    }
+    (void)tph;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Os[(16 * mt + 4 * lg + r) * OS + 64 * wave + 16 * ct + lj] = acc[mt][ct][r];
+    __syncthreads();
+    // ---- hidden^T (256 x 32 q) = Wf^T O^T; wave w owns hidden units 32 w .. 32 w + 31 ----
+    f32x4 Z[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) { Z[rt][0] = f32x4{0, 0, 0, 0}; Z[rt][1] = f32x4{0, 0, 0, 0}; }
+    {
+        const f32x4* fp = reinterpret_cast<const f32x4*>(wf_pg) + (size_t)wave * 2 * KB * 64 + lane;
+#pragma unroll 4
+        for (int kb = 0; kb < KB; ++kb) {
+            const f32x4 w0 = fp[(size_t)kb * 64], w1 = fp[(size_t)(KB + kb) * 64];
+            const f32x4 o0 = *reinterpret_cast<const f32x4*>(Os + lj * OS + 16 * kb + 4 * lg);
+            const f32x4 o1 = *reinterpret_cast<const f32x4*>(Os + (16 + lj) * OS + 16 * kb + 4 * lg);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                Z[0][0] = KM_MFMA(w0[s], o0[s], Z[0][0]);
+                Z[0][1] = KM_MFMA(w0[s], o1[s], Z[0][1]);
+                Z[1][0] = KM_MFMA(w1[s], o0[s], Z[1][0]);
+                Z[1][1] = KM_MFMA(w1[s], o1[s], Z[1][1]);
+            }
+        }
+    }
+    {
+        float zp[2] = {0.f, 0.f};
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int hid = 32 * wave + 16 * rt + 4 * lg + r;
+                const float bfv = bf[hid], w2v = w2[hid];
+                zp[0] += fmaxf(Z[rt][0][r] + bfv, 0.f) * w2v;
+                zp[1] += fmaxf(Z[rt][1][r] + bfv, 0.f) * w2v;
+            }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            zp[qt] += __shfl_xor(zp[qt], 16);
+            zp[qt] += __shfl_xor(zp[qt], 32);
+        }
+        if (lg == 0) { R2[wave * 32 + lj] = zp[0]; R2[wave * 32 + 16 + lj] = zp[1]; }
+    }
+    __syncthreads();
+    if (tid < 52) {
+        const int slot = gen_mouth_slot(tid);
+        float z;
+        if (slot >= 0) {
+            z = b2[0];
+#pragma unroll
+            for (int w = 0; w < NWv; ++w) z += R2[w * 32 + slot];
+        } else {
+            z = zemo[b];
+        }
+        const float bs = 1.0f / (1.0f + expf(-z));
+        if (raw) raw[(int64_t)b * 52 + tid] = bs;
+        out[(int64_t)b * 52 + tid] = fminf(fmaxf(wsum[tid] * bs, 0.f), 1.f);
+    }
+}
+
 __global__ void gather_clip_logits_kernel(const float* __restrict__ zclip, float* __restrict__ zwin, int64_t nw, int64_t w0, int wpc) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nw) zwin[i] = zclip[(w0 + i) / wpc];
@@ -755,6 +878,20 @@ static int core_generic_after_encoder(Context* c, int64_t B, const float* zemo, 
     g.B = dv(c, "wv_raw"); g.b_rs = 1; g.b_cs = d;
     g.C = V; g.c_rs = d; g.M = (int)(B * NKk); g.N = d; g.K = d;
     if (int rc = launch_gemm(g, 1, stream)) return rc;
+    if (d == 512 && DH == 256 && NKk == 80 && (H == 8 || H == 16) && c->packed.count("wf_pg") &&
+        std::getenv("KM_GENERIC_NO_OUT_FUSION") == nullptr) {
+        // P V, the decoder fold and the tail in one kernel per window
+        constexpr int lds = (32 * (512 + 8) + 8 * 32) * (int)sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_out_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr = true;
+        }
+        hipLaunchKernelGGL(attn_out_kernel<512>, dim3((unsigned)B), dim3(512), lds, (hipStream_t)stream, S, V, dv(c, "wf_pg"), dv(c, "bf"),
+                           dv(c, "w2"), dv(c, "b2"), zemo, dv(c, "wsum"), out, raw, H);
+        HIP_TRY(hipGetLastError());
+        return KM_OK;
+    }
     // O[b][:, h*hd:(h+1)*hd] = P[b,h] V[b][:, h*hd:(h+1)*hd]
     g = GemmArgs{}; g.alpha = 1.f;
     g.A = S; g.a_rs = NKk; g.a_cs = 1; g.a_bs1 = (int64_t)H * 28 * NKk; g.a_bs2 = (int64_t)28 * NKk;

@@ -186,6 +186,21 @@ int finalize_host(Context* c) {
     put(c, "qk", to_f(Qk));                                        // (H, 28, d)
     put(c, "wf", to_f(Wf));                                        // (d, DH)
     put(c, "wf_t", to_f(transpose(Wf, d, DH)));                    // (DH, d): K-contiguous for gemm_nt_kernel
+    if (DH % 32 == 0 && d % 16 == 0) {
+        // decoder[0] fold as MFMA A-operand image for attn_out_kernel (km_generic.hip): wave w owns hidden units
+        // 32 w + 16 rt + j; [w][rt][kb][lane][s] = Wf[k = 16 kb + 4 g + s][hid]  (one coalesced 1 KiB load per wave)
+        const int NWv = DH / 32, KBv = d / 16;
+        std::vector<float> wf_pg((size_t)NWv * 2 * KBv * 64 * 4);
+        for (int w = 0; w < NWv; ++w)
+            for (int rt = 0; rt < 2; ++rt)
+                for (int kb = 0; kb < KBv; ++kb)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 4; ++e) {
+                            const int g = l >> 4, j = l & 15, k = 16 * kb + 4 * g + e;
+                            wf_pg[((((size_t)w * 2 + rt) * KBv + kb) * 64 + l) * 4 + e] = (float)Wf[(size_t)k * DH + 32 * w + 16 * rt + j];
+                        }
+        put(c, "wf_pg", std::move(wf_pg));
+    }
     {   // channel encoder weight with K padded to a multiple of 16 (zeros): rows stay 16-byte aligned and the long
         // and short-term columns form ONE contraction for encoder_tn_kernel (km_generic.hip)
         const int KT = c->KT, KP = (KT + 15) / 16 * 16;
