@@ -399,6 +399,86 @@ __global__ __launch_bounds__(64) void decoder_tail_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// scores_softmax_kernel<D>: P_b (H*28 x 80) = softmax_rows(Qk Y_b^T) for one window per workgroup (8 waves).  Wave w owns
+// row tiles 2 w' ... of the stacked heads (a row's 80 keys are 5 column tiles in ONE wave: the row maximum and sum are
+// an in-lane pass over the 5 tiles plus a DPP reduction over the 16 key lanes -- no exchange), A = the packed folded
+// query-key image (qk_pg, one coalesced KiB per wave and k block), B = Y rows straight from L2 (one b128 per lane and
+// 16 k).  Replaces the scores GEMM + softmax_rows_kernel and the round trip of the raw scores.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));
+    return v;
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void scores_softmax_kernel(const float* __restrict__ Y, const float* __restrict__ qk_pg,
+                                                             float* __restrict__ S, int rows /* H * 28 */) {
+    constexpr int NKc = 80, KB = D / 16;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lg = lane >> 4, lj = lane & 15;
+    const int MT = (rows + 15) >> 4;
+    const float* Yb = Y + (int64_t)b * NKc * D;
+    float* Sb = S + (int64_t)b * rows * NKc;
+    for (int mt0 = 2 * wave; mt0 < MT; mt0 += 16) {                        // two row tiles per pass (wave-uniform)
+        const bool two = mt0 + 1 < MT;
+        f32x4 acc[2][5];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) acc[i][nt] = f32x4{0, 0, 0, 0};
+        const f32x4* ap0 = reinterpret_cast<const f32x4*>(qk_pg) + (size_t)mt0 * KB * 64 + lane;
+        const f32x4* ap1 = ap0 + (two ? (size_t)KB * 64 : 0);
+        const float* yrow = Yb + (int64_t)lj * D + 4 * lg;
+        f32x4 a0 = ap0[0], a1 = ap1[0], yb[5];
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) yb[nt] = *reinterpret_cast<const f32x4*>(yrow + (int64_t)16 * nt * D);
+        for (int kb = 0; kb < KB; ++kb) {
+            const int kn = kb + 1 < KB ? kb + 1 : kb;
+            const f32x4 a0n = ap0[(size_t)kn * 64], a1n = ap1[(size_t)kn * 64];
+            f32x4 ybn[5];
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) ybn[nt] = *reinterpret_cast<const f32x4*>(yrow + (int64_t)16 * nt * D + 16 * kn);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) {
+                    acc[0][nt] = KM_MFMA(a0[s], yb[nt][s], acc[0][nt]);
+                    acc[1][nt] = KM_MFMA(a1[s], yb[nt][s], acc[1][nt]);
+                }
+            a0 = a0n; a1 = a1n;
+#pragma unroll
+            for (int nt = 0; nt < 5; ++nt) yb[nt] = ybn[nt];
+        }
+        // softmax over the 80 keys of every row: C/D layout puts row 4 lg + r of a tile in lanes lj = 0..15 x 5 tiles
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i == 1 && !two) break;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float m = acc[i][0][r];
+#pragma unroll
+                for (int nt = 1; nt < 5; ++nt) m = fmaxf(m, acc[i][nt][r]);
+                m = row16_max(m);
+                float e[5], sum = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) { e[nt] = __builtin_amdgcn_exp2f((acc[i][nt][r] - m) * 1.44269504088896341f); sum += e[nt]; }
+                sum = row16_sum(sum);
+                const float inv = 1.0f / sum;
+                const int row = 16 * (mt0 + i) + 4 * lg + r;
+                if (row < rows) {
+#pragma unroll
+                    for (int nt = 0; nt < 5; ++nt) Sb[(int64_t)row * NKc + 16 * nt + lj] = e[nt] * inv;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // attn_out_kernel<D>: everything after the softmax for one window in one workgroup (8 waves): O = P V per head straight
 // from the softmaxed scores and the value projection in L2 (A fragments as one b128 per 16 keys, B as four coalesced
 // dword rows), O -> LDS [32 q][D + 8], hidden^T = Wf^T O^T with the packed fold (wf_pg), ReLU . w2, cross-wave sum in
@@ -857,6 +937,11 @@ static int core_generic_after_encoder(Context* c, int64_t B, const float* zemo, 
     if (!ln_done)
         hipLaunchKernelGGL(ln_rows_kernel, dim3((unsigned)((B * NKk + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Y,
                            B * NKk, d, dv(c, "ln_g"), dv(c, "ln_b"), (float*)nullptr, (float*)nullptr);
+    const bool fused_scores = d == 512 && NKk == 80 && c->packed.count("qk_pg") && std::getenv("KM_GENERIC_NO_SCORE_FUSION") == nullptr;
+    if (fused_scores) {
+        hipLaunchKernelGGL(scores_softmax_kernel<512>, dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream, Y, dv(c, "qk_pg"), S, H * 28);
+        HIP_TRY(hipGetLastError());
+    }
     // S[b] (H*28 x 80) = Qk (H*28 x d) Y_b^T: all heads of a window in ONE product -- the folded query matrix of every
     // head spans the full d, so the heads are just row blocks (28-row tiles would waste 56 % of a 64-row MFMA tile)
     g = GemmArgs{}; g.alpha = 1.f; g.batch2 = 1;
@@ -864,9 +949,11 @@ static int core_generic_after_encoder(Context* c, int64_t B, const float* zemo, 
     g.B = Y; g.b_rs = 1; g.b_cs = d; g.b_bs1 = (int64_t)NKk * d;
     g.C = S; g.c_rs = NKk; g.c_bs1 = (int64_t)H * 28 * NKk;
     g.M = H * 28; g.N = NKk; g.K = d;
-    if (int rc = launch_gemm(g, (int)B, stream)) return rc;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((B * H * 28 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S,
-                       B * H * 28, NKk);
+    if (!fused_scores) {
+        if (int rc = launch_gemm(g, (int)B, stream)) return rc;
+        hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((B * H * 28 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S,
+                           B * H * 28, NKk);
+    }
     if (attn) {
         const int64_t n = B * 28 * NKk;
         hipLaunchKernelGGL(head_mean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S, attn,

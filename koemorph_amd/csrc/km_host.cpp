@@ -201,6 +201,20 @@ int finalize_host(Context* c) {
                         }
         put(c, "wf_pg", std::move(wf_pg));
     }
+    if (d % 16 == 0) {
+        // folded query-key matrix of ALL heads as MFMA A-operand image for scores_softmax_kernel: row tile mt covers rows
+        // 16 mt .. 16 mt + 15 of the (H * 28, d) matrix (zero rows past the end); [mt][kb][lane][s] = Qk[16 mt + j][16 kb + 4 g + s]
+        const int rows = H * NQ, MT = (rows + 15) / 16, KBv = d / 16;
+        std::vector<float> qk_pg((size_t)MT * KBv * 64 * 4, 0.0f);
+        for (int mt = 0; mt < MT; ++mt)
+            for (int kb = 0; kb < KBv; ++kb)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 4; ++e) {
+                        const int g = l >> 4, j = l & 15, r = 16 * mt + j, k = 16 * kb + 4 * g + e;
+                        if (r < rows) qk_pg[(((size_t)mt * KBv + kb) * 64 + l) * 4 + e] = (float)Qk[(size_t)r * d + k];
+                    }
+        put(c, "qk_pg", std::move(qk_pg));
+    }
     {   // channel encoder weight with K padded to a multiple of 16 (zeros): rows stay 16-byte aligned and the long
         // and short-term columns form ONE contraction for encoder_tn_kernel (km_generic.hip)
         const int KT = c->KT, KP = (KT + 15) / 16 * 16;
