@@ -417,7 +417,12 @@ int km_forward_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L, 
     if (!c->fused_ok) {     // generic shapes: staged front end, GEMM-chain core, stand-alone EMA
         if (!c->ws_generic) return fail(KM_ERR_WORKSPACE, "generic workspace missing: call km_reserve after km_finalize");
         if (int rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, stream)) return rc;
-        if (c->NK == 80 && std::getenv("KM_GENERIC_STAGED") == nullptr) {
+        if (generic_core_takes_power(c) && std::getenv("KM_GENERIC_STAGED") == nullptr) {
+            // power-mel -> dB conversion inside the encoder's tile staging: no log-mel image at all
+            if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, L, stream)) return rc;
+            if (int rc = launch_core_generic_power(c, c->mel_plans[0], B, n_frames, c->ws_zemo, out_dev, nullptr,
+                                                   nullptr, stream)) return rc;
+        } else if (c->NK == 80 && std::getenv("KM_GENERIC_STAGED") == nullptr) {
             // log-mel written straight into the packed encoder input; long + short-term rows in one contraction
             float* xp = generic_packed_x(c, B);
             if (int rc = launch_mel_packed(c, c->mel_plans[0], audio_dev, B, L, xp, c->T, (c->KT + 15) / 16 * 16, stream)) return rc;

@@ -162,6 +162,9 @@ int launch_gather_clip_logits(Context* c, const float* zclip, float* zwin, int64
 int launch_core_generic_packed(Context* c, const float* xp, int64_t B, const float* zemo, float* out, float* raw, float* attn,
                                void* stream);
 float* generic_packed_x(Context* c, int64_t B);
+bool generic_core_takes_power(Context* c);
+int launch_core_generic_power(Context* c, MelPlan* plan, int64_t B, int64_t n_frames, const float* zemo, float* out,
+                              float* raw, float* attn, void* stream);
 int launch_core_generic(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short, const float* zemo,
                         float* out, float* raw, float* attn, void* stream);
 
