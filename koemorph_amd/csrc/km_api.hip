@@ -416,10 +416,14 @@ int km_forward_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L, 
                     (long long)B, (long long)L);
     if (!c->fused_ok) {     // generic shapes: staged front end, GEMM-chain core, stand-alone EMA
         if (!c->ws_generic) return fail(KM_ERR_WORKSPACE, "generic workspace missing: call km_reserve after km_finalize");
-        if (int rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, stream)) return rc;
-        if (generic_core_takes_power(c) && std::getenv("KM_GENERIC_STAGED") == nullptr) {
+        const bool power_path = generic_core_takes_power(c) && std::getenv("KM_GENERIC_STAGED") == nullptr;
+        const bool fuse_emo = power_path && mel_fuses_emotion(c, c->mel_plans[0]);   // emotion logits inside the front-end kernel
+        if (!fuse_emo)
+            if (int rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, stream)) return rc;
+        if (power_path) {
             // power-mel -> dB conversion inside the encoder's tile staging: no log-mel image at all
-            if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, L, stream)) return rc;
+            if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, L, stream, 0, 0, 0, 1, nullptr, nullptr,
+                                          fuse_emo ? emotion_dev : nullptr, fuse_emo ? c->ws_zemo : nullptr)) return rc;
             if (int rc = launch_core_generic_power(c, c->mel_plans[0], B, n_frames, c->ws_zemo, out_dev, nullptr,
                                                    nullptr, stream)) return rc;
         } else if (c->NK == 80 && std::getenv("KM_GENERIC_STAGED") == nullptr) {

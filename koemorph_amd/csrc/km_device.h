@@ -69,6 +69,7 @@ struct EmoArgs {
     const float *wee_t = nullptr /* (256, 256): rows >= ED are zero */, *bee = nullptr, *lg = nullptr, *lb = nullptr, *we2 = nullptr, *be2 = nullptr,
                 *w2 = nullptr, *b2 = nullptr;
     float* zemo = nullptr;        // (B)
+    int d = 256, DH = 128;        // 256 / 128: emotion_window_d256 (wee_t is then the zero-padded (256, 256) image)
 };
 
 // scratch: 1536 floats of LDS.  Must be called by all 512 threads of the workgroup (contains barriers).
@@ -159,6 +160,86 @@ __device__ __forceinline__ void emotion_window_d256(const EmoArgs& e, int64_t b,
 #pragma unroll
             for (int q = 0; q < 8; ++q) hsum += part[q * DH + mm];
             s += fmaxf(hsum, 0.f) * e.w2[mm];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) e.zemo[b] = s + e.b2[0];
+    }
+    __syncthreads();   // scratch is free again
+}
+
+// The same stream for the other shapes (d_model, decoder hidden: powers of two in [64, 1024]; emotion_dim <= 256), again
+// for a 512-thread workgroup.  Both layers read their weights as float4 (four adjacent output columns per thread) with
+// the contraction index split over 512 / (columns / 4) thread groups, 16 independent 16-byte loads in flight per thread;
+// partial sums meet in LDS in group order (deterministic).  wee_t is (ED, d), we2 is (d, DH).
+// scratch: 256 + d + 2048 floats of LDS.  Must be called by all 512 threads of the workgroup (contains barriers).
+struct EmoShape { int d = 0, DH = 0; };
+
+__device__ __forceinline__ void emotion_layer_f4(const float* __restrict__ w, int K, int N, const float* x, float* part) {
+    const int tid = threadIdx.x;
+    const int tpr = N >> 2;                        // threads per weight row
+    const int G = 512 / tpr;                       // k groups
+    const int c4 = tid & (tpr - 1), g = tid / tpr;
+    const int kc = (K + G - 1) / G;
+    const int k0 = g * kc, k1 = (k0 + kc) < K ? (k0 + kc) : K;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* wp = w + 4 * c4;
+    for (int k = k0; k < k1; k += 16) {
+        float4 wv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wv[u] = (k + u) < k1 ? *reinterpret_cast<const float4*>(wp + (size_t)(k + u) * N) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float xv = (k + u) < k1 ? x[k + u] : 0.f;
+            acc.x = fmaf(xv, wv[u].x, acc.x); acc.y = fmaf(xv, wv[u].y, acc.y);
+            acc.z = fmaf(xv, wv[u].z, acc.z); acc.w = fmaf(xv, wv[u].w, acc.w);
+        }
+    }
+    *reinterpret_cast<float4*>(part + g * N + 4 * c4) = acc;
+}
+
+__device__ __forceinline__ void emotion_window_generic(const EmoArgs& e, const EmoShape sh, int64_t b, float* scratch) {
+    const int d = sh.d, DH = sh.DH;
+    float* emo_s = scratch;           // [256]
+    float* e1 = scratch + 256;        // [d]
+    float* part = e1 + d;             // [512 * 4]: [G1][d], then [G2][DH]
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 256) emo_s[tid] = tid < e.ED ? e.emo[b * e.ED + tid] : 0.f;
+    __syncthreads();
+    emotion_layer_f4(e.wee_t, e.ED, d, emo_s, part);
+    __syncthreads();
+    {
+        const int G1 = 2048 / d;
+        for (int n = tid; n < d; n += 512) {
+            float s = e.bee[n];
+            for (int g = 0; g < G1; ++g) s += part[g * d + n];
+            e1[n] = s;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {   // LayerNorm (eps 1e-5), two-pass, one wave
+        float s = 0.f;
+        for (int n = lane; n < d; n += 64) s += e1[n];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / d;
+        float v = 0.f;
+        for (int n = lane; n < d; n += 64) { const float t = e1[n] - mean; v += t * t; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        const float rstd = 1.0f / sqrtf(v / d + 1e-5f);
+        for (int n = lane; n < d; n += 64) e1[n] = (e1[n] - mean) * rstd * e.lg[n] + e.lb[n];
+    }
+    __syncthreads();
+    emotion_layer_f4(e.we2, d, DH, e1, part);
+    __syncthreads();
+    if (tid < 64) {   // ReLU, dot with w2
+        const int G2 = 2048 / DH;
+        float s = 0.f;
+        for (int m = lane; m < DH; m += 64) {
+            float h = e.be2[m];
+            for (int g = 0; g < G2; ++g) h += part[g * DH + m];
+            s += fmaxf(h, 0.f) * e.w2[m];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);

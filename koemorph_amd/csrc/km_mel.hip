@@ -550,7 +550,10 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
 
     // The emotion stream of this window (0.2 MFLOP, latency bound, independent of the audio) rides in the workgroup
     // that has one chunk less to do than its sibling: no separate launch, no exposed latency.
-    if (a.emo.emo && blockIdx.x == gridDim.x - 1) emotion_window_d256(a.emo, gw, pw);
+    if (a.emo.emo && blockIdx.x == gridDim.x - 1) {
+        if (a.emo.d == 256 && a.emo.DH == 128) emotion_window_d256(a.emo, gw, pw);
+        else emotion_window_generic(a.emo, EmoShape{a.emo.d, a.emo.DH}, gw, pw);
+    }
 
     for (int i = tid; i < a.fb4_nnz; i += NT) fbw[i] = 0.25f * a.fb4_weight[i];
     if (tid < FPB * 15) pw[(tid / 15) * NFS + 513 + tid % 15] = 0.f;     // row padding read by the 16-bin mel trips
@@ -816,7 +819,10 @@ static LogParams log_params(const km_mel_config& m) {
 // true when launch_mel_power can compute the per-window emotion logits inside the front-end kernel
 bool mel_fuses_emotion(Context* c, MelPlan* p) {
     static const bool use_rp = std::getenv("KM_MEL_TWO_FRAME") == nullptr && std::getenv("KM_EMOTION_SEPARATE") == nullptr;
-    return use_rp && p->cfg.n_fft == 1024 && c->kind == 0 && c->d == 256 && c->DH == 128 && c->ED <= 256;
+    auto pow2 = [](int v) { return v >= 64 && v <= 1024 && (v & (v - 1)) == 0; };
+    static const bool generic_ok = std::getenv("KM_EMOTION_GENERIC_SEPARATE") == nullptr;
+    const bool d256 = c->d == 256 && c->DH == 128;
+    return use_rp && p->cfg.n_fft == 1024 && c->kind == 0 && c->ED <= 256 && (d256 || (generic_ok && pow2(c->d) && pow2(c->DH)));
 }
 
 int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, void* stream,
@@ -871,7 +877,8 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
             return fail(KM_ERR_UNSUPPORTED, "launch_mel_power: emotion fusion requested for an unsupported configuration");
         auto dvp = [&](const char* name) { return (const float*)c->packed.at(name).dev; };
         a.emo.emo = emotion; a.emo.ED = c->ED; a.emo.zemo = zemo;
-        a.emo.wee_t = dvp("wee_t256"); a.emo.bee = dvp("bee"); a.emo.lg = dvp("eln_g"); a.emo.lb = dvp("eln_b");
+        a.emo.d = c->d; a.emo.DH = c->DH;
+        a.emo.wee_t = (c->d == 256 && c->DH == 128) ? dvp("wee_t256") : dvp("wee_t"); a.emo.bee = dvp("bee"); a.emo.lg = dvp("eln_g"); a.emo.lb = dvp("eln_b");
         a.emo.we2 = dvp("we2"); a.emo.be2 = dvp("be2"); a.emo.w2 = dvp("w2"); a.emo.b2 = dvp("b2");
     }
     // persistent over frame chunks: each workgroup walks chunks blockIdx.x, +gridDim.x, ... of its window with the
