@@ -402,9 +402,13 @@ __global__ __launch_bounds__(64) void decoder_tail_kernel(const float* __restric
 // scores_softmax_kernel<D>: P_b (H*28 x 80) = softmax_rows(Qk Y_b^T) for one window per workgroup (8 waves).  Wave w owns
 // row tiles 2 w' ... of the stacked heads (a row's 80 keys are 5 column tiles in ONE wave: the row maximum and sum are
 // an in-lane pass over the 5 tiles plus a DPP reduction over the 16 key lanes -- no exchange), A = the packed folded
-// query-key image (qk_pg, one coalesced KiB per wave and k block), B = Y rows straight from L2 (one b128 per lane and
-// 16 k).  Replaces the scores GEMM + softmax_rows_kernel and the round trip of the raw scores.
+// query-key image (qk_pg, one coalesced KiB per wave and k block, k block outermost so a workgroup's fetch per step is
+// one contiguous run), B = Y rows staged through LDS in 64-k chunks.  Replaces the scores GEMM + softmax_rows_kernel
+// and the round trip of the raw scores.
 // ---------------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 as_f32x4(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
+
 __device__ __forceinline__ float row16_max(float v) {
     v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
     v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
@@ -416,43 +420,90 @@ __device__ __forceinline__ float row16_max(float v) {
 template <int D>
 __global__ __launch_bounds__(512) void scores_softmax_kernel(const float* __restrict__ Y, const float* __restrict__ qk_pg,
                                                              float* __restrict__ S, int rows /* H * 28 */) {
-    constexpr int NKc = 80, KB = D / 16;
+    constexpr int NKc = 80, KB = D / 16, CH = 4, NCH = KB / CH, QS = NKc + 1;
+    static_assert(KB % CH == 0 && CH % 2 == 0, "k blocks come in chunks of four");
+    // Y_b reaches the MFMAs through LDS in chunks of 64 k ([k / 4][row, padded to 81][k % 4]: conflict-free b128 on both
+    // sides), double buffered: read from L2 once per workgroup instead of once per wave (7 x 160 KB per window before).
+    __shared__ __attribute__((aligned(16))) float Ys[2][16 * QS * 4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lg = lane >> 4, lj = lane & 15;
     const int MT = (rows + 15) >> 4;
     const float* Yb = Y + (int64_t)b * NKc * D;
     float* Sb = S + (int64_t)b * rows * NKc;
-    for (int mt0 = 2 * wave; mt0 < MT; mt0 += 16) {                        // two row tiles per pass (wave-uniform)
-        const bool two = mt0 + 1 < MT;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Yb), 0, (unsigned)(NKc * D * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qk_pg), 0, (unsigned)(MT * KB * 1024), 0x00020000);
+    constexpr unsigned OOB = 0x7fffffffu;
+    u32x4 yst[3];
+    auto ystage = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int idx = tid + 512 * j, row = idx >> 4, q = idx & 15;
+            yst[j] = __builtin_amdgcn_raw_buffer_load_b128(yr, idx < NKc * 16 ? (unsigned)((row * D + 64 * ch + 4 * q) * 4) : OOB, 0, 0);
+        }
+    };
+    auto ycommit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int idx = tid + 512 * j, row = idx >> 4, q = idx & 15;
+            asm volatile("" ::"v"(yst[j]));     // unconditional use: the load stays out of the branch
+            if (idx < NKc * 16) *reinterpret_cast<u32x4*>(&Ys[buf][(q * QS + row) * 4]) = yst[j];
+        }
+    };
+    const int npass = (MT + 15) >> 4;
+    for (int pass = 0; pass < npass; ++pass) {                             // two row tiles per wave and pass
+        const int mt0 = 16 * pass + 2 * wave;
+        const bool active = mt0 < MT, two = mt0 + 1 < MT;                  // wave-uniform
         f32x4 acc[2][5];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int nt = 0; nt < 5; ++nt) acc[i][nt] = f32x4{0, 0, 0, 0};
-        const f32x4* ap0 = reinterpret_cast<const f32x4*>(qk_pg) + (size_t)mt0 * KB * 64 + lane;
-        const f32x4* ap1 = ap0 + (two ? (size_t)KB * 64 : 0);
-        const float* yrow = Yb + (int64_t)lj * D + 4 * lg;
-        f32x4 a0 = ap0[0], a1 = ap1[0], yb[5];
+        // qk_pg is [k block][row tile][lane][4]: what the workgroup's waves fetch for one k block is ONE contiguous
+        // 1 KiB x MT run (with the row tile outermost the 14 runs sat 32 KiB apart -- one L2 channel for all of them)
+        const unsigned a0o = (unsigned)((mt0 * 64 + lane) * 16), a1o = a0o + (two ? 1024u : 0u);
+        auto lda = [&](unsigned o, int kb) { return as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(ar, active ? o + (unsigned)(kb * MT) * 1024u : OOB, 0, 0)); };
+        auto ldy = [&](int buf, int kk, int nt) { return *reinterpret_cast<const f32x4*>(&Ys[buf][((4 * kk + lg) * QS + 16 * nt + lj) * 4]); };
+        ystage(0);
+        f32x4 av[2][2], yb[2][5];
+        av[0][0] = lda(a0o, 0); av[0][1] = lda(a1o, 0);
+        ycommit(0);
+        __syncthreads();
 #pragma unroll
-        for (int nt = 0; nt < 5; ++nt) yb[nt] = *reinterpret_cast<const f32x4*>(yrow + (int64_t)16 * nt * D);
-        for (int kb = 0; kb < KB; ++kb) {
-            const int kn = kb + 1 < KB ? kb + 1 : kb;
-            const f32x4 a0n = ap0[(size_t)kn * 64], a1n = ap1[(size_t)kn * 64];
-            f32x4 ybn[5];
+        for (int nt = 0; nt < 5; ++nt) yb[0][nt] = ldy(0, 0, nt);
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int buf = ch & 1;
+            const bool more = ch + 1 < NCH;
+            if (more) ystage(ch + 1);
 #pragma unroll
-            for (int nt = 0; nt < 5; ++nt) ybn[nt] = *reinterpret_cast<const f32x4*>(yrow + (int64_t)16 * nt * D + 16 * kn);
+            for (int kk = 0; kk < CH; ++kk) {
+                const int cur = kk & 1, nxt = cur ^ 1, kb = CH * ch + kk;
+                const int kn = kb + 1 < KB ? kb + 1 : kb;
+                av[nxt][0] = lda(a0o, kn); av[nxt][1] = lda(a1o, kn);
+                if (kk + 1 < CH) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int nt = 0; nt < 5; ++nt) {
-                    acc[0][nt] = KM_MFMA(a0[s], yb[nt][s], acc[0][nt]);
-                    acc[1][nt] = KM_MFMA(a1[s], yb[nt][s], acc[1][nt]);
+                    for (int nt = 0; nt < 5; ++nt) yb[nxt][nt] = ldy(buf, kk + 1, nt);
                 }
-            a0 = a0n; a1 = a1n;
+                __builtin_amdgcn_sched_barrier(0);
+                if (active) {
 #pragma unroll
-            for (int nt = 0; nt < 5; ++nt) yb[nt] = ybn[nt];
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int nt = 0; nt < 5; ++nt) {
+                            acc[0][nt] = KM_MFMA(av[cur][0][s], yb[cur][nt][s], acc[0][nt]);
+                            acc[1][nt] = KM_MFMA(av[cur][1][s], yb[cur][nt][s], acc[1][nt]);
+                        }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) ycommit(buf ^ 1);
+            __syncthreads();
+            if (more) {
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) yb[0][nt] = ldy(buf ^ 1, 0, nt);
+            }
         }
+        if (!active) continue;
         // softmax over the 80 keys of every row: C/D layout puts row 4 lg + r of a tile in lanes lj = 0..15 x 5 tiles
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -875,8 +926,6 @@ __global__ __launch_bounds__(256) void encoder_tn_kernel(const float* __restrict
 // FUSE_DB: the input is the front end's POWER-mel (B, n_frames, 80) + window maxima; the dB / log conversion and the
 // row packing (T long rows, 3 short-term rows, zero rows) happen while a tile is staged, so no packed log-mel image is
 // written and read back (mel_log_packed_kernel disappears from km_forward_audio).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
 struct EncSrc {
     const float* melpow; const unsigned* melmax; int n_frames, T; LogParams lp;
 };

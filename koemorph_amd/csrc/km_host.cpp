@@ -211,7 +211,7 @@ int finalize_host(Context* c) {
                 for (int l = 0; l < 64; ++l)
                     for (int e = 0; e < 4; ++e) {
                         const int g = l >> 4, j = l & 15, r = 16 * mt + j, k = 16 * kb + 4 * g + e;
-                        if (r < rows) qk_pg[(((size_t)mt * KBv + kb) * 64 + l) * 4 + e] = (float)Qk[(size_t)r * d + k];
+                        if (r < rows) qk_pg[(((size_t)kb * MT + mt) * 64 + l) * 4 + e] = (float)Qk[(size_t)r * d + k];
                     }
         put(c, "qk_pg", std::move(qk_pg));
     }
