@@ -108,5 +108,69 @@ def main():
         print(f"{c['name']}: bs[0,:3]={rec['blendshapes'][0,:3]}  ->  {os.path.getsize(path)/1024:.1f} KB")
 
 
+# ---- legacy KoeMorphModel (src/model/gaussian_face.py): two chained frames per case ------------------------------
+KOEMORPH_CASES = [
+    dict(name="koemorph_d64_T20", cfg=dict(d_model=64, num_heads=4, num_encoder_layers=1, num_attention_layers=2,
+                                           decoder_hidden_dim=32, decoder_layers=2, emotion_dim=24), B=3, T=20, seed=61),
+    dict(name="koemorph_d256_T30_default", cfg=dict(), B=2, T=30, seed=62),
+    dict(name="koemorph_d128_T75_open", cfg=dict(d_model=128, num_heads=8, num_encoder_layers=2, num_attention_layers=3,
+                                                 decoder_hidden_dim=64, decoder_layers=1, decoder_activation="relu",
+                                                 causal=False, window_size=None, use_constraints=False, emotion_dim=88),
+         B=2, T=75, seed=63),
+    # default mask at T = 256: rows >= 5 have every key masked -> NaN in the reference (SURVEY: "default config is broken")
+    dict(name="koemorph_d64_T256_masked", cfg=dict(d_model=64, num_heads=4, num_encoder_layers=1, num_attention_layers=1,
+                                                   decoder_hidden_dim=32, decoder_layers=1, emotion_dim=24), B=1, T=256, seed=64),
+]
+
+
+def koemorph_inputs(synth, seed, B, T, mel_dim, emotion_dim):
+    return synth.normal(seed * 7 + 1, (B, T, mel_dim), std=1.0), synth.normal(seed * 7 + 2, (B, T, emotion_dim), std=1.0)
+
+
+def main_koemorph():
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    from src.model.gaussian_face import KoeMorphModel  # reference, read-only
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from koemorph_amd import synth
+    from oracle.koemorph_model import KoeMorphConfig, make_koemorph_params
+
+    torch.set_num_threads(4)
+    for c in KOEMORPH_CASES:
+        if os.environ.get("KM_GOLDEN_ONLY") and os.environ["KM_GOLDEN_ONLY"] not in c["name"]:
+            continue
+        kc = KoeMorphConfig(**c["cfg"])
+        params = make_koemorph_params(c["seed"], kc)
+        m = KoeMorphModel(mel_dim=kc.mel_dim, emotion_dim=kc.emotion_dim, d_model=kc.d_model, d_query=kc.d_model,
+                          num_heads=kc.num_heads, num_encoder_layers=kc.num_encoder_layers,
+                          num_attention_layers=kc.num_attention_layers, decoder_hidden_dim=kc.decoder_hidden_dim,
+                          decoder_layers=kc.decoder_layers, decoder_activation=kc.decoder_activation,
+                          use_temporal_smoothing=kc.use_temporal_smoothing, use_constraints=kc.use_constraints,
+                          causal=kc.causal, window_size=kc.window_size).eval()
+        sd = m.state_dict()
+        missing = [k for k in sd if k not in params]          # buffers of the smoother / constraints keep their initial values
+        assert all(k.startswith(("temporal_smoother.", "constraints.")) for k in missing), missing
+        sd.update({k: torch.from_numpy(np.asarray(v)) for k, v in params.items()})
+        m.load_state_dict(sd, strict=True)
+        m.reset_temporal_state()
+        mel, emo = koemorph_inputs(synth, c["seed"], c["B"], c["T"], kc.mel_dim, kc.emotion_dim)
+        mel2, emo2 = koemorph_inputs(synth, c["seed"] + 100, c["B"], c["T"], kc.mel_dim, kc.emotion_dim)
+        rec = {"config": json.dumps(dict(cfg=kc.to_dict(), B=c["B"], T=c["T"], seed=c["seed"]))}
+        with torch.no_grad():
+            o1 = m(torch.from_numpy(mel), torch.from_numpy(emo), return_attention=True)
+            o2 = m(torch.from_numpy(mel2), torch.from_numpy(emo2), prev_blendshapes=o1["blendshapes"], return_attention=True)
+        for tag, o in (("f1", o1), ("f2", o2)):
+            rec[tag + "/blendshapes"] = o["blendshapes"].numpy()
+            rec[tag + "/raw_blendshapes"] = o["raw_blendshapes"].numpy()
+            for li, w in enumerate(o["attention_weights"]):
+                rec[f"{tag}/attn{li}"] = w.numpy()[:, :, ::13, :].copy()        # query rows 0, 13, 26, 39 of every head
+        path = os.path.join(OUT, c["name"] + ".npz")
+        np.savez_compressed(path, **rec)
+        print(f"{c['name']}: f1[0,:3]={rec['f1/blendshapes'][0,:3]} f2[0,:3]={rec['f2/blendshapes'][0,:3]} -> {os.path.getsize(path)/1024:.1f} KB")
+
+
 if __name__ == "__main__":
-    main()
+    if os.environ.get("KM_GOLDEN_GROUP", "all") in ("all", "core"):
+        main()
+    if os.environ.get("KM_GOLDEN_GROUP", "all") in ("all", "koemorph"):
+        main_koemorph()

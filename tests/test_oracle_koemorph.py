@@ -1,0 +1,61 @@
+"""Pin oracle/koemorph_model.py to golden vectors captured from the reference's own KoeMorphModel
+(/root/reference/src/model/gaussian_face.py, run by oracle/gen_golden.py in the build container)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from koemorph_amd import synth
+from oracle import koemorph_model as km
+from oracle.gen_golden import koemorph_inputs
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "koemorph_*.npz")))
+
+
+def load_case(path):
+    z = np.load(path)
+    meta = json.loads(str(z["config"]))
+    cfg = km.KoeMorphConfig(**meta["cfg"])
+    params = km.make_koemorph_params(meta["seed"], cfg)
+    f1 = koemorph_inputs(synth, meta["seed"], meta["B"], meta["T"], cfg.mel_dim, cfg.emotion_dim)
+    f2 = koemorph_inputs(synth, meta["seed"] + 100, meta["B"], meta["T"], cfg.mel_dim, cfg.emotion_dim)
+    return z, cfg, params, f1, f2
+
+
+def assert_same(got, want, atol):
+    assert got.shape == want.shape
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    np.testing.assert_allclose(got[ok], want[ok], atol=atol, rtol=0)
+
+
+def test_golden_files_present():
+    assert len(GOLDEN) == 4
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_oracle_matches_reference_two_frames(path):
+    z, cfg, params, (mel1, emo1), (mel2, emo2) = load_case(path)
+    o1 = km.koemorph_forward(params, cfg, mel1, emo1)
+    o2 = km.koemorph_forward(params, cfg, mel2, emo2, prev_blendshapes=o1["blendshapes"], smoother_state=o1["smoother_state"])
+    for tag, o in (("f1", o1), ("f2", o2)):
+        assert_same(o["blendshapes"], z[tag + "/blendshapes"], 2e-6)
+        assert_same(o["raw_blendshapes"], z[tag + "/raw_blendshapes"], 2e-6)
+        for li, w in enumerate(o["attention_weights"]):
+            assert_same(w[:, :, ::13, :], z[f"{tag}/attn{li}"], 2e-6)
+
+
+def test_param_count_matches_survey():
+    # 4 427 573 parameters at the defaults with d_query = 256
+    n = sum(int(np.prod(s)) for _, s in km.param_shapes(km.KoeMorphConfig()))
+    assert n == 4427573
+
+
+def test_mask_rows():
+    m = km.attention_mask(52, 30, True, 30)
+    assert not m[0, 0] and m[0, 1:].all()                  # causal: query 0 sees key 0 only
+    assert (~m[51]).sum() == 16                            # key_pos 29: window [14, 30)
+    full = km.attention_mask(52, 256, True, 30)
+    assert full[5:].all() and not full[:5].all(axis=1).any()    # rows >= 5: every key masked -> NaN rows in the reference
