@@ -282,6 +282,45 @@ int km_legacy_create(const km_legacy_config* cfg, km_handle* out);
 int km_legacy_forward(km_handle h, const float* audio_dev, int64_t B, int64_t L, float* out_dev, void* stream);
 int km_legacy_forward_mel(km_handle h, const float* mel_dev, int64_t B, int64_t T_mel, float* out_dev, void* stream);
 
+/* ---- legacy multi-layer model: KoeMorphModel (src/model/gaussian_face.py:29-268) -----------------------
+ * The model behind create_koemorph_model / scripts/rt.py:283-304, eval mode: DualStreamEncoder on both feature streams
+ * (Linear + ReLU + LayerNorm, then num_encoder_layers post-norm nn.TransformerEncoderLayer with 8 heads, 4 d feed-forward,
+ * exact GELU; src/model/dual_stream_attention.py:296-390), their average, BlendshapeQueryEmbedding conditioned on the
+ * previous frame (src/model/attention.py:481-514), num_attention_layers x [MultiHeadCrossAttention with the causal and
+ * window masks of attention.py:208-246, residual, LayerNorm], BlendshapeDecoder (diagonal of output_proj, sigmoid,
+ * 0.9 / 0.1 mix with the previous frame; src/model/decoder.py:108-177), exponential learnable TemporalSmoother
+ * (decoder.py:278-292) and BlendshapeConstraints (decoder.py:434-466).  d_query must equal d_model (the reference's
+ * residual `attn_out + attention_output` needs it; its default d_query = 128 does not run).  State-dict keys are the
+ * reference's; the buffers of the smoother / constraints are NOT parameters here: the smoother state is the caller's
+ * (B, 52) device array (zero it for reset_temporal_state).  A query row whose keys are all masked yields NaN, as in
+ * the reference.
+ *   km_koemorph_reserve  workspace for max_batch x max_frames
+ *   km_koemorph_forward  mel_dev (B, T, mel_dim), emotion_dev (B, T, emotion_dim), prev_dev (B, 52) or NULL,
+ *                        smoother_state_dev (B, 52) in/out or NULL (= apply_smoothing False), apply_constraints,
+ *                        -> out_dev (B, 52), raw_dev (B, 52) or NULL, attn_dev (layers, B, H, 52, T) or NULL */
+typedef struct km_koemorph_config {
+    int32_t abi_version;            /* KM_ABI_VERSION */
+    int32_t mel_dim;                /* 80 */
+    int32_t emotion_dim;            /* 256 */
+    int32_t d_model;                /* 256, a multiple of 8 and of num_heads */
+    int32_t num_heads;              /* 8 */
+    int32_t num_encoder_layers;     /* 2 */
+    int32_t num_attention_layers;   /* 4 */
+    int32_t decoder_hidden_dim;     /* 128 */
+    int32_t decoder_layers;         /* 2 */
+    int32_t decoder_activation;     /* 0 relu, 1 gelu (default) */
+    int32_t causal;                 /* 1 */
+    int32_t window_size;            /* 30; < 0 = None */
+    int32_t use_temporal_smoothing; /* 1: temporal_smoother.alpha is a parameter */
+    int32_t use_constraints;        /* 1 */
+    int32_t num_blendshapes;        /* 52 */
+} km_koemorph_config;
+int km_koemorph_create(const km_koemorph_config* cfg, km_handle* out);
+int km_koemorph_reserve(km_handle h, int64_t max_batch, int64_t max_frames);
+int km_koemorph_forward(km_handle h, const float* mel_dev, const float* emotion_dev, int64_t B, int64_t T,
+                        const float* prev_dev, float* smoother_state_dev, int32_t apply_constraints,
+                        float* out_dev, float* raw_dev, float* attn_dev, void* stream);
+
 /* ---- streaming: many concurrent speaker streams, state resident on the device -------------------------
  * Replaces, for all streams of this GPU at once, MelAudioBuffer.add_audio_frame / get_current_audio
  * (src/features/mel_sliding_window.py:70-140), MelSlidingWindowExtractor.process_audio_frame (:252-324) and

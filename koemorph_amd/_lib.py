@@ -40,6 +40,12 @@ class KMLegacyConfig(C.Structure):
                 ("decoder_hidden", C.c_int32), ("num_blendshapes", C.c_int32), ("mel", KMMelConfig)]
 
 
+class KMKoeMorphConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("abi_version", "mel_dim", "emotion_dim", "d_model", "num_heads", "num_encoder_layers",
+                                         "num_attention_layers", "decoder_hidden_dim", "decoder_layers", "decoder_activation",
+                                         "causal", "window_size", "use_temporal_smoothing", "use_constraints", "num_blendshapes")]
+
+
 class KMLossConfig(C.Structure):
     _fields_ = [("perceptual_weight", C.c_float), ("temporal_weight", C.c_float), ("sparsity_weight", C.c_float),
                 ("smoothness_weight", C.c_float), ("landmark_weight", C.c_float), ("velocity_weight", C.c_float),
@@ -103,6 +109,9 @@ SIGNATURES = {
     "km_legacy_create": (C.c_int, [C.POINTER(KMLegacyConfig), C.POINTER(_h)]),
     "km_legacy_forward": (C.c_int, [_h, _p, _i64, _i64, _p, _p]),
     "km_legacy_forward_mel": (C.c_int, [_h, _p, _i64, _i64, _p, _p]),
+    "km_koemorph_create": (C.c_int, [C.POINTER(KMKoeMorphConfig), C.POINTER(_h)]),
+    "km_koemorph_reserve": (C.c_int, [_h, _i64, _i64]),
+    "km_koemorph_forward": (C.c_int, [_h, _p, _p, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p]),
     "km_stream_create": (C.c_int, [_h, _i64, C.c_double, C.c_double, C.POINTER(KMMelConfig)]),
     "km_stream_push": (C.c_int, [_h, _p, _i64, _p]),
     "km_stream_tick": (C.c_int, [_h, _p, _p, _p, _p]),

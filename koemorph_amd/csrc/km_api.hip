@@ -75,6 +75,7 @@ static int free_ws(Context* c) {
 int km_reserve(km_handle h, int64_t max_windows, int64_t max_samples) {
     if (!h || max_windows <= 0 || max_samples < 0) return fail(KM_ERR_INVALID_ARG, "km_reserve: bad argument");
     Context* c = h;
+    if (c->kind == 2) return fail(KM_ERR_INVALID_ARG, "KoeMorphModel handles take no audio: use km_koemorph_reserve");
     // frames for the smallest hop among the registered plans (upper bound for all of them)
     int min_hop = c->cfg.mel.hop_length, max_mels = c->cfg.mel.n_mels;
     for (MelPlan* p : c->mel_plans) {
@@ -383,6 +384,32 @@ int km_legacy_forward_mel(km_handle h, const float* mel_dev, int64_t B, int64_t 
         return fail(KM_ERR_WORKSPACE, "workspace too small for %lld windows x %lld frames: call km_reserve",
                     (long long)B, (long long)T_mel);
     return launch_legacy(c, mel_dev, B, T_mel, out_dev, stream);
+}
+
+int km_koemorph_reserve(km_handle h, int64_t max_batch, int64_t max_frames) {
+    if (int rc = need_ready(h)) return rc;
+    Context* c = h;
+    if (c->kind != 2) return fail(KM_ERR_INVALID_ARG, "not a KoeMorphModel handle (km_koemorph_create)");
+    if (max_batch <= 0 || max_frames <= 0) return fail(KM_ERR_INVALID_ARG, "km_koemorph_reserve: bad argument");
+    if (max_batch <= c->kmm_batch && max_frames <= c->kmm_frames) return KM_OK;
+    const int64_t Bm = max_batch > c->kmm_batch ? max_batch : c->kmm_batch, Tm = max_frames > c->kmm_frames ? max_frames : c->kmm_frames;
+    if (c->ws_generic) { HIP_TRY(hipFree(c->ws_generic)); c->ws_generic = nullptr; c->kmm_batch = c->kmm_frames = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_generic), (size_t)(Bm * koemorph_ws_floats(c, Tm)) * sizeof(float)));
+    c->kmm_batch = Bm; c->kmm_frames = Tm;
+    return KM_OK;
+}
+
+int km_koemorph_forward(km_handle h, const float* mel_dev, const float* emotion_dev, int64_t B, int64_t T,
+                        const float* prev_dev, float* smoother_state_dev, int32_t apply_constraints,
+                        float* out_dev, float* raw_dev, float* attn_dev, void* stream) {
+    if (int rc = need_ready(h)) return rc;
+    Context* c = h;
+    if (c->kind != 2) return fail(KM_ERR_INVALID_ARG, "not a KoeMorphModel handle (km_koemorph_create)");
+    if (!mel_dev || !emotion_dev || !out_dev || B <= 0 || T <= 0) return fail(KM_ERR_INVALID_ARG, "km_koemorph_forward: bad argument");
+    // the workspace is carved per call for (B, T): B * ws(T) floats must fit what km_koemorph_reserve allocated
+    if (!c->ws_generic || B * koemorph_ws_floats(c, T) > c->kmm_batch * koemorph_ws_floats(c, c->kmm_frames))
+        return fail(KM_ERR_WORKSPACE, "workspace too small for %lld x %lld frames: call km_koemorph_reserve", (long long)B, (long long)T);
+    return launch_koemorph(c, mel_dev, emotion_dev, B, T, prev_dev, smoother_state_dev, apply_constraints, out_dev, raw_dev, attn_dev, stream);
 }
 
 int km_legacy_forward(km_handle h, const float* audio_dev, int64_t B, int64_t L, float* out_dev, void* stream) {

@@ -54,8 +54,10 @@ struct MelPlan {
 
 struct Context {
     km_config cfg{};
-    int kind = 0;                                // 0 dual-stream production model, 1 legacy SimplifiedKoeMorphModel
+    int kind = 0;                                // 0 dual-stream production model, 1 legacy SimplifiedKoeMorphModel, 2 legacy KoeMorphModel
     int legacy_hidden = 128;
+    km_koemorph_config kmm{};                    // kind 2
+    int64_t kmm_batch = 0, kmm_frames = 0;       // kind 2: reserved workspace (ws_generic)
     int d = 0, H = 0, hd = 0, T = 0, KT = 0, ED = 0, DH = 0, NB = 0, NK = 0;
     std::map<std::string, HostParam> params;     // reference state-dict tensors (fp32 masters)
     std::vector<std::string> param_order;
@@ -157,6 +159,10 @@ int train_adamw(Context* c, const float* flat_grad, float lr, float b1, float b2
 int64_t generic_ws_floats(Context* c);
 int64_t legacy_ws_floats(Context* c, int64_t frames);
 int finalize_host_legacy(Context* c);
+int finalize_host_koemorph(Context* c);
+int64_t koemorph_ws_floats(Context* c, int64_t T);
+int launch_koemorph(Context* c, const float* mel, const float* emo, int64_t B, int64_t T, const float* prev, float* state,
+                    int apply_constraints, float* out, float* raw, float* attn, void* stream);
 int launch_legacy(Context* c, const float* mel, int64_t B, int64_t T_mel, float* out, void* stream);
 int launch_gather_clip_logits(Context* c, const float* zclip, float* zwin, int64_t nw, int64_t w0, int wins_per_clip, void* stream);
 int launch_core_generic_packed(Context* c, const float* xp, int64_t B, const float* zemo, float* out, float* raw, float* attn,

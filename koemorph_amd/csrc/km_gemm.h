@@ -18,7 +18,7 @@ struct GemmArgs {
     int64_t a_kbs, b_kbs;
     float alpha, beta;
     int bias_mode;                               // 0 none, 1 bias[n], 2 bias[m]
-    int relu;
+    int relu;                                    // epilogue activation: 0 none, 1 ReLU, 2 exact-erf GELU
 };
 
 int launch_gemm(const GemmArgs& g, int batch, void* stream);

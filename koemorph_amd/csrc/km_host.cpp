@@ -131,10 +131,33 @@ int finalize_host_legacy(Context* c) {
     return KM_OK;
 }
 
+// KoeMorphModel (gaussian_face.py:29-173): every tensor keeps the reference's layout (nn.Linear weights are (out, in) =
+// the B^T operand of the NT GEMM); the key / value projections of ALL cross-attention layers read the same encoded
+// audio, so they are stacked into one (2 L d, d) weight: one GEMM instead of 2 L.
+int finalize_host_koemorph(Context* c) {
+    const int d = c->d, L = c->kmm.num_attention_layers;
+    for (const auto& k : c->param_order) put(c, k.c_str(), std::vector<float>(P(c, k.c_str())));
+    std::vector<float> w((size_t)2 * L * d * d), b((size_t)2 * L * d);
+    for (int i = 0; i < L; ++i)
+        for (int kv = 0; kv < 2; ++kv) {
+            const std::string base = "cross_attention_layers." + std::to_string(i) + (kv ? ".v_proj." : ".k_proj.");
+            const std::vector<float>& W = c->params.at(base + "weight").data;
+            const std::vector<float>& Bv = c->params.at(base + "bias").data;
+            std::copy(W.begin(), W.end(), w.begin() + (size_t)(2 * i + kv) * d * d);
+            std::copy(Bv.begin(), Bv.end(), b.begin() + (size_t)(2 * i + kv) * d);
+        }
+    put(c, "kmm_kv_w", std::move(w));
+    put(c, "kmm_kv_b", std::move(b));
+    c->fused_ok = false;
+    c->host_finalized = true;
+    return KM_OK;
+}
+
 int finalize_host(Context* c) {
     for (const auto& k : c->param_order)
         if (!c->params[k].loaded) return fail(KM_ERR_NOT_FINALIZED, "parameter '%s' was never loaded", k.c_str());
     if (c->kind == 1) return finalize_host_legacy(c);
+    if (c->kind == 2) return finalize_host_koemorph(c);
     const int d = c->d, H = c->H, hd = c->hd, KT = c->KT, ED = c->ED, DH = c->DH, NB = c->NB;
     const int NQ = kNumMouth;
 
@@ -479,6 +502,83 @@ int km_create(const km_config* cfg, km_handle* out) {
     c->params["smoothing_alpha"].data[0] = 0.8f;
     c->params["smoothing_alpha"].loaded = true;
     c->mel_plans.push_back(build_mel_plan(cfg->mel));
+    *out = c;
+    return KM_OK;
+}
+
+int km_koemorph_create(const km_koemorph_config* cfg, km_handle* out) {
+    if (!cfg || !out) return fail(KM_ERR_INVALID_ARG, "km_koemorph_create: NULL argument");
+    if (cfg->abi_version != KM_ABI_VERSION) return fail(KM_ERR_INVALID_ARG, "km_koemorph_config.abi_version %d != %d", cfg->abi_version, KM_ABI_VERSION);
+    if (cfg->d_model <= 0 || cfg->num_heads <= 0 || cfg->d_model % cfg->num_heads != 0)     // attention.py:68-71
+        return fail(KM_ERR_INVALID_ARG, "d_model (%d) must be divisible by num_heads (%d)", cfg->d_model, cfg->num_heads);
+    if (cfg->d_model % 8 != 0) return fail(KM_ERR_INVALID_ARG, "d_model (%d) must be divisible by the encoder's 8 heads", cfg->d_model);
+    if (cfg->mel_dim <= 0 || cfg->emotion_dim <= 0 || cfg->decoder_hidden_dim <= 0 || cfg->num_encoder_layers < 0 ||
+        cfg->num_attention_layers < 0 || cfg->decoder_layers < 0 || cfg->num_blendshapes <= 0 || cfg->num_blendshapes > 64)
+        return fail(KM_ERR_INVALID_ARG, "km_koemorph_create: bad dimension");
+    if (cfg->decoder_activation != 0 && cfg->decoder_activation != 1)
+        return fail(KM_ERR_UNSUPPORTED, "decoder_activation: only relu (0) and gelu (1)");
+    if (cfg->use_constraints && cfg->num_blendshapes < 27)
+        return fail(KM_ERR_INVALID_ARG, "the default exclusion pairs (25, 26), (20, 21) need >= 27 blendshapes");
+    km_context* c = new km_context();
+    c->kind = 2;
+    c->kmm = *cfg;
+    c->cfg.abi_version = KM_ABI_VERSION; c->cfg.d_model = cfg->d_model; c->cfg.num_heads = cfg->num_heads;
+    c->cfg.num_blendshapes = cfg->num_blendshapes; c->cfg.temperature = 1.0f;
+    c->d = cfg->d_model; c->H = cfg->num_heads; c->hd = c->d / c->H; c->NB = cfg->num_blendshapes; c->NK = cfg->mel_dim;
+    c->ED = cfg->emotion_dim;
+    const int64_t d = c->d, hid = cfg->decoder_hidden_dim, nb = c->NB;
+    auto key = [](const std::string& s) { return s; };
+    // state-dict layout of KoeMorphModel (gaussian_face.py:111-173)
+    const char* streams[2] = {"mel", "emotion"};
+    for (int si = 0; si < 2; ++si) {
+        const std::string p = std::string("audio_encoder.") + streams[si] + "_encoder.";
+        expect(c, key(p + "0.weight").c_str(), {d, si ? (int64_t)cfg->emotion_dim : (int64_t)cfg->mel_dim});
+        expect(c, key(p + "0.bias").c_str(), {d});
+        expect(c, key(p + "3.weight").c_str(), {d});
+        expect(c, key(p + "3.bias").c_str(), {d});
+    }
+    for (int si = 0; si < 2; ++si)
+        for (int i = 0; i < cfg->num_encoder_layers; ++i) {
+            const std::string p = std::string("audio_encoder.") + streams[si] + "_transformer.layers." + std::to_string(i) + ".";
+            expect(c, (p + "self_attn.in_proj_weight").c_str(), {3 * d, d});
+            expect(c, (p + "self_attn.in_proj_bias").c_str(), {3 * d});
+            expect(c, (p + "self_attn.out_proj.weight").c_str(), {d, d});
+            expect(c, (p + "self_attn.out_proj.bias").c_str(), {d});
+            expect(c, (p + "linear1.weight").c_str(), {4 * d, d});
+            expect(c, (p + "linear1.bias").c_str(), {4 * d});
+            expect(c, (p + "linear2.weight").c_str(), {d, 4 * d});
+            expect(c, (p + "linear2.bias").c_str(), {d});
+            for (const char* n : {"norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"}) expect(c, (p + n).c_str(), {d});
+        }
+    expect(c, "query_embeddings.query_embeddings", {nb, d});
+    expect(c, "query_embeddings.conditioning_net.0.weight", {d / 2, nb});
+    expect(c, "query_embeddings.conditioning_net.0.bias", {d / 2});
+    expect(c, "query_embeddings.conditioning_net.3.weight", {d, d / 2});
+    expect(c, "query_embeddings.conditioning_net.3.bias", {d});
+    for (int i = 0; i < cfg->num_attention_layers; ++i) {
+        const std::string p = "cross_attention_layers." + std::to_string(i) + ".";
+        for (const char* n : {"q_proj", "k_proj", "v_proj", "out_proj"}) {
+            expect(c, (p + n + ".weight").c_str(), {d, d});
+            expect(c, (p + n + ".bias").c_str(), {d});
+        }
+    }
+    for (int i = 0; i < cfg->num_attention_layers; ++i) {
+        expect(c, ("attention_layer_norms." + std::to_string(i) + ".weight").c_str(), {d});
+        expect(c, ("attention_layer_norms." + std::to_string(i) + ".bias").c_str(), {d});
+    }
+    expect(c, "decoder.input_proj.weight", {hid, d});
+    expect(c, "decoder.input_proj.bias", {hid});
+    for (int i = 0; i < cfg->decoder_layers; ++i) {
+        expect(c, ("decoder.hidden_layers." + std::to_string(i) + ".weight").c_str(), {hid, hid});
+        expect(c, ("decoder.hidden_layers." + std::to_string(i) + ".bias").c_str(), {hid});
+    }
+    for (int i = 0; i < cfg->decoder_layers; ++i) {
+        expect(c, ("decoder.layer_norms." + std::to_string(i) + ".weight").c_str(), {hid});
+        expect(c, ("decoder.layer_norms." + std::to_string(i) + ".bias").c_str(), {hid});
+    }
+    expect(c, "decoder.output_proj.weight", {nb, hid});
+    expect(c, "decoder.output_proj.bias", {nb});
+    if (cfg->use_temporal_smoothing) expect(c, "temporal_smoother.alpha", {});
     *out = c;
     return KM_OK;
 }

@@ -1,0 +1,110 @@
+"""HIP KoeMorphModel (km_koemorph_*) against golden vectors from the reference's own module and against the oracle."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from koemorph_amd import _lib
+from koemorph_amd.model import KoeMorphModel, create_koemorph_model
+from oracle import koemorph_model as okm
+from test_oracle_koemorph import GOLDEN, assert_same, load_case
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4          # north-star tolerance on the 52 coefficients; observed <= 3e-6
+
+
+def build(cfg: okm.KoeMorphConfig, params):
+    m = KoeMorphModel(mel_dim=cfg.mel_dim, emotion_dim=cfg.emotion_dim, d_model=cfg.d_model, d_query=cfg.d_model,
+                      num_heads=cfg.num_heads, num_encoder_layers=cfg.num_encoder_layers,
+                      num_attention_layers=cfg.num_attention_layers, decoder_hidden_dim=cfg.decoder_hidden_dim,
+                      decoder_layers=cfg.decoder_layers, decoder_activation=cfg.decoder_activation,
+                      use_temporal_smoothing=cfg.use_temporal_smoothing, use_constraints=cfg.use_constraints, causal=cfg.causal,
+                      window_size=cfg.window_size)
+    sd = m.state_dict()
+    sd.update({k: torch.from_numpy(np.asarray(v)) for k, v in params.items()})
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_two_frames_match_reference_golden(path):
+    z, cfg, params, (mel1, emo1), (mel2, emo2) = load_case(path)
+    m = build(cfg, params)
+    with torch.no_grad():
+        o1 = m(torch.from_numpy(mel1).cuda(), torch.from_numpy(emo1).cuda(), return_attention=True)
+        o2 = m(torch.from_numpy(mel2).cuda(), torch.from_numpy(emo2).cuda(), prev_blendshapes=o1["blendshapes"], return_attention=True)
+    for tag, o in (("f1", o1), ("f2", o2)):
+        assert_same(o["blendshapes"].cpu().numpy(), z[tag + "/blendshapes"], TOL)
+        assert_same(o["raw_blendshapes"].cpu().numpy(), z[tag + "/raw_blendshapes"], TOL)
+        assert len(o["attention_weights"]) == cfg.num_attention_layers
+        for li, w in enumerate(o["attention_weights"]):
+            assert_same(w.cpu().numpy()[:, :, ::13, :], z[f"{tag}/attn{li}"], TOL)
+
+
+def test_options_against_oracle():
+    cfg = okm.KoeMorphConfig(d_model=64, num_heads=4, num_encoder_layers=1, num_attention_layers=2, decoder_hidden_dim=32,
+                             decoder_layers=2, emotion_dim=24, window_size=9)
+    params = okm.make_koemorph_params(71, cfg)
+    m = build(cfg, params)
+    from koemorph_amd import synth
+    mel, emo = synth.normal(1, (5, 40, 80)), synth.normal(2, (5, 40, 24))
+    prev = synth.uniform(3, (5, 52), 0, 1)
+    with torch.no_grad():
+        a = m(torch.from_numpy(mel).cuda(), torch.from_numpy(emo).cuda(), prev_blendshapes=torch.from_numpy(prev).cuda(),
+              apply_smoothing=False, apply_constraints=False)
+        b = m(torch.from_numpy(mel).cuda(), torch.from_numpy(emo).cuda(), apply_smoothing=True, apply_constraints=True)
+    wa = okm.koemorph_forward(params, cfg, mel, emo, prev_blendshapes=prev, apply_smoothing=False, apply_constraints=False)
+    wb = okm.koemorph_forward(params, cfg, mel, emo)
+    np.testing.assert_allclose(a["blendshapes"].cpu().numpy(), wa["blendshapes"], atol=TOL)
+    np.testing.assert_array_equal(a["blendshapes"].cpu().numpy(), a["raw_blendshapes"].cpu().numpy())
+    np.testing.assert_allclose(b["blendshapes"].cpu().numpy(), wb["blendshapes"], atol=TOL)
+    # attention rows sum to one (reference tests/model/test_attention.py:53-56), outputs in [0, 1]
+    with torch.no_grad():
+        o = m(torch.from_numpy(mel).cuda(), torch.from_numpy(emo).cuda(), return_attention=True)
+    for w in o["attention_weights"]:
+        np.testing.assert_allclose(w.sum(-1).cpu().numpy(), 1.0, atol=1e-5)
+    bs = o["blendshapes"].cpu().numpy()
+    assert (bs >= 0).all() and (bs <= 1).all()
+    # a new sequence starts the smoother from zero again
+    m.reset_temporal_state()
+    with torch.no_grad():
+        c = m(torch.from_numpy(mel).cuda(), torch.from_numpy(emo).cuda())
+    np.testing.assert_array_equal(c["blendshapes"].cpu().numpy(), b["blendshapes"].cpu().numpy())
+
+
+def test_inference_step_chain_and_factory():
+    m = create_koemorph_model({"d_model": 64, "d_query": 64, "num_heads": 8, "num_encoder_layers": 1, "num_attention_layers": 1,
+                               "decoder_hidden_dim": 32, "emotion_dim": 16}).cuda().eval()
+    assert m.get_model_info()["num_attention_layers"] == 1 and m.get_num_parameters() > 0
+    prev = None
+    for t in range(3):                                    # T = 1 frames, as scripts/rt.py feeds them
+        mel = torch.randn(1, 1, 80, device="cuda")
+        emo = torch.randn(1, 1, 16, device="cuda")
+        prev = m.inference_step(mel, emo, prev)
+        assert prev.shape == (1, 52) and torch.isfinite(prev).all()
+
+
+def test_error_paths():
+    with pytest.raises(ValueError):
+        KoeMorphModel()                                   # d_query 128 != d_model 256: the reference's default does not run
+    with pytest.raises(ValueError):
+        KoeMorphModel(d_model=100, d_query=100, num_heads=8)
+    with pytest.raises(NotImplementedError):
+        KoeMorphModel(d_query=256, smoothing_method="median")
+    m = KoeMorphModel(d_model=64, d_query=64, num_heads=4, num_encoder_layers=0, num_attention_layers=1, decoder_hidden_dim=32,
+                      emotion_dim=8).cuda().eval()
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 4, 80).cuda(), torch.zeros(1, 4, 8).cuda(), audio_mask=torch.ones(1, 4, dtype=torch.bool).cuda())
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 4, 80).cuda(), torch.zeros(1, 5, 8).cuda())
+    with torch.no_grad():
+        assert m(torch.zeros(2, 4, 80).cuda(), torch.zeros(2, 4, 8).cuda())["blendshapes"].shape == (2, 52)
+    lib = _lib.load()
+    h = m._h
+    with pytest.raises(_lib.KoeMorphError):               # workspace was reserved for 2 x 4 frames
+        _lib.check(lib.km_koemorph_forward(h, C.c_void_p(8), C.c_void_p(8), 64, 64, None, None, 0, C.c_void_p(8), None, None, None))
+    with pytest.raises(_lib.KoeMorphError):
+        _lib.check(lib.km_reserve(h, 1, 16000))           # audio workspace entry point on a KoeMorphModel handle
