@@ -44,11 +44,13 @@ __global__ __launch_bounds__(256) void kmm_ln_rows_kernel(float* __restrict__ x,
 // softmax over the T keys of each (b, h, q) row with the causal / window masks of attention.py:208-246 applied on the
 // fly: key j of query q is masked when j > q (causal) or outside [kp - w/2, kp + w/2] with kp = floor(q T / NQ).
 // A fully masked row becomes NaN, as torch's softmax over -inf only; a NaN score makes its whole row NaN.
+template <int G>   // G lanes per row (a power of two <= 64): 64 / G rows per wave, so short key axes (T = 1 per tick) fill the wave
 __global__ __launch_bounds__(256) void kmm_masked_softmax_kernel(float* __restrict__ x, int64_t rows, int T, int NQ, int causal, int window) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const int q = (int)(row % NQ);
+    constexpr int RPW = 64 / G;
+    const int lane = threadIdx.x & 63, sub = lane & (G - 1);
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / G;
+    const bool live = row < rows;                       // dead rows still take part in the shuffles
+    const int q = live ? (int)(row % NQ) : 0;
     int lo = 0, hi = T;
     if (window >= 0) {
         const int kp = (int)(((int64_t)q * T) / NQ);
@@ -56,22 +58,37 @@ __global__ __launch_bounds__(256) void kmm_masked_softmax_kernel(float* __restri
         hi = kp + window / 2 + 1 < T ? kp + window / 2 + 1 : T;
     }
     if (causal && q + 1 < hi) hi = q + 1;
-    float* p = x + row * T;
+    if (!live) hi = lo;
+    float* p = x + (live ? row : 0) * T;
     float m = -INFINITY;
-    for (int i = lo + lane; i < hi; i += 64) m = fmaxf(m, p[i]);
+    for (int i = lo + sub; i < hi; i += G) m = fmaxf(m, p[i]);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    for (int o = G / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     float s = 0.f;
-    for (int i = lo + lane; i < hi; i += 64) s += expf(p[i] - m);
+    for (int i = lo + sub; i < hi; i += G) s += expf(p[i] - m);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (!live) return;
     // masked keys go through the same arithmetic as torch's masked_fill(-inf) + softmax: 0 for a regular row, NaN when the
     // row has no key at all (exp(-inf - -inf)) or holds a NaN score (0 * NaN)
     const float inv = 1.0f / s;
-    for (int i = lane; i < T; i += 64) {
+    for (int i = sub; i < T; i += G) {
         const bool in = i >= lo && i < hi;
         p[i] = expf((in ? p[i] : -INFINITY) - m) * inv;
     }
+}
+
+static int masked_softmax(float* S, int64_t rows, int T, int NQ, int causal, int window, hipStream_t st) {
+#define KMM_MS(G)                                                                                                              \
+    hipLaunchKernelGGL(kmm_masked_softmax_kernel<G>, dim3((unsigned)((rows + 4 * (64 / G) - 1) / (4 * (64 / G)))), dim3(256), 0, st, S, \
+                       rows, T, NQ, causal, window)
+    if (T <= 1) KMM_MS(1);
+    else if (T <= 4) KMM_MS(4);
+    else if (T <= 16) KMM_MS(16);
+    else KMM_MS(64);
+#undef KMM_MS
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
 }
 
 // y = 0.5 (a + b)
@@ -250,9 +267,7 @@ int launch_koemorph(Context* c, const float* mel, const float* emo, int64_t B, i
         g.C = S; g.c_rs = T; g.c_bs1 = (int64_t)H * NB * T; g.c_bs2 = (int64_t)NB * T;
         g.M = NB; g.N = (int)T; g.K = hd; g.batch2 = H;
         if (int rc = launch_gemm(g, (int)(B * H), st)) return rc;
-        hipLaunchKernelGGL(kmm_masked_softmax_kernel, dim3((unsigned)((B * H * NB + 3) / 4)), dim3(256), 0, st, S, B * H * NB, (int)T, NB,
-                           k.causal, k.window_size);
-        HIP_TRY(hipGetLastError());
+        if (int rc = masked_softmax(S, B * H * NB, (int)T, NB, k.causal, k.window_size, st)) return rc;
         if (attn)
             HIP_TRY(hipMemcpyAsync(attn + (int64_t)i * B * H * NB * T, S, (size_t)(B * H * NB * T) * sizeof(float), hipMemcpyDeviceToDevice, st));
         g = GemmArgs{};                                     // O2[b][:, h] (NB x hd) = P V_h

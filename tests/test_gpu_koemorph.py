@@ -108,3 +108,20 @@ def test_error_paths():
         _lib.check(lib.km_koemorph_forward(h, C.c_void_p(8), C.c_void_p(8), 64, 64, None, None, 0, C.c_void_p(8), None, None, None))
     with pytest.raises(_lib.KoeMorphError):
         _lib.check(lib.km_reserve(h, 1, 16000))           # audio workspace entry point on a KoeMorphModel handle
+
+
+@pytest.mark.parametrize("T", [1, 3, 10, 70, 130])
+def test_key_axis_lengths_against_oracle(T):
+    """Every lane grouping of the masked softmax (1 / 4 / 16 / 64 lanes per row) and the > 128-key row softmax of the encoder."""
+    from koemorph_amd import synth
+    cfg = okm.KoeMorphConfig(d_model=64, num_heads=4, num_encoder_layers=1, num_attention_layers=2, decoder_hidden_dim=32,
+                             decoder_layers=1, emotion_dim=24, window_size=None if T == 130 else 30, causal=T != 130)
+    params = okm.make_koemorph_params(80 + T, cfg)
+    m = build(cfg, params)
+    mel, emo = synth.normal(T, (7, T, 80)), synth.normal(T + 1, (7, T, 24))
+    with torch.no_grad():
+        o = m(torch.from_numpy(mel).cuda(), torch.from_numpy(emo).cuda(), return_attention=True)
+    w = okm.koemorph_forward(params, cfg, mel, emo)
+    assert_same(o["blendshapes"].cpu().numpy(), w["blendshapes"], TOL)
+    for a, b in zip(o["attention_weights"], w["attention_weights"]):
+        assert_same(a.cpu().numpy(), b, TOL)
