@@ -271,9 +271,12 @@ int launch_gemm(const GemmArgs& g, int batch, void* stream) {
 #define KM_NT_MIN_WGS 192
 #endif
     // the 128-row tiles only pay off when they still fill the chip (training-sized products stay on 64 x 64 tiles)
-    const int64_t nt_wgs = (int64_t)batch * ((g.M + 127) / 128) * (g.N > 64 ? (g.N + 127) / 128 : 1);
-    if (fast && gemm_nt_ok(g) && nt_wgs >= KM_NT_MIN_WGS) {
-        if (g.N > 64) {
+    const int64_t mt_wgs = (int64_t)batch * ((g.M + 127) / 128);
+    const int64_t wgs4 = mt_wgs * ((g.N + 127) / 128), wgs2 = mt_wgs * ((g.N + 63) / 64);
+    static const bool mid = std::getenv("KM_GEMM_NO_NT2_MID") == nullptr;
+    const bool use4 = g.N > 64 && wgs4 >= KM_NT_MIN_WGS;
+    if (fast && gemm_nt_ok(g) && (use4 || (wgs2 >= KM_NT_MIN_WGS && (mid || g.N <= 64)))) {
+        if (use4) {
             const dim3 grid((unsigned)((g.N + 127) / 128), (unsigned)((g.M + gnt::BM - 1) / gnt::BM), (unsigned)batch);
             hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, g);
         } else {
