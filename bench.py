@@ -62,10 +62,19 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # KM_BENCH_BACKEND=gloo is the one-GPU rehearsal of the N > 1 code path (ranks share the card, CPU collectives);
+        # the driver's runs use RCCL with one rank per GPU
+        backend = os.environ.get("KM_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
+        backend = None
         torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     n_gpus = max(world, 1)
@@ -121,7 +130,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
