@@ -24,7 +24,10 @@ params = okm.make_koemorph_params(5, cfg)
 m = KoeMorphModel(d_query=cfg.d_model)
 sd = m.state_dict(); sd.update({k: torch.from_numpy(np.asarray(v)) for k, v in params.items()}); m.load_state_dict(sd)
 m = m.cuda().eval()
-for B, T in ((int(os.environ.get("B", 256)), 30), (1024, 1)):
+CASES = ((int(os.environ.get("B", 256)), 30), (1024, 1))
+if os.environ.get("ONLY"):
+    CASES = (CASES[int(os.environ["ONLY"])],)
+for B, T in CASES:
     mel = torch.from_numpy(synth.normal(1, (B, T, 80))).cuda()
     emo = torch.from_numpy(synth.normal(2, (B, T, 256))).cuda()
     prev = torch.from_numpy(synth.uniform(3, (B, 52), 0, 1)).cuda()
