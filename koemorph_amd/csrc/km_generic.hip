@@ -154,22 +154,25 @@ namespace gnt {
 constexpr int BM = 128, BK = 16;
 }
 
-// out-of-range rows read row 0 (valid memory) and are zeroed by value: the loads stay unconditional
+// Tiles are fetched with buffer loads: an out-of-range row points past the descriptor's range and reads zeros without a
+// memory access, so no select touches the loaded values before the commit -- with plain loads + `ok ? v : 0` the
+// compiler waited for the tile (vmcnt(0)) and wrote it to LDS after the first five MFMAs of a k step instead of the last.
+typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
 template <int E>
-__device__ __forceinline__ void nt_stage(const float* const (&p)[E], const bool (&ok)[E], int k0, float4 (&r)[E]) {
+__device__ __forceinline__ void nt_stage(__amdgpu_buffer_rsrc_t rs, const unsigned (&off)[E], int k0, nt_u32x4 (&r)[E]) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const float4 v = *reinterpret_cast<const float4*>(p[e] + k0);
-        r[e] = ok[e] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int e = 0; e < E; ++e) r[e] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[e] + (unsigned)k0 * 4u, 0, 0);
 }
 template <int E>
-__device__ __forceinline__ void nt_commit(float* dst, int tid, const float4 (&r)[E]) {
+__device__ __forceinline__ void nt_commit(float* dst, int tid, const nt_u32x4 (&r)[E]) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) *reinterpret_cast<float4*>(dst + (tid + 256 * e) * 4) = r[e];
+    for (int e = 0; e < E; ++e) *reinterpret_cast<nt_u32x4*>(dst + (tid + 256 * e) * 4) = r[e];
 }
 
-template <int NT>   // 16-column MFMA tiles per wave: 4 -> BN 128, 2 -> BN 64
+// PIN: scheduling barriers hold the next tile's loads at the top of a k step and its LDS commit at the bottom.  Short
+// contractions (K <= 256: 16 steps, the legacy model's products) gain 7 % from it; long ones (K = 512, C4's value
+// projection on 128-column tiles) lose 2 % to the extra live registers, so the launcher picks per product.
+template <int NT, bool PIN>   // 16-column MFMA tiles per wave: 4 -> BN 128, 2 -> BN 64
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     using namespace gnt;
     constexpr int BN = 32 * NT;
@@ -187,22 +190,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     // staging map: element e of this thread is row (tid + 256 e) & (rows - 1), k group (tid + 256 e) / rows
     constexpr int EA = BM * 4 / 256, EB = BN * 4 / 256;
     static_assert(EA >= 1 && EB >= 1, "tile too small for 256 threads");
-    const float* ap[EA];
-    const float* bp[EB];
-    bool aok[EA], bok[EB];
+    // byte offsets from the (batch's) operand base; gemm_nt_ok() keeps both operands under 2 GiB
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (unsigned)((((int64_t)g.M - 1) * g.a_rs + g.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bp), 0, (unsigned)((((int64_t)g.N - 1) * g.b_cs + g.K) * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned aoff[EA], boff[EB];
 #pragma unroll
     for (int e = 0; e < EA; ++e) {
         const int idx = tid + 256 * e, m = idx & (BM - 1), kg = idx / BM;
-        aok[e] = m0 + m < g.M;
-        ap[e] = A + (int64_t)(aok[e] ? m0 + m : 0) * g.a_rs + 4 * kg;
+        aoff[e] = m0 + m < g.M ? (unsigned)(((int64_t)(m0 + m) * g.a_rs + 4 * kg) * 4) : OOB;
     }
 #pragma unroll
     for (int e = 0; e < EB; ++e) {
         const int idx = tid + 256 * e, n = idx & (BN - 1), kg = idx / BN;
-        bok[e] = n0 + n < g.N;
-        bp[e] = Bp + (int64_t)(bok[e] ? n0 + n : 0) * g.b_cs + 4 * kg;
+        boff[e] = n0 + n < g.N ? (unsigned)(((int64_t)(n0 + n) * g.b_cs + 4 * kg) * 4) : OOB;
     }
-    float4 ra[EA], rb[EB];
+    nt_u32x4 ra[EA], rb[EB];
 
     f32x4 acc[4][NT];
 #pragma unroll
@@ -211,16 +214,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
         for (int jn = 0; jn < NT; ++jn) acc[i][jn] = f32x4{0, 0, 0, 0};
 
     const int kt = g.K / BK;
-    nt_stage<EA>(ap, aok, 0, ra);
-    nt_stage<EB>(bp, bok, 0, rb);
+    nt_stage<EA>(ars, aoff, 0, ra);
+    nt_stage<EB>(brs, boff, 0, rb);
     nt_commit<EA>(As[0], tid, ra);
     nt_commit<EB>(Bs[0], tid, rb);
     __syncthreads();
     for (int it = 0; it < kt; ++it) {
         const int buf = it & 1;
         const int knext = (it + 1 < kt ? it + 1 : it) * BK;      // last iteration: a harmless reload of the current tile
-        nt_stage<EA>(ap, aok, knext, ra);
-        nt_stage<EB>(bp, bok, knext, rb);
+        nt_stage<EA>(ars, aoff, knext, ra);
+        nt_stage<EB>(brs, boff, knext, rb);
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);   // ... and the loads stay ahead of them (the scheduler sinks them to save registers)
         const float* as = As[buf];
         const float* bs = Bs[buf];
         f32x4 af[4], bf[NT];
@@ -235,6 +239,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
                 for (int jn = 0; jn < NT; ++jn) acc[i][jn] = KM_MFMA(af[i][s], bf[jn][s], acc[i][jn]);
         // the other buffer: its last readers passed the previous barrier (after the last tile: written, never read)
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);   // the commit (and the wait for the tile) stays behind the MFMAs
         nt_commit<EA>(As[buf ^ 1], tid, ra);
         nt_commit<EB>(Bs[buf ^ 1], tid, rb);
         __syncthreads();
@@ -261,6 +266,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 
 static bool gemm_nt_ok(const GemmArgs& g) {
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const int64_t lim = (int64_t)1 << 29;     // floats: buffer-load offsets are 32-bit byte offsets with the top bit reserved for "out of range"
+    if (((int64_t)g.M - 1) * g.a_rs + g.K >= lim || ((int64_t)g.N - 1) * g.b_cs + g.K >= lim) return false;
     return g.a_cs == 1 && g.b_rs == 1 && g.K >= 16 && g.K % 16 == 0 && g.kb_count <= 1 && g.M >= 64 && al(g.A) && al(g.B) &&
            g.a_rs % 4 == 0 && g.b_cs % 4 == 0 && g.a_bs1 % 4 == 0 && g.a_bs2 % 4 == 0 && g.b_bs1 % 4 == 0 && g.b_bs2 % 4 == 0;
 }
@@ -278,10 +285,11 @@ int launch_gemm(const GemmArgs& g, int batch, void* stream) {
     if (fast && gemm_nt_ok(g) && (use4 || (wgs2 >= KM_NT_MIN_WGS && (mid || g.N <= 64)))) {
         if (use4) {
             const dim3 grid((unsigned)((g.N + 127) / 128), (unsigned)((g.M + gnt::BM - 1) / gnt::BM), (unsigned)batch);
-            hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, g);
+            if (g.K <= 256) hipLaunchKernelGGL((gemm_nt_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
+            else hipLaunchKernelGGL((gemm_nt_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, g);
         } else {
             const dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + gnt::BM - 1) / gnt::BM), (unsigned)batch);
-            hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g);
+            hipLaunchKernelGGL((gemm_nt_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, g);   // 80 registers either way
         }
         HIP_TRY(hipGetLastError());
         return KM_OK;
