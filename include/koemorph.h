@@ -295,7 +295,10 @@ int km_legacy_forward_mel(km_handle h, const float* mel_dev, int64_t B, int64_t 
  * (B, 52) device array (zero it for reset_temporal_state).  A query row whose keys are all masked yields NaN, as in
  * the reference.
  *   km_koemorph_reserve  workspace for max_batch x max_frames
- *   km_koemorph_forward  mel_dev (B, T, mel_dim), emotion_dev (B, T, emotion_dim), prev_dev (B, 52) or NULL,
+ *   km_koemorph_forward  mel_dev (B, T, mel_dim), emotion_dev (B, T, emotion_dim), audio_mask_dev (B, T) bytes, 1 = valid
+ *                        frame, or NULL (padded frames are masked as keys in the encoder and in every cross-attention
+ *                        layer, gaussian_face.py:180,204,224; what the encoder leaves AT padded positions is unspecified,
+ *                        as in torch, and never reaches the output), prev_dev (B, 52) or NULL,
  *                        smoother_state_dev (B, 52) in/out or NULL (= apply_smoothing False), apply_constraints,
  *                        -> out_dev (B, 52), raw_dev (B, 52) or NULL, attn_dev (layers, B, H, 52, T) or NULL */
 typedef struct km_koemorph_config {
@@ -318,8 +321,8 @@ typedef struct km_koemorph_config {
 int km_koemorph_create(const km_koemorph_config* cfg, km_handle* out);
 int km_koemorph_reserve(km_handle h, int64_t max_batch, int64_t max_frames);
 int km_koemorph_forward(km_handle h, const float* mel_dev, const float* emotion_dev, int64_t B, int64_t T,
-                        const float* prev_dev, float* smoother_state_dev, int32_t apply_constraints,
-                        float* out_dev, float* raw_dev, float* attn_dev, void* stream);
+                        const uint8_t* audio_mask_dev, const float* prev_dev, float* smoother_state_dev,
+                        int32_t apply_constraints, float* out_dev, float* raw_dev, float* attn_dev, void* stream);
 
 /* ---- streaming: many concurrent speaker streams, state resident on the device -------------------------
  * Replaces, for all streams of this GPU at once, MelAudioBuffer.add_audio_frame / get_current_audio

@@ -111,7 +111,7 @@ SIGNATURES = {
     "km_legacy_forward_mel": (C.c_int, [_h, _p, _i64, _i64, _p, _p]),
     "km_koemorph_create": (C.c_int, [C.POINTER(KMKoeMorphConfig), C.POINTER(_h)]),
     "km_koemorph_reserve": (C.c_int, [_h, _i64, _i64]),
-    "km_koemorph_forward": (C.c_int, [_h, _p, _p, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p]),
+    "km_koemorph_forward": (C.c_int, [_h, _p, _p, _i64, _i64, _p, _p, _p, _i32, _p, _p, _p, _p]),
     "km_stream_create": (C.c_int, [_h, _i64, C.c_double, C.c_double, C.POINTER(KMMelConfig)]),
     "km_stream_push": (C.c_int, [_h, _p, _i64, _p]),
     "km_stream_tick": (C.c_int, [_h, _p, _p, _p, _p]),

@@ -400,8 +400,8 @@ int km_koemorph_reserve(km_handle h, int64_t max_batch, int64_t max_frames) {
 }
 
 int km_koemorph_forward(km_handle h, const float* mel_dev, const float* emotion_dev, int64_t B, int64_t T,
-                        const float* prev_dev, float* smoother_state_dev, int32_t apply_constraints,
-                        float* out_dev, float* raw_dev, float* attn_dev, void* stream) {
+                        const uint8_t* audio_mask_dev, const float* prev_dev, float* smoother_state_dev,
+                        int32_t apply_constraints, float* out_dev, float* raw_dev, float* attn_dev, void* stream) {
     if (int rc = need_ready(h)) return rc;
     Context* c = h;
     if (c->kind != 2) return fail(KM_ERR_INVALID_ARG, "not a KoeMorphModel handle (km_koemorph_create)");
@@ -409,7 +409,8 @@ int km_koemorph_forward(km_handle h, const float* mel_dev, const float* emotion_
     // the workspace is carved per call for (B, T): B * ws(T) floats must fit what km_koemorph_reserve allocated
     if (!c->ws_generic || B * koemorph_ws_floats(c, T) > c->kmm_batch * koemorph_ws_floats(c, c->kmm_frames))
         return fail(KM_ERR_WORKSPACE, "workspace too small for %lld x %lld frames: call km_koemorph_reserve", (long long)B, (long long)T);
-    return launch_koemorph(c, mel_dev, emotion_dev, B, T, prev_dev, smoother_state_dev, apply_constraints, out_dev, raw_dev, attn_dev, stream);
+    return launch_koemorph(c, mel_dev, emotion_dev, B, T, audio_mask_dev, prev_dev, smoother_state_dev, apply_constraints, out_dev, raw_dev,
+                           attn_dev, stream);
 }
 
 int km_legacy_forward(km_handle h, const float* audio_dev, int64_t B, int64_t L, float* out_dev, void* stream) {

@@ -44,8 +44,11 @@ __global__ __launch_bounds__(256) void kmm_ln_rows_kernel(float* __restrict__ x,
 // softmax over the T keys of each (b, h, q) row with the causal / window masks of attention.py:208-246 applied on the
 // fly: key j of query q is masked when j > q (causal) or outside [kp - w/2, kp + w/2] with kp = floor(q T / NQ).
 // A fully masked row becomes NaN, as torch's softmax over -inf only; a NaN score makes its whole row NaN.
+// kvalid (B, T), 1 = attend, or null: the key padding mask (attention.py:196-200; src_key_padding_mask of the encoder),
+// looked up per batch element = row / rows_per_b.
 template <int G>   // G lanes per row (a power of two <= 64): 64 / G rows per wave, so short key axes (T = 1 per tick) fill the wave
-__global__ __launch_bounds__(256) void kmm_masked_softmax_kernel(float* __restrict__ x, int64_t rows, int T, int NQ, int causal, int window) {
+__global__ __launch_bounds__(256) void kmm_masked_softmax_kernel(float* __restrict__ x, int64_t rows, int T, int NQ, int causal, int window,
+                                                                 const unsigned char* __restrict__ kvalid, int rows_per_b) {
     constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63, sub = lane & (G - 1);
     const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / G;
@@ -60,12 +63,13 @@ __global__ __launch_bounds__(256) void kmm_masked_softmax_kernel(float* __restri
     if (causal && q + 1 < hi) hi = q + 1;
     if (!live) hi = lo;
     float* p = x + (live ? row : 0) * T;
+    const unsigned char* kv = kvalid ? kvalid + (live ? row / rows_per_b : 0) * T : nullptr;
     float m = -INFINITY;
-    for (int i = lo + sub; i < hi; i += G) m = fmaxf(m, p[i]);
+    for (int i = lo + sub; i < hi; i += G) m = fmaxf(m, (!kv || kv[i]) ? p[i] : -INFINITY);
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     float s = 0.f;
-    for (int i = lo + sub; i < hi; i += G) s += expf(p[i] - m);
+    for (int i = lo + sub; i < hi; i += G) s += expf(((!kv || kv[i]) ? p[i] : -INFINITY) - m);
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (!live) return;
@@ -73,15 +77,16 @@ __global__ __launch_bounds__(256) void kmm_masked_softmax_kernel(float* __restri
     // row has no key at all (exp(-inf - -inf)) or holds a NaN score (0 * NaN)
     const float inv = 1.0f / s;
     for (int i = sub; i < T; i += G) {
-        const bool in = i >= lo && i < hi;
+        const bool in = i >= lo && i < hi && (!kv || kv[i]);
         p[i] = expf((in ? p[i] : -INFINITY) - m) * inv;
     }
 }
 
-static int masked_softmax(float* S, int64_t rows, int T, int NQ, int causal, int window, hipStream_t st) {
+static int masked_softmax(float* S, int64_t rows, int T, int NQ, int causal, int window, const unsigned char* kvalid, int rows_per_b,
+                          hipStream_t st) {
 #define KMM_MS(G)                                                                                                              \
     hipLaunchKernelGGL(kmm_masked_softmax_kernel<G>, dim3((unsigned)((rows + 4 * (64 / G) - 1) / (4 * (64 / G)))), dim3(256), 0, st, S, \
-                       rows, T, NQ, causal, window)
+                       rows, T, NQ, causal, window, kvalid, rows_per_b)
     if (T <= 1) KMM_MS(1);
     else if (T <= 4) KMM_MS(4);
     else if (T <= 16) KMM_MS(16);
@@ -180,8 +185,8 @@ int64_t koemorph_ws_floats(Context* c, int64_t T) {
 }
 
 // one stream of DualStreamEncoder (dual_stream_attention.py:369-388): x = LN(ReLU(in W0^T + b0)), then the post-norm layers
-static int encode_stream(Context* c, const char* stream, const float* in, int in_dim, int64_t B, int64_t T, float* x, float* qkv,
-                         float* S, float* O, float* ffn, hipStream_t st) {
+static int encode_stream(Context* c, const char* stream, const float* in, int in_dim, int64_t B, int64_t T, const unsigned char* kvalid,
+                         float* x, float* qkv, float* S, float* O, float* ffn, hipStream_t st) {
     const int d = c->d, HE = 8, hde = d / HE;
     const int64_t R = B * T;
     const std::string p = std::string("audio_encoder.") + stream + "_encoder.";
@@ -198,7 +203,8 @@ static int encode_stream(Context* c, const char* stream, const float* in, int in
         g.C = S; g.c_rs = T; g.c_bs1 = (int64_t)HE * T * T; g.c_bs2 = T * T;
         g.M = (int)T; g.N = (int)T; g.K = hde; g.batch2 = HE;
         if (int rc = launch_gemm(g, (int)(B * HE), st)) return rc;
-        if (int rc = launch_softmax_rows(S, B * HE * T, (int)T, st)) return rc;
+        if (kvalid) { if (int rc = masked_softmax(S, B * HE * T, (int)T, (int)T, 0, -1, kvalid, (int)(HE * T), st)) return rc; }
+        else if (int rc = launch_softmax_rows(S, B * HE * T, (int)T, st)) return rc;
         g = GemmArgs{};                                     // O[b][:, h] (T x hd) = P V_h
         g.alpha = 1.f;
         g.A = S; g.a_rs = T; g.a_cs = 1; g.a_bs1 = (int64_t)HE * T * T; g.a_bs2 = T * T;
@@ -216,8 +222,8 @@ static int encode_stream(Context* c, const char* stream, const float* in, int in
     return KM_OK;
 }
 
-int launch_koemorph(Context* c, const float* mel, const float* emo, int64_t B, int64_t T, const float* prev, float* state,
-                    int apply_constraints, float* out, float* raw, float* attn, void* stream) {
+int launch_koemorph(Context* c, const float* mel, const float* emo, int64_t B, int64_t T, const unsigned char* kvalid, const float* prev,
+                    float* state, int apply_constraints, float* out, float* raw, float* attn, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const km_koemorph_config& k = c->kmm;
     const int d = c->d, H = c->H, hd = c->hd, NB = c->NB, hid = k.decoder_hidden_dim, L = k.num_attention_layers;
@@ -238,8 +244,8 @@ int launch_koemorph(Context* c, const float* mel, const float* emo, int64_t B, i
     float* cond = dB + RQ * hid;
     float* cond1 = cond + B * d;
     // ---- DualStreamEncoder on both streams, then the average (gaussian_face.py:203-209) ----
-    if (int rc = encode_stream(c, "mel", mel, k.mel_dim, B, T, xm, qkv, S, O, ffn, st)) return rc;
-    if (int rc = encode_stream(c, "emotion", emo, k.emotion_dim, B, T, xe, qkv, S, O, ffn, st)) return rc;
+    if (int rc = encode_stream(c, "mel", mel, k.mel_dim, B, T, kvalid, xm, qkv, S, O, ffn, st)) return rc;
+    if (int rc = encode_stream(c, "emotion", emo, k.emotion_dim, B, T, kvalid, xe, qkv, S, O, ffn, st)) return rc;
     hipLaunchKernelGGL(kmm_avg_kernel, dim3((unsigned)((R * d + 255) / 256)), dim3(256), 0, st, xm, xe, xm, R * d);
     // ---- queries (attention.py:481-514) ----
     if (prev) {
@@ -267,7 +273,7 @@ int launch_koemorph(Context* c, const float* mel, const float* emo, int64_t B, i
         g.C = S; g.c_rs = T; g.c_bs1 = (int64_t)H * NB * T; g.c_bs2 = (int64_t)NB * T;
         g.M = NB; g.N = (int)T; g.K = hd; g.batch2 = H;
         if (int rc = launch_gemm(g, (int)(B * H), st)) return rc;
-        if (int rc = masked_softmax(S, B * H * NB, (int)T, NB, k.causal, k.window_size, st)) return rc;
+        if (int rc = masked_softmax(S, B * H * NB, (int)T, NB, k.causal, k.window_size, kvalid, H * NB, st)) return rc;
         if (attn)
             HIP_TRY(hipMemcpyAsync(attn + (int64_t)i * B * H * NB * T, S, (size_t)(B * H * NB * T) * sizeof(float), hipMemcpyDeviceToDevice, st));
         g = GemmArgs{};                                     // O2[b][:, h] (NB x hd) = P V_h

@@ -11,8 +11,8 @@ libkoemorph_hip.so (``km_koemorph_forward``): exact-fp32 MFMA GEMMs + row kernel
 Dropout layers are the identity).  Differences, all loud:
   * ``d_query`` must equal ``d_model`` (the reference's own residual ``attn_out + attention_output`` raises otherwise,
     its default ``d_query=128`` included);
-  * ``audio_mask`` other than ``None``, smoothing methods other than "exponential", ``output_activation`` other than
-    "sigmoid" and decoder activations other than relu / gelu raise ``NotImplementedError``;
+  * smoothing methods other than "exponential", ``output_activation`` other than "sigmoid" and decoder activations
+    other than relu / gelu raise ``NotImplementedError``;
   * there is no CPU fallback.
 """
 from __future__ import annotations
@@ -196,8 +196,6 @@ class KoeMorphModel(nn.Module):
     def forward(self, mel_features: torch.Tensor, emotion_features: torch.Tensor, audio_mask: Optional[torch.Tensor] = None,
                 prev_blendshapes: Optional[torch.Tensor] = None, apply_smoothing: bool = True, apply_constraints: bool = True,
                 return_attention: bool = False) -> Dict[str, torch.Tensor]:
-        if audio_mask is not None:
-            raise NotImplementedError("audio_mask: padded batches are not built; pass equal-length windows")
         if self.training and torch.is_grad_enabled():
             raise RuntimeError("the HIP forward implements eval-mode arithmetic; call .eval() or torch.no_grad()")
         if mel_features.dim() != 3 or emotion_features.dim() != 3 or mel_features.shape[:2] != emotion_features.shape[:2]:
@@ -213,6 +211,11 @@ class KoeMorphModel(nn.Module):
             self._reserved = (max(B, self._reserved[0]), max(T, self._reserved[1]))
         nb = self.num_blendshapes
         prev = None if prev_blendshapes is None else prev_blendshapes.float().contiguous()
+        valid = None
+        if audio_mask is not None:                        # (B, T) bool, True = valid frame
+            if tuple(audio_mask.shape) != (B, T):
+                raise ValueError(f"audio_mask must be (B, T) = {(B, T)}, got {tuple(audio_mask.shape)}")
+            valid = audio_mask.to(device=dev, dtype=torch.uint8).contiguous()
         smooth = apply_smoothing and self.use_temporal_smoothing
         if smooth and (self._smoother_state is None or self._smoother_state.shape[0] != B):
             # decoder.py:282-283: the (1, 52) state is expanded to the batch (zeros after a reset)
@@ -223,7 +226,8 @@ class KoeMorphModel(nn.Module):
         L = len(self.cross_attention_layers)
         attn = torch.empty(L, B, self.num_heads, nb, T, device=dev) if return_attention and L else None
         with torch.cuda.device(dev):
-            check(lib.km_koemorph_forward(h, _ptr(mel), _ptr(emo), B, T, _ptr(prev) if prev is not None else None,
+            check(lib.km_koemorph_forward(h, _ptr(mel), _ptr(emo), B, T, _ptr(valid) if valid is not None else None,
+                                          _ptr(prev) if prev is not None else None,
                                           _ptr(self._smoother_state) if smooth else None, 1 if apply_constraints else 0,
                                           _ptr(out), _ptr(raw), _ptr(attn) if attn is not None else None, _stream_ptr(dev)))
         output = {"blendshapes": out, "raw_blendshapes": raw}

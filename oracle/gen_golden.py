@@ -117,6 +117,10 @@ KOEMORPH_CASES = [
                                                  decoder_hidden_dim=64, decoder_layers=1, decoder_activation="relu",
                                                  causal=False, window_size=None, use_constraints=False, emotion_dim=88),
          B=2, T=75, seed=63),
+    # padded batch: audio_mask with 20 / 13 / 7 valid frames
+    dict(name="koemorph_d64_T20_padded", cfg=dict(d_model=64, num_heads=4, num_encoder_layers=2, num_attention_layers=2,
+                                                  decoder_hidden_dim=32, decoder_layers=1, emotion_dim=24), B=3, T=20, seed=65,
+         valid=[20, 13, 7]),
     # default mask at T = 256: rows >= 5 have every key masked -> NaN in the reference (SURVEY: "default config is broken")
     dict(name="koemorph_d64_T256_masked", cfg=dict(d_model=64, num_heads=4, num_encoder_layers=1, num_attention_layers=1,
                                                    decoder_hidden_dim=32, decoder_layers=1, emotion_dim=24), B=1, T=256, seed=64),
@@ -156,9 +160,13 @@ def main_koemorph():
         mel, emo = koemorph_inputs(synth, c["seed"], c["B"], c["T"], kc.mel_dim, kc.emotion_dim)
         mel2, emo2 = koemorph_inputs(synth, c["seed"] + 100, c["B"], c["T"], kc.mel_dim, kc.emotion_dim)
         rec = {"config": json.dumps(dict(cfg=kc.to_dict(), B=c["B"], T=c["T"], seed=c["seed"]))}
+        am = None
+        if c.get("valid"):
+            am = torch.arange(c["T"])[None, :] < torch.tensor(c["valid"])[:, None]
+            rec["valid"] = np.asarray(c["valid"], dtype=np.int32)
         with torch.no_grad():
-            o1 = m(torch.from_numpy(mel), torch.from_numpy(emo), return_attention=True)
-            o2 = m(torch.from_numpy(mel2), torch.from_numpy(emo2), prev_blendshapes=o1["blendshapes"], return_attention=True)
+            o1 = m(torch.from_numpy(mel), torch.from_numpy(emo), audio_mask=am, return_attention=True)
+            o2 = m(torch.from_numpy(mel2), torch.from_numpy(emo2), audio_mask=am, prev_blendshapes=o1["blendshapes"], return_attention=True)
         for tag, o in (("f1", o1), ("f2", o2)):
             rec[tag + "/blendshapes"] = o["blendshapes"].numpy()
             rec[tag + "/raw_blendshapes"] = o["raw_blendshapes"].numpy()

@@ -128,23 +128,27 @@ def _heads(x, H):
     return x.view(B, N, H, d // H).transpose(1, 2)          # (B, H, N, hd)
 
 
-def _encoder_layer(x, P, p, H):
-    """nn.TransformerEncoderLayer, norm_first=False, activation gelu, eval mode."""
+def _encoder_layer(x, P, p, H, key_valid=None):
+    """nn.TransformerEncoderLayer, norm_first=False, activation gelu, eval mode; key_valid (B, T) True = attend
+    (src_key_padding_mask = ~key_valid, dual_stream_attention.py:371-374)."""
     d = x.shape[-1]
     qkv = F.linear(x, P[p + "self_attn.in_proj_weight"], P[p + "self_attn.in_proj_bias"])
     q, k, v = (_heads(t, H) for t in qkv.split(d, dim=-1))
-    a = torch.softmax(q @ k.transpose(-2, -1) / math.sqrt(d // H), dim=-1) @ v
+    s = q @ k.transpose(-2, -1) / math.sqrt(d // H)
+    if key_valid is not None:
+        s = s.masked_fill(~key_valid[:, None, None, :], float("-inf"))
+    a = torch.softmax(s, dim=-1) @ v
     a = a.transpose(1, 2).reshape(x.shape)
     x = _ln(x + F.linear(a, P[p + "self_attn.out_proj.weight"], P[p + "self_attn.out_proj.bias"]), P, p + "norm1.")
     ff = F.linear(_gelu(F.linear(x, P[p + "linear1.weight"], P[p + "linear1.bias"])), P[p + "linear2.weight"], P[p + "linear2.bias"])
     return _ln(x + ff, P, p + "norm2.")
 
 
-def encode_stream(x, P, stream, num_layers):
+def encode_stream(x, P, stream, num_layers, key_valid=None):
     p = f"audio_encoder.{stream}_encoder."
     x = _ln(torch.relu(F.linear(x, P[p + "0.weight"], P[p + "0.bias"])), P, p + "3.")
     for i in range(num_layers):
-        x = _encoder_layer(x, P, f"audio_encoder.{stream}_transformer.layers.{i}.", ENCODER_HEADS)
+        x = _encoder_layer(x, P, f"audio_encoder.{stream}_transformer.layers.{i}.", ENCODER_HEADS, key_valid)
     return x
 
 
@@ -163,14 +167,18 @@ def attention_mask(nq: int, T: int, causal: bool, window_size: Optional[int]) ->
 
 
 def koemorph_forward(params: Dict[str, np.ndarray], c: KoeMorphConfig, mel, emotion, prev_blendshapes=None,
-                     smoother_state=None, apply_smoothing=True, apply_constraints=True, dtype=torch.float64):
-    """Returns dict(blendshapes, raw_blendshapes, attention_weights [L x (B, H, 52, T)], smoother_state)."""
+                     smoother_state=None, apply_smoothing=True, apply_constraints=True, dtype=torch.float64, audio_mask=None):
+    """Returns dict(blendshapes, raw_blendshapes, attention_weights [L x (B, H, 52, T)], smoother_state).
+    audio_mask (B, T) bool, True = valid frame (gaussian_face.py:180,204,224): padded frames are masked as keys in the
+    encoder's self-attention and in every cross-attention layer.  What the encoder leaves AT padded positions never
+    reaches the output (torch's eval fast path zeroes them, the plain path does not), so it is not pinned."""
     P = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype) for k, v in params.items()}
     mel = torch.as_tensor(np.asarray(mel)).to(dtype)
     emo = torch.as_tensor(np.asarray(emotion)).to(dtype)
     B, T, _ = mel.shape
     d, H, nb = c.d_model, c.num_heads, c.num_blendshapes
-    enc = (encode_stream(mel, P, "mel", c.num_encoder_layers) + encode_stream(emo, P, "emotion", c.num_encoder_layers)) / 2
+    valid = None if audio_mask is None else torch.as_tensor(np.asarray(audio_mask)).bool()
+    enc = (encode_stream(mel, P, "mel", c.num_encoder_layers, valid) + encode_stream(emo, P, "emotion", c.num_encoder_layers, valid)) / 2
     x = P["query_embeddings.query_embeddings"].unsqueeze(0).repeat(B, 1, 1)
     prev = None if prev_blendshapes is None else torch.as_tensor(np.asarray(prev_blendshapes)).to(dtype)
     if prev is not None:
@@ -186,6 +194,8 @@ def koemorph_forward(params: Dict[str, np.ndarray], c: KoeMorphConfig, mel, emot
         v = _heads(F.linear(enc, P[p + "v_proj.weight"], P[p + "v_proj.bias"]), H)
         s = (q @ k.transpose(-2, -1)) * scale
         s = s.masked_fill(mask, float("-inf"))
+        if valid is not None:
+            s = s.masked_fill(~valid[:, None, None, :], float("-inf"))
         w = torch.softmax(s, dim=-1)
         attn.append(w)
         o = (w @ v).transpose(1, 2).reshape(B, nb, d)

@@ -10,7 +10,7 @@ import torch
 from koemorph_amd import _lib
 from koemorph_amd.model import KoeMorphModel, create_koemorph_model
 from oracle import koemorph_model as okm
-from test_oracle_koemorph import GOLDEN, assert_same, load_case
+from test_oracle_koemorph import GOLDEN, assert_same, case_mask, load_case
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4          # north-star tolerance on the 52 coefficients; observed <= 3e-6
@@ -33,9 +33,12 @@ def build(cfg: okm.KoeMorphConfig, params):
 def test_two_frames_match_reference_golden(path):
     z, cfg, params, (mel1, emo1), (mel2, emo2) = load_case(path)
     m = build(cfg, params)
+    am = case_mask(z, mel1.shape[1])
+    am = None if am is None else torch.from_numpy(am).cuda()
     with torch.no_grad():
-        o1 = m(torch.from_numpy(mel1).cuda(), torch.from_numpy(emo1).cuda(), return_attention=True)
-        o2 = m(torch.from_numpy(mel2).cuda(), torch.from_numpy(emo2).cuda(), prev_blendshapes=o1["blendshapes"], return_attention=True)
+        o1 = m(torch.from_numpy(mel1).cuda(), torch.from_numpy(emo1).cuda(), audio_mask=am, return_attention=True)
+        o2 = m(torch.from_numpy(mel2).cuda(), torch.from_numpy(emo2).cuda(), audio_mask=am, prev_blendshapes=o1["blendshapes"],
+               return_attention=True)
     for tag, o in (("f1", o1), ("f2", o2)):
         assert_same(o["blendshapes"].cpu().numpy(), z[tag + "/blendshapes"], TOL)
         assert_same(o["raw_blendshapes"].cpu().numpy(), z[tag + "/raw_blendshapes"], TOL)
@@ -96,8 +99,8 @@ def test_error_paths():
         KoeMorphModel(d_query=256, smoothing_method="median")
     m = KoeMorphModel(d_model=64, d_query=64, num_heads=4, num_encoder_layers=0, num_attention_layers=1, decoder_hidden_dim=32,
                       emotion_dim=8).cuda().eval()
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 4, 80).cuda(), torch.zeros(1, 4, 8).cuda(), audio_mask=torch.ones(1, 4, dtype=torch.bool).cuda())
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 4, 80).cuda(), torch.zeros(1, 4, 8).cuda(), audio_mask=torch.ones(1, 5, dtype=torch.bool).cuda())
     with pytest.raises(ValueError):
         m(torch.zeros(1, 4, 80).cuda(), torch.zeros(1, 5, 8).cuda())
     with torch.no_grad():
@@ -105,7 +108,7 @@ def test_error_paths():
     lib = _lib.load()
     h = m._h
     with pytest.raises(_lib.KoeMorphError):               # workspace was reserved for 2 x 4 frames
-        _lib.check(lib.km_koemorph_forward(h, C.c_void_p(8), C.c_void_p(8), 64, 64, None, None, 0, C.c_void_p(8), None, None, None))
+        _lib.check(lib.km_koemorph_forward(h, C.c_void_p(8), C.c_void_p(8), 64, 64, None, None, None, 0, C.c_void_p(8), None, None, None))
     with pytest.raises(_lib.KoeMorphError):
         _lib.check(lib.km_reserve(h, 1, 16000))           # audio workspace entry point on a KoeMorphModel handle
 
@@ -125,3 +128,22 @@ def test_key_axis_lengths_against_oracle(T):
     assert_same(o["blendshapes"].cpu().numpy(), w["blendshapes"], TOL)
     for a, b in zip(o["attention_weights"], w["attention_weights"]):
         assert_same(a.cpu().numpy(), b, TOL)
+
+
+def test_padding_is_invisible():
+    """A padded batch gives each item the result of its own unpadded forward (reference tests/model/test_koemorph_model.py:77-97
+    only checks the shape): frames behind the mask never reach the output, whatever they hold."""
+    from koemorph_amd import synth
+    cfg = okm.KoeMorphConfig(d_model=64, num_heads=4, num_encoder_layers=2, num_attention_layers=2, decoder_hidden_dim=32,
+                             decoder_layers=1, emotion_dim=24, causal=False, window_size=None)
+    params = okm.make_koemorph_params(91, cfg)
+    m = build(cfg, params)
+    T, lens = 24, [24, 17, 5, 1]
+    mel, emo = synth.normal(5, (4, T, 80)), synth.normal(6, (4, T, 24))
+    mask = torch.arange(T)[None, :] < torch.tensor(lens)[:, None]
+    junk = mel.copy(); junk[~mask.numpy()] = 1e3                                  # garbage in the padded frames
+    with torch.no_grad():
+        padded = m(torch.from_numpy(junk).cuda(), torch.from_numpy(emo).cuda(), audio_mask=mask.cuda(), apply_smoothing=False)["blendshapes"].cpu().numpy()
+        for i, n in enumerate(lens):
+            alone = m(torch.from_numpy(mel[i:i + 1, :n]).cuda(), torch.from_numpy(emo[i:i + 1, :n]).cuda(), apply_smoothing=False)["blendshapes"].cpu().numpy()
+            np.testing.assert_allclose(padded[i:i + 1], alone, atol=2e-6)

@@ -24,6 +24,11 @@ def load_case(path):
     return z, cfg, params, f1, f2
 
 
+def case_mask(z, T):
+    """audio_mask (B, T) of a padded-batch fixture (True = valid frame), or None."""
+    return None if "valid" not in z.files else np.arange(T)[None, :] < z["valid"][:, None]
+
+
 def assert_same(got, want, atol):
     assert got.shape == want.shape
     assert np.array_equal(np.isnan(got), np.isnan(want))
@@ -32,14 +37,15 @@ def assert_same(got, want, atol):
 
 
 def test_golden_files_present():
-    assert len(GOLDEN) == 4
+    assert len(GOLDEN) == 5
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_oracle_matches_reference_two_frames(path):
     z, cfg, params, (mel1, emo1), (mel2, emo2) = load_case(path)
-    o1 = km.koemorph_forward(params, cfg, mel1, emo1)
-    o2 = km.koemorph_forward(params, cfg, mel2, emo2, prev_blendshapes=o1["blendshapes"], smoother_state=o1["smoother_state"])
+    am = case_mask(z, mel1.shape[1])
+    o1 = km.koemorph_forward(params, cfg, mel1, emo1, audio_mask=am)
+    o2 = km.koemorph_forward(params, cfg, mel2, emo2, prev_blendshapes=o1["blendshapes"], smoother_state=o1["smoother_state"], audio_mask=am)
     for tag, o in (("f1", o1), ("f2", o2)):
         assert_same(o["blendshapes"], z[tag + "/blendshapes"], 2e-6)
         assert_same(o["raw_blendshapes"], z[tag + "/raw_blendshapes"], 2e-6)
