@@ -151,7 +151,7 @@ int launch_softmax_rows(float* x, int64_t rows, int w, void* stream);
 //     barrier per k tile.
 // ---------------------------------------------------------------------------------------------------------
 namespace gnt {
-constexpr int BM = 128, BK = 16;
+constexpr int BK = 16;
 }
 
 // Tiles are fetched with buffer loads: an out-of-range row points past the descriptor's range and reads zeros without a
@@ -172,9 +172,10 @@ __device__ __forceinline__ void nt_commit(float* dst, int tid, const nt_u32x4 (&
 // PIN: scheduling barriers hold the next tile's loads at the top of a k step and its LDS commit at the bottom.  Short
 // contractions (K <= 256: 16 steps, the legacy model's products) gain 7 % from it; long ones (K = 512, C4's value
 // projection on 128-column tiles) lose 2 % to the extra live registers, so the launcher picks per product.
-template <int NT, bool PIN>   // 16-column MFMA tiles per wave: 4 -> BN 128, 2 -> BN 64
+template <int MT, int NT, bool PIN>   // 16-row / 16-column MFMA tiles per wave: MT 4 -> BM 128, 2 -> BM 64; NT 4 -> BN 128, 2 -> BN 64
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     using namespace gnt;
+    constexpr int BM = 32 * MT;
     constexpr int BN = 32 * NT;
     __shared__ __attribute__((aligned(16))) float As[2][4 * BM * 4];
     __shared__ __attribute__((aligned(16))) float Bs[2][4 * BN * 4];
@@ -207,9 +208,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     }
     nt_u32x4 ra[EA], rb[EB];
 
-    f32x4 acc[4][NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int jn = 0; jn < NT; ++jn) acc[i][jn] = f32x4{0, 0, 0, 0};
 
@@ -227,15 +228,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
         if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);   // ... and the loads stay ahead of them (the scheduler sinks them to save registers)
         const float* as = As[buf];
         const float* bs = Bs[buf];
-        f32x4 af[4], bf[NT];
+        f32x4 af[MT], bf[NT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + (lg * BM + 64 * wm + 16 * i + lj) * 4);
+        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + (lg * BM + 16 * MT * wm + 16 * i + lj) * 4);
 #pragma unroll
         for (int jn = 0; jn < NT; ++jn) bf[jn] = *reinterpret_cast<const f32x4*>(bs + (lg * BN + 16 * NT * wn + 16 * jn + lj) * 4);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int jn = 0; jn < NT; ++jn) acc[i][jn] = KM_MFMA(af[i][s], bf[jn][s], acc[i][jn]);
         // the other buffer: its last readers passed the previous barrier (after the last tile: written, never read)
@@ -245,12 +246,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int jn = 0; jn < NT; ++jn)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 64 * wm + 16 * i + 4 * lg + r, n = n0 + 16 * NT * wn + 16 * jn + lj;
+                const int m = m0 + 16 * MT * wm + 16 * i + 4 * lg + r, n = n0 + 16 * NT * wn + 16 * jn + lj;
                 if (m < g.M && n < g.N) {
                     float v = g.alpha * acc[i][jn][r];
                     if (g.bias_mode == 1) v += g.bias[n];
@@ -277,19 +278,30 @@ int launch_gemm(const GemmArgs& g, int batch, void* stream) {
 #ifndef KM_NT_MIN_WGS
 #define KM_NT_MIN_WGS 192
 #endif
-    // the 128-row tiles only pay off when they still fill the chip (training-sized products stay on 64 x 64 tiles)
-    const int64_t mt_wgs = (int64_t)batch * ((g.M + 127) / 128);
-    const int64_t wgs4 = mt_wgs * ((g.N + 127) / 128), wgs2 = mt_wgs * ((g.N + 63) / 64);
+    // largest tile that still gives the chip >= 192 workgroups: 128 x 128, 128 x 64, then 64 x 64 (16 accumulator registers:
+    // several workgroups per CU, which a 16-step contraction needs to hide its barriers)
+    const int64_t mt_wgs = (int64_t)batch * ((g.M + 127) / 128), mt64_wgs = (int64_t)batch * ((g.M + 63) / 64);
+    const int64_t wgs4 = mt_wgs * ((g.N + 127) / 128), wgs2 = mt_wgs * ((g.N + 63) / 64), wgs22 = mt64_wgs * ((g.N + 63) / 64);
     static const bool mid = std::getenv("KM_GEMM_NO_NT2_MID") == nullptr;
+    static const bool small = std::getenv("KM_GEMM_NO_64_TILE") == nullptr;
+    static const int64_t small_below = std::getenv("KM_GEMM_64_BELOW") ? atoll(std::getenv("KM_GEMM_64_BELOW")) : 1024;   // < 4 big tiles per CU
     const bool use4 = g.N > 64 && wgs4 >= KM_NT_MIN_WGS;
-    if (fast && gemm_nt_ok(g) && (use4 || (wgs2 >= KM_NT_MIN_WGS && (mid || g.N <= 64)))) {
+    const bool use2 = !use4 && wgs2 >= KM_NT_MIN_WGS && (mid || g.N <= 64);
+    const bool use22 = small && gemm_nt_ok(g) && ((!use4 && !use2 && wgs22 >= KM_NT_MIN_WGS) || ((use4 ? wgs4 : wgs2) < small_below && (use4 || use2)));
+    if (fast && use22) {
+        const dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)batch);
+        hipLaunchKernelGGL((gemm_nt_kernel<2, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
+        HIP_TRY(hipGetLastError());
+        return KM_OK;
+    }
+    if (fast && gemm_nt_ok(g) && (use4 || use2)) {
         if (use4) {
-            const dim3 grid((unsigned)((g.N + 127) / 128), (unsigned)((g.M + gnt::BM - 1) / gnt::BM), (unsigned)batch);
-            if (g.K <= 256) hipLaunchKernelGGL((gemm_nt_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
-            else hipLaunchKernelGGL((gemm_nt_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, g);
+            const dim3 grid((unsigned)((g.N + 127) / 128), (unsigned)((g.M + 127) / 128), (unsigned)batch);
+            if (g.K <= 256) hipLaunchKernelGGL((gemm_nt_kernel<4, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, g);
+            else hipLaunchKernelGGL((gemm_nt_kernel<4, 4, false>), grid, dim3(256), 0, (hipStream_t)stream, g);
         } else {
-            const dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + gnt::BM - 1) / gnt::BM), (unsigned)batch);
-            hipLaunchKernelGGL((gemm_nt_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, g);   // 80 registers either way
+            const dim3 grid((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 127) / 128), (unsigned)batch);
+            hipLaunchKernelGGL((gemm_nt_kernel<4, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, g);   // 80 registers either way
         }
         HIP_TRY(hipGetLastError());
         return KM_OK;
