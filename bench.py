@@ -159,6 +159,11 @@ def main():
             pmc = json.load(open(pmc_path))
         except Exception:
             pmc = {}
+    sq = {}
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "pmc_sq.json")))["core_fused_kernel"]["derived"]
+    except Exception:
+        sq = {}
     roof_core = {"kernel": "core_fused_kernel<false,true>", "bound": "mfma", "achieved": round(core_tflops, 3),
                  "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(core_tflops / PEAK_F32_MFMA_TFLOPS, 4),
                  "traffic": (pmc.get("core_fused_kernel") or {}).get("hbm_bytes_per_launch"),
@@ -166,6 +171,12 @@ def main():
                  # the kernel executes fewer FLOPs than the reference formulation (folded projections):
                  "executed_mfma_flops_per_launch": EXECUTED_MFMA_FLOPS_PER_FRAME * B,
                  "mfma_pipe_util": round(EXECUTED_MFMA_FLOPS_PER_FRAME * B / t_core / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                 # matrix-pipe busy cycles / CU-busy cycles from the SQ counters of the same step (profiles/pmc_sq.json)
+                 "mfma_busy_frac_pmc": sq.get("mfma_util_of_cu_busy"),
+                 # the north star's literal "attention-GEMM roofline": QK^T + PV alone are 2.29 of the 48.8 MFLOP per frame
+                 "attention_gemm_only": {"flops_per_frame": 2.294e6,
+                                         "achieved": round(2.294e6 * B / t_core / 1e12, 3), "unit": "TFLOP/s",
+                                         "frac": round(2.294e6 * B / t_core / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
                  "note": "achieved/frac use the ALGORITHMIC FLOPs of the reference formulation (48.8 M/frame, SURVEY 8d); "
                          "eval-mode weight folding executes 35.2 M/frame, so frac can exceed 1 -- mfma_pipe_util is the "
                          "hardware figure (a pure MFMA loop sustains 0.88-0.93 of the nominal peak, tools/micro/mfma_rate.hip)"}
