@@ -227,6 +227,13 @@ class RealTimeInference:
             mel_sequence_length=int(cfg.get("mel_sequence_length", 256)), device=str(self.device),
             real_time_mode=True, emotion_provider=emotion_provider)
         state = checkpoint.get("model_state_dict", checkpoint)
+        if any(k.startswith("audio_encoder.mel_encoder.") for k in state):
+            # a checkpoint of the legacy multi-layer model (reference create_koemorph_model, scripts/rt.py:283-304).  The
+            # reference's own loop cannot run it either: inference_step (scripts/rt.py:349-367) passes four positional
+            # arguments, prosody features among them, to KoeMorphModel.inference_step(mel, emotion, prev).
+            raise ValueError("this checkpoint holds the legacy multi-layer KoeMorphModel; load it with "
+                             "koemorph_amd.model.create_koemorph_model(config) and drive inference_step(mel_features, "
+                             "emotion_features, prev_blendshapes) directly -- scripts/rt.py serves the dual-stream model")
         model.load_state_dict(state)
         return model.to(self.device).eval()
 

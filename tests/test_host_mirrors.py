@@ -169,3 +169,18 @@ def test_train_sequential_cli():
         (10, 8, 256, 1, 1e-4, 1e-5, 1.0)                               # train_sequential.py:73-86 defaults
     with pytest.raises(SystemExit):
         ts.build_parser().parse_args([])
+
+
+def test_rt_rejects_legacy_koemorph_checkpoint(tmp_path):
+    """A checkpoint of the legacy multi-layer model is refused with a pointer to its mirror (the reference's own rt.py loop
+    cannot drive that class either: it passes prosody features to a three-argument inference_step)."""
+    import torch
+    from koemorph_amd.model import KoeMorphModel
+    m = KoeMorphModel(d_model=64, d_query=64, num_heads=4, num_encoder_layers=1, num_attention_layers=1, decoder_hidden_dim=32,
+                      emotion_dim=8)
+    path = tmp_path / "legacy.pt"
+    torch.save({"model_state_dict": m.state_dict()}, path)
+    r = rt.RealTimeInference.__new__(rt.RealTimeInference)
+    r.sample_rate, r.target_fps, r.device = 16000, 30.0, torch.device("cpu")
+    with pytest.raises(ValueError, match="create_koemorph_model"):
+        r._load_model(str(path), None, None)
