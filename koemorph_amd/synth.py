@@ -210,3 +210,88 @@ def params_checksum(params: Dict[str, np.ndarray]) -> float:
         a = params[k].astype(np.float64).ravel()
         acc += float(np.sum(a * (1.0 + (np.arange(a.size) % 7)))) + float(np.sum(np.abs(a)))
     return acc
+
+
+# ---- legacy multi-layer KoeMorphModel (reference src/model/gaussian_face.py:29-173): configuration, state-dict layout
+# and seeded parameters for tests, fixtures and tools/bench_koemorph.py -------------------------------------------------
+from dataclasses import asdict, dataclass   # noqa: E402
+from typing import Optional                 # noqa: E402
+
+
+@dataclass
+class KoeMorphConfig:
+    mel_dim: int = 80
+    emotion_dim: int = 256
+    d_model: int = 256
+    num_heads: int = 8
+    num_encoder_layers: int = 2
+    num_attention_layers: int = 4
+    decoder_hidden_dim: int = 128
+    decoder_layers: int = 2
+    decoder_activation: str = "gelu"
+    causal: bool = True
+    window_size: Optional[int] = 30
+    use_temporal_smoothing: bool = True
+    use_constraints: bool = True
+    num_blendshapes: int = 52
+
+    def to_dict(self):
+        return asdict(self)
+
+
+
+
+def koemorph_param_shapes(c: KoeMorphConfig):
+    """State-dict keys and shapes of the learnable tensors (buffers of the smoother / constraints excluded)."""
+    d, dq, hid, nb = c.d_model, c.d_model, c.decoder_hidden_dim, c.num_blendshapes
+    s = []
+    for stream, dim in (("mel", c.mel_dim), ("emotion", c.emotion_dim)):
+        p = f"audio_encoder.{stream}_encoder."
+        s += [(p + "0.weight", (d, dim)), (p + "0.bias", (d,)), (p + "3.weight", (d,)), (p + "3.bias", (d,))]
+    for stream in ("mel", "emotion"):
+        for i in range(c.num_encoder_layers):
+            p = f"audio_encoder.{stream}_transformer.layers.{i}."
+            s += [(p + "self_attn.in_proj_weight", (3 * d, d)), (p + "self_attn.in_proj_bias", (3 * d,)),
+                  (p + "self_attn.out_proj.weight", (d, d)), (p + "self_attn.out_proj.bias", (d,)),
+                  (p + "linear1.weight", (4 * d, d)), (p + "linear1.bias", (4 * d,)),
+                  (p + "linear2.weight", (d, 4 * d)), (p + "linear2.bias", (d,)),
+                  (p + "norm1.weight", (d,)), (p + "norm1.bias", (d,)), (p + "norm2.weight", (d,)), (p + "norm2.bias", (d,))]
+    s += [("query_embeddings.query_embeddings", (nb, dq)),
+          ("query_embeddings.conditioning_net.0.weight", (dq // 2, nb)), ("query_embeddings.conditioning_net.0.bias", (dq // 2,)),
+          ("query_embeddings.conditioning_net.3.weight", (dq, dq // 2)), ("query_embeddings.conditioning_net.3.bias", (dq,))]
+    for i in range(c.num_attention_layers):
+        p = f"cross_attention_layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s += [(p + n + ".weight", (d, d)), (p + n + ".bias", (d,))]
+    for i in range(c.num_attention_layers):
+        s += [(f"attention_layer_norms.{i}.weight", (d,)), (f"attention_layer_norms.{i}.bias", (d,))]
+    s += [("decoder.input_proj.weight", (hid, d)), ("decoder.input_proj.bias", (hid,))]
+    for i in range(c.decoder_layers):
+        s += [(f"decoder.hidden_layers.{i}.weight", (hid, hid)), (f"decoder.hidden_layers.{i}.bias", (hid,))]
+    for i in range(c.decoder_layers):
+        s += [(f"decoder.layer_norms.{i}.weight", (hid,)), (f"decoder.layer_norms.{i}.bias", (hid,))]
+    s += [("decoder.output_proj.weight", (nb, hid)), ("decoder.output_proj.bias", (nb,))]
+    if c.use_temporal_smoothing:
+        s += [("temporal_smoother.alpha", ())]
+    return s
+
+
+def make_koemorph_params(seed: int, c: KoeMorphConfig, scale: float = 1.0) -> Dict[str, np.ndarray]:
+    """Seeded 'trained-like' parameters: uniform weights of +-1.5/sqrt(fan_in), LayerNorm gains around 1, small biases."""
+    out = {}
+    for i, (k, shp) in enumerate(koemorph_param_shapes(c)):
+        sd = seed * 1000 + i
+        if k == "temporal_smoother.alpha":
+            out[k] = np.float32(0.8 + 0.1 * float(normal(sd, (1,))[0])).reshape(())
+        elif k == "query_embeddings.query_embeddings":
+            out[k] = normal(sd, shp, std=0.5 * scale)
+        elif (".norm" in k or "layer_norms" in k or "_encoder.3." in k) and k.endswith("weight"):
+            out[k] = (1.0 + 0.1 * normal(sd, shp)).astype(np.float32)
+        elif k.endswith("weight"):
+            b = scale * 1.5 / float(np.sqrt(shp[-1]))
+            out[k] = uniform(sd, shp, -b, b)
+        else:
+            out[k] = normal(sd, shp, std=0.05 * scale)
+    return out
+
+

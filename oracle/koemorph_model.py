@@ -21,7 +21,6 @@ A query row whose keys are all masked is NaN in the reference (softmax over -inf
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, asdict
 from typing import Dict, Optional
 
 import numpy as np
@@ -29,84 +28,11 @@ import torch
 import torch.nn.functional as F
 
 
-@dataclass
-class KoeMorphConfig:
-    mel_dim: int = 80
-    emotion_dim: int = 256
-    d_model: int = 256
-    num_heads: int = 8
-    num_encoder_layers: int = 2
-    num_attention_layers: int = 4
-    decoder_hidden_dim: int = 128
-    decoder_layers: int = 2
-    decoder_activation: str = "gelu"
-    causal: bool = True
-    window_size: Optional[int] = 30
-    use_temporal_smoothing: bool = True
-    use_constraints: bool = True
-    num_blendshapes: int = 52
-
-    def to_dict(self):
-        return asdict(self)
-
+# configuration + seeded parameters live on the product side (data generators, shared with tools/bench_koemorph.py)
+from koemorph_amd.synth import KoeMorphConfig, koemorph_param_shapes as param_shapes, make_koemorph_params  # noqa: E402,F401
 
 ENCODER_HEADS = 8          # nn.TransformerEncoderLayer(nhead=8) is hard-wired (dual_stream_attention.py:338)
 EXCLUSION_PAIRS = ((25, 26), (20, 21))     # decoder.py:384-387
-
-
-def param_shapes(c: KoeMorphConfig):
-    """State-dict keys and shapes of the learnable tensors (buffers of the smoother / constraints excluded)."""
-    d, dq, hid, nb = c.d_model, c.d_model, c.decoder_hidden_dim, c.num_blendshapes
-    s = []
-    for stream, dim in (("mel", c.mel_dim), ("emotion", c.emotion_dim)):
-        p = f"audio_encoder.{stream}_encoder."
-        s += [(p + "0.weight", (d, dim)), (p + "0.bias", (d,)), (p + "3.weight", (d,)), (p + "3.bias", (d,))]
-    for stream in ("mel", "emotion"):
-        for i in range(c.num_encoder_layers):
-            p = f"audio_encoder.{stream}_transformer.layers.{i}."
-            s += [(p + "self_attn.in_proj_weight", (3 * d, d)), (p + "self_attn.in_proj_bias", (3 * d,)),
-                  (p + "self_attn.out_proj.weight", (d, d)), (p + "self_attn.out_proj.bias", (d,)),
-                  (p + "linear1.weight", (4 * d, d)), (p + "linear1.bias", (4 * d,)),
-                  (p + "linear2.weight", (d, 4 * d)), (p + "linear2.bias", (d,)),
-                  (p + "norm1.weight", (d,)), (p + "norm1.bias", (d,)), (p + "norm2.weight", (d,)), (p + "norm2.bias", (d,))]
-    s += [("query_embeddings.query_embeddings", (nb, dq)),
-          ("query_embeddings.conditioning_net.0.weight", (dq // 2, nb)), ("query_embeddings.conditioning_net.0.bias", (dq // 2,)),
-          ("query_embeddings.conditioning_net.3.weight", (dq, dq // 2)), ("query_embeddings.conditioning_net.3.bias", (dq,))]
-    for i in range(c.num_attention_layers):
-        p = f"cross_attention_layers.{i}."
-        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
-            s += [(p + n + ".weight", (d, d)), (p + n + ".bias", (d,))]
-    for i in range(c.num_attention_layers):
-        s += [(f"attention_layer_norms.{i}.weight", (d,)), (f"attention_layer_norms.{i}.bias", (d,))]
-    s += [("decoder.input_proj.weight", (hid, d)), ("decoder.input_proj.bias", (hid,))]
-    for i in range(c.decoder_layers):
-        s += [(f"decoder.hidden_layers.{i}.weight", (hid, hid)), (f"decoder.hidden_layers.{i}.bias", (hid,))]
-    for i in range(c.decoder_layers):
-        s += [(f"decoder.layer_norms.{i}.weight", (hid,)), (f"decoder.layer_norms.{i}.bias", (hid,))]
-    s += [("decoder.output_proj.weight", (nb, hid)), ("decoder.output_proj.bias", (nb,))]
-    if c.use_temporal_smoothing:
-        s += [("temporal_smoother.alpha", ())]
-    return s
-
-
-def make_koemorph_params(seed: int, c: KoeMorphConfig, scale: float = 1.0) -> Dict[str, np.ndarray]:
-    """Seeded 'trained-like' parameters: uniform weights of +-1.5/sqrt(fan_in), LayerNorm gains around 1, small biases."""
-    from koemorph_amd import synth
-    out = {}
-    for i, (k, shp) in enumerate(param_shapes(c)):
-        sd = seed * 1000 + i
-        if k == "temporal_smoother.alpha":
-            out[k] = np.float32(0.8 + 0.1 * float(synth.normal(sd, (1,))[0])).reshape(())
-        elif k == "query_embeddings.query_embeddings":
-            out[k] = synth.normal(sd, shp, std=0.5 * scale)
-        elif (".norm" in k or "layer_norms" in k or "_encoder.3." in k) and k.endswith("weight"):
-            out[k] = (1.0 + 0.1 * synth.normal(sd, shp)).astype(np.float32)
-        elif k.endswith("weight"):
-            b = scale * 1.5 / float(np.sqrt(shp[-1]))
-            out[k] = synth.uniform(sd, shp, -b, b)
-        else:
-            out[k] = synth.normal(sd, shp, std=0.05 * scale)
-    return out
 
 
 def _gelu(x):

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Legacy KoeMorphModel (km_koemorph_forward) on ONE GPU at the reference's default depth (d_model 256, 2 + 2 encoder layers,
 4 cross-attention layers, decoder 128 x 2): windows/s for a batch of T-frame windows and for the T = 1 per-tick form that
-scripts/rt.py feeds, with the CPU oracle (float32 torch, all host cores) timed beside it on a bounded sample."""
+scripts/rt.py feeds.  The CPU figure beside it comes from tests/perf_koemorph_cpu.py (the oracle lives under tests' side of
+the fence: nothing outside tests/, smoke() and bench.py's cpu_baseline leg imports it)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from koemorph_amd import synth
 from koemorph_amd.model import KoeMorphModel
-from oracle import koemorph_model as okm
 
 
 def flops(c, T):
@@ -19,8 +19,8 @@ def flops(c, T):
     return enc + cross + dec
 
 
-cfg = okm.KoeMorphConfig()
-params = okm.make_koemorph_params(5, cfg)
+cfg = synth.KoeMorphConfig()
+params = synth.make_koemorph_params(5, cfg)
 m = KoeMorphModel(d_query=cfg.d_model)
 sd = m.state_dict(); sd.update({k: torch.from_numpy(np.asarray(v)) for k, v in params.items()}); m.load_state_dict(sd)
 m = m.cuda().eval()
@@ -37,15 +37,6 @@ for B, T in CASES:
         n = 20
         for _ in range(n): m(mel, emo, prev_blendshapes=prev)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-    nb = min(B, 16)                                          # bounded CPU sample
-    cores = min(16, os.cpu_count() or 1)                     # the box's CPU share for one GPU
-    torch.set_num_threads(cores)
-    args = (params, cfg, mel[:nb].cpu().numpy(), emo[:nb].cpu().numpy())
-    okm.koemorph_forward(*args, prev_blendshapes=prev[:nb].cpu().numpy(), dtype=torch.float32)       # warm-up
-    t0 = time.perf_counter()
-    for _ in range(3): okm.koemorph_forward(*args, prev_blendshapes=prev[:nb].cpu().numpy(), dtype=torch.float32)
-    cpu = (time.perf_counter() - t0) / (3 * nb)
     print(json.dumps({"workload": f"KoeMorphModel d256, {B} windows x {T} frames", "ms_per_forward": round(dt * 1e3, 3),
                       "windows_per_s": round(B / dt, 1), "mflop_per_window": round(flops(cfg, T) / 1e6, 1),
-                      "algorithmic_tflops": round(flops(cfg, T) * B / dt / 1e12, 2),
-                      "cpu_oracle": {"windows_per_s": round(1 / cpu, 1), "cores": cores, "sample": f"3 x {nb} windows, float32 torch"}}))
+                      "algorithmic_tflops": round(flops(cfg, T) * B / dt / 1e12, 2)}))
