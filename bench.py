@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="windows per GPU per step")
     ap.add_argument("--cpu-windows", type=int, default=256, help="windows per CPU-baseline pass (0 = skip)")
+    ap.add_argument("--no-split", action="store_true", help="skip the experimental split-bf16 timing")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget")
     ap.add_argument("--pipeline", action="store_true",
                     help="two-deep pipeline across steps (km_forward_audio_pipelined) instead of strict stream order; "
@@ -193,6 +194,30 @@ def main():
     else:
         stage_ms["emotion_kernel_d256"] = round(t_emo * 1e3, 4)
 
+    # ---- experimental (NOT the reported value): the same step with phases 2+3 of the core as split-bf16 products,
+    # fp32 accumulation (KM_CORE_SPLIT).  Timed the same way, N=1 only.
+    split = None
+    if n_gpus == 1 and not pipelined and os.environ.get("KM_CORE_SPLIT") is None and not args.no_split:
+        ref_out = eng.forward_audio(audio, emo).clone()
+        split = {"note": "opt-in variant, never used for `value`: fp32 operands of the S / V GEMMs split into 3 (6 product terms) "
+                         "or 2 (3 terms) bf16 pieces on v_mfma_f32_16x16x32_bf16; error study in tests/study_split_bf16.py"}
+        for terms in (6, 3):
+            os.environ["KM_CORE_SPLIT"] = str(terms)
+            try:
+                got = eng.forward_audio(audio, emo).clone()
+                for _ in range(args.warmup):
+                    step()
+                sync()
+                ts = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                sync()
+                dts = time.perf_counter() - ts
+            finally:
+                del os.environ["KM_CORE_SPLIT"]
+            split[f"{terms}_terms"] = {"ms_per_step": round(dts / args.steps * 1e3, 4), "frames_per_s": round(B * args.steps / dts, 1),
+                                       "max_abs_diff_vs_f32_kernel": float((got - ref_out).abs().max())}
+
     # ---- CPU baseline: the oracle on this host's cores (rank 0, N=1 only), bounded sample ----------
     cpu = None
     if rank == 0 and n_gpus == 1 and args.cpu_windows > 0:
@@ -228,6 +253,7 @@ def main():
                                    "window 256 -> 52 coefficients + EMA; from audio resident in HBM",
                        "windows_per_gpu": B, "samples_per_window": L, "parallelism": f"window-sharded x{n_gpus}, no collective"},
             "roofline": roofline, "roofline_other_kernel": other, "kernel_ms": stage_ms, "cpu_baseline": cpu,
+            "experimental_split_bf16": split,
         }
         print(json.dumps(line))
     if dist is not None:

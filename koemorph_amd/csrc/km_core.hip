@@ -52,7 +52,15 @@ constexpr int KB = 16;               // 16-wide k blocks of the d=256 contractio
 constexpr int R1_FLOATS = KTP * NK;  // 21120: X [264][80]  ==  Y [80][264]
 constexpr int R2_FLOATS = 2 * NW * NK;   // 1280: cross-wave reduction scratch, one [80 rows][8 waves] image per LayerNorm pass
 constexpr int LDS_BYTES = (R1_FLOATS + R2_FLOATS) * 4;
+// split-bf16 variant (NP pieces per fp32 value): Y lives in LDS as NP planes [80][YSB] of bf16
+constexpr int YSB = 264;                            // bf16 per plane row: 132 dwords = 4 (mod 64), conflict-free b128 fragments
+constexpr int PLANE_FLOATS = NK * YSB / 2;          // 10560
+constexpr int r1_floats(int np) { return np * PLANE_FLOATS > R1_FLOATS ? np * PLANE_FLOATS : R1_FLOATS; }
+constexpr int lds_bytes(int np) { return (r1_floats(np) + R2_FLOATS) * 4; }
 }  // namespace fused
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4c __attribute__((ext_vector_type(4)));
 
 struct CoreArgs {
     const float* mel;        // (B, t_in, 80)
@@ -60,6 +68,7 @@ struct CoreArgs {
     const float* zemo;       // (B) emotion-stream logit
     int t_in;
     const float *wce_p, *bce, *ln_g, *ln_b, *qk_p, *wv_p, *wf_p, *bf, *w2, *b2, *wsum;
+    const void* qkv_s;       // split-bf16 image of qk_p / wv_p (NP > 0 variants only)
     float* out;    // (B, 52)
     float* raw;    // (B, 52) or null
     float* attn;   // (B, 28, 80) or null (ATTN variant only)
@@ -90,12 +99,15 @@ struct CoreArgs {
 // or -1 for the 24 expression rows
 __device__ __forceinline__ int mouth_slot_of(int i) { return (i >= 14 && i <= 40) ? i - 14 : (i == 51 ? 27 : -1); }
 
-template <bool ATTN, bool FUSE_DB>
+// NP > 0 (experimental, opt-in: KM_CORE_SPLIT = 3 or 6 terms): phases 2+3 on the bf16 matrix pipe with every
+// fp32 operand split into NP bf16 pieces and the products of weight >= 2^-16 (NP 2: three) or >= 2^-24 (NP 3: six)
+// accumulated in fp32.  Everything else is unchanged.
+template <bool ATTN, bool FUSE_DB, int NP = 0>
 __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
     using namespace fused;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* R1 = smem;
-    float* R2 = smem + R1_FLOATS;
+    float* R2 = smem + r1_floats(NP);
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -260,9 +272,24 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
         for (int mt = 0; mt < 5; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float* yr = R1 + (16 * mt + 4 * g + r) * YS + n0;
-                yr[0] = (acc[mt][0][r] - mean[mt][r]) * rstd[mt][r] * g0 + be0;
-                yr[16] = (acc[mt][1][r] - mean[mt][r]) * rstd[mt][r] * g1 + be1;
+                const float y0 = (acc[mt][0][r] - mean[mt][r]) * rstd[mt][r] * g0 + be0;
+                const float y1 = (acc[mt][1][r] - mean[mt][r]) * rstd[mt][r] * g1 + be1;
+                if constexpr (NP == 0) {
+                    float* yr = R1 + (16 * mt + 4 * g + r) * YS + n0;
+                    yr[0] = y0;
+                    yr[16] = y1;
+                } else {       // NP bf16 pieces per value, one plane per piece
+                    unsigned short* yp = reinterpret_cast<unsigned short*>(R1) + (16 * mt + 4 * g + r) * YSB + n0;
+                    float r0 = y0, r1 = y1;
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc) {
+                        const __bf16 p0 = (__bf16)r0, p1 = (__bf16)r1;
+                        yp[pc * (NK * YSB)] = __builtin_bit_cast(unsigned short, p0);
+                        yp[pc * (NK * YSB) + 16] = __builtin_bit_cast(unsigned short, p1);
+                        r0 -= (float)p0;
+                        r1 -= (float)p1;
+                    }
+                }
             }
     }
     __syncthreads();
@@ -274,7 +301,49 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
         S[mt][0] = f32x4{0, 0, 0, 0}; S[mt][1] = f32x4{0, 0, 0, 0};
         V[mt][0] = f32x4{0, 0, 0, 0}; V[mt][1] = f32x4{0, 0, 0, 0};
     }
-    {
+    if constexpr (NP > 0) {
+        // [head = wave][k block of 32][tile: Qk 0, Qk 1, Wv 0, Wv 1][piece][lane] x 16 bytes, one k block prefetched
+        const u32x4c* wp = reinterpret_cast<const u32x4c*>(a.qkv_s) + (size_t)wave * 8 * 4 * NP * 64 + lane;
+        const unsigned short* Yp = reinterpret_cast<const unsigned short*>(R1) + j * YSB + 8 * g;
+        u32x4c bw[4][NP];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) bw[t][pc] = wp[(t * NP + pc) * 64];
+        for (int kb = 0; kb < 8; ++kb) {
+            const int kn = kb + 1 < 8 ? kb + 1 : kb;
+            u32x4c bn[4][NP];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) bn[t][pc] = wp[((kn * 4 + t) * NP + pc) * 64];
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) {
+                bf16x8 ap[NP];
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc)
+                    ap[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4c*>(Yp + pc * (NK * YSB) + 16 * mt * YSB + 32 * kb));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    f32x4 c4 = t < 2 ? S[mt][t] : V[mt][t - 2];
+                    // smallest terms first: (1,1) (0,2) (2,0) | (0,1) (1,0) | (0,0)
+                    if constexpr (NP == 3) {
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[1], __builtin_bit_cast(bf16x8, bw[t][1]), c4, 0, 0, 0);
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0], __builtin_bit_cast(bf16x8, bw[t][2]), c4, 0, 0, 0);
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[2], __builtin_bit_cast(bf16x8, bw[t][0]), c4, 0, 0, 0);
+                    }
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0], __builtin_bit_cast(bf16x8, bw[t][1]), c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[1], __builtin_bit_cast(bf16x8, bw[t][0]), c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0], __builtin_bit_cast(bf16x8, bw[t][0]), c4, 0, 0, 0);
+                    if (t < 2) S[mt][t] = c4; else V[mt][t - 2] = c4;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) bw[t][pc] = bn[t][pc];
+        }
+    } else {
         const f32x4* qp = reinterpret_cast<const f32x4*>(a.qk_p) + (size_t)wave * KB * 2 * 64 + lane;
         const f32x4* vp = reinterpret_cast<const f32x4*>(a.wv_p) + (size_t)wave * KB * 2 * 64 + lane;
         f32x4 q0 = qp[0], q1 = qp[64], v0 = vp[0], v1 = vp[64];
@@ -724,6 +793,10 @@ static int core_attrs() {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, fused::LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&core_fused_kernel<false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, fused::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&core_fused_kernel<false, true, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, fused::lds_bytes(2)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&core_fused_kernel<false, true, 3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, fused::lds_bytes(3)));
         attr_set = true;
     }
     return KM_OK;
@@ -789,7 +862,18 @@ int launch_core_fused_db(Context* c, MelPlan* p, int64_t B, int64_t n_frames, co
     a.melpow = c->ws_melpow; a.melmax = c->ws_melmax; a.n_frames = (int)n_frames; a.lp = plan_log_params(p);
     a.n_use = (int)(n_use > 0 ? n_use : n_frames); a.ready = ready; a.started = started;
     if (seq) { a.seq_pow = seq->pow; a.seq_edge = seq->edge; a.seq_nfc = seq->nfc; a.seq_stride = seq->stride; a.seq_n = seq->n_per_clip; }
-    hipLaunchKernelGGL((core_fused_kernel<false, true>), dim3((unsigned)B), dim3(fused::NT), fused::LDS_BYTES, (hipStream_t)stream, a);
+    // experimental, off by default: KM_CORE_SPLIT = 3 / 6 runs phases 2+3 as split-bf16 products (read per call: tests A/B it)
+    const char* split = std::getenv("KM_CORE_SPLIT");
+    const int terms = split ? atoi(split) : 0;
+    if (terms == 3) {
+        a.qkv_s = dv(c, "qkv_s2");
+        hipLaunchKernelGGL((core_fused_kernel<false, true, 2>), dim3((unsigned)B), dim3(fused::NT), fused::lds_bytes(2), (hipStream_t)stream, a);
+    } else if (terms == 6) {
+        a.qkv_s = dv(c, "qkv_s3");
+        hipLaunchKernelGGL((core_fused_kernel<false, true, 3>), dim3((unsigned)B), dim3(fused::NT), fused::lds_bytes(3), (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL((core_fused_kernel<false, true>), dim3((unsigned)B), dim3(fused::NT), fused::LDS_BYTES, (hipStream_t)stream, a);
+    }
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }

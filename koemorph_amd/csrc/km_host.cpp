@@ -62,6 +62,19 @@ static dvec mm(const dvec& A, const dvec& B, int M, int K, int N) {
     return C;
 }
 
+// bf16 by round-to-nearest-even on the fp32 bits (what v_cvt_pk_bf16_f32 does for finite values) and back
+static inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf16_to_float(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
 static dvec transpose(const dvec& A, int R, int Cn) {
     dvec T((size_t)R * Cn);
     for (int i = 0; i < R; ++i)
@@ -324,6 +337,29 @@ int finalize_host(Context* c) {
         put(c, "qk_p", std::move(qk_p));
         put(c, "wv_p", std::move(wv_p));
         put(c, "wf_p", std::move(wf_p));
+        // Experimental split-bf16 form of the same phase-2/3 operands (opt-in through KM_CORE_SPLIT): every
+        // fp32 weight as NP bf16 pieces w = p0 + p1 (+ p2), B fragments of v_mfma_f32_16x16x32_bf16 (lane 16 g + j holds
+        // k = 8 g .. 8 g + 7 of column j), [head][k block of 32][tile: Qk 0, Qk 1, Wv 0, Wv 1][piece][lane][8 bf16]
+        for (int NP = 2; NP <= 3; ++NP) {
+            std::vector<uint16_t> img((size_t)H * 8 * 4 * NP * 64 * 8);
+            for (int h = 0; h < H; ++h)
+                for (int kb = 0; kb < 8; ++kb)
+                    for (int t = 0; t < 4; ++t)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 8; ++e) {
+                                const int g = l >> 4, j = l & 15, k = 32 * kb + 8 * g + e, q = 16 * (t & 1) + j;
+                                float w = t < 2 ? (q < NQ ? (float)Qk[((size_t)h * NQ + q) * d + k] : 0.0f)
+                                                : (float)Wv[(size_t)(h * hd + 16 * (t & 1) + j) * d + k];
+                                for (int pc = 0; pc < NP; ++pc) {
+                                    const uint16_t b16 = bf16_rne(w);
+                                    img[(((((size_t)h * 8 + kb) * 4 + t) * NP + pc) * 64 + l) * 8 + e] = b16;
+                                    w -= bf16_to_float(b16);          // exact: the remainder has <= 16 significant bits
+                                }
+                            }
+            std::vector<float> bits(img.size() / 2);
+            std::memcpy(bits.data(), img.data(), img.size() * sizeof(uint16_t));
+            put(c, NP == 2 ? "qkv_s2" : "qkv_s3", std::move(bits));
+        }
     }
     c->host_finalized = true;
     return KM_OK;
