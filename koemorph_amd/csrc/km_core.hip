@@ -55,7 +55,11 @@ constexpr int LDS_BYTES = (R1_FLOATS + R2_FLOATS) * 4;
 // split-bf16 variant (NP pieces per fp32 value): Y lives in LDS as NP planes [80][YSB] of bf16
 constexpr int YSB = 264;                            // bf16 per plane row: 132 dwords = 4 (mod 64), conflict-free b128 fragments
 constexpr int PLANE_FLOATS = NK * YSB / 2;          // 10560
-constexpr int r1_floats(int np) { return np * PLANE_FLOATS > R1_FLOATS ? np * PLANE_FLOATS : R1_FLOATS; }
+// ... and X as NP planes [80 channels][XSB frames] (transposed while it is staged): 288 = 9 k blocks of 32 >= 259 frames,
+// 296 bf16 = 148 dwords = 20 (mod 64): the 16 rows of a b128 beat still hit 64 different banks
+constexpr int XSB = 296, XKB = 9;
+constexpr int XPLANE_FLOATS = NK * XSB / 2;         // 11840
+constexpr int r1_floats(int np) { return np * XPLANE_FLOATS > R1_FLOATS ? np * XPLANE_FLOATS : R1_FLOATS; }
 constexpr int lds_bytes(int np) { return (r1_floats(np) + R2_FLOATS) * 4; }
 }  // namespace fused
 
@@ -69,6 +73,7 @@ struct CoreArgs {
     int t_in;
     const float *wce_p, *bce, *ln_g, *ln_b, *qk_p, *wv_p, *wf_p, *bf, *w2, *b2, *wsum;
     const void* qkv_s;       // split-bf16 image of qk_p / wv_p (NP > 0 variants only)
+    const void* wce_s;       // ... and of wce_p
     float* out;    // (B, 52)
     float* raw;    // (B, 52) or null
     float* attn;   // (B, 28, 80) or null (ATTN variant only)
@@ -141,6 +146,57 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
         };
         float4* dst = reinterpret_cast<float4*>(R1);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (NP > 0) {
+            // Split variant: X goes to LDS transposed, as NP bf16 planes [80 channels][XSB frames].  A thread takes EIGHT
+            // consecutive frames of one float4 of channels (loads still coalesced along the 20 float4 of a row), converts,
+            // splits, and writes the eight frames of each channel and piece as ONE 16-byte store; frames 259 .. 287 (k
+            // padding) come out of the same loop as zeros.  36 blocks of 8 frames x 20 = 720 units over 512 threads.
+            auto src_row = [&](int t) -> int {          // frame feeding encoder input row t, or -1 (zero row)
+                if (t < T) return t < tv ? (t < F ? t : F - 1) : -1;
+                if (t >= T + 3) return -1;
+                const int r = t - T;
+                int fr = -1;
+                if (U >= 3) fr = U - 3 + r; else if (r < U) fr = r;
+                return fr >= F ? F - 1 : fr;
+            };
+            auto stage_planes = [&](auto mode) {
+                constexpr int MODE = decltype(mode)::value;
+#pragma unroll 1
+                for (int unit = tid; unit < XKB * 4 * 20; unit += NT) {
+                    const int t8 = unit / 20, c4 = unit - t8 * 20;
+                    float4 xv8[8];
+                    unsigned okm = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int fr = src_row(8 * t8 + q);
+                        okm |= (fr >= 0 ? 1u : 0u) << q;
+                        xv8[q] = fr >= 0 ? row4(fr)[c4] : z4;
+                    }
+                    float xe[4][8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float4 v = (okm >> q) & 1 ? log_four_t<MODE>(a.lp, xv8[q], ref_db, floor_db) : z4;
+                        xe[0][q] = v.x; xe[1][q] = v.y; xe[2][q] = v.z; xe[3][q] = v.w;
+                    }
+                    unsigned short* xp = reinterpret_cast<unsigned short*>(R1) + (4 * c4) * XSB + 8 * t8;
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            bf16x8 pk;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const __bf16 pbf = (__bf16)xe[e][q];
+                                pk[q] = pbf;
+                                xe[e][q] -= (float)pbf;
+                            }
+                            *reinterpret_cast<bf16x8*>(xp + pc * (NK * XSB) + e * XSB) = pk;
+                        }
+                }
+            };
+            if (a.lp.log_mode == KM_LOG_LN_EPS) stage_planes(std::integral_constant<int, KM_LOG_LN_EPS>{});
+            else stage_planes(std::integral_constant<int, KM_LOG_DB_MAX>{});
+        } else {
         // all T*20/NT = 10 row loads of a thread (and the short-row load) are in flight before the first conversion
         constexpr int NLD = T * 20 / NT;
         static_assert(NLD * NT == T * 20, "phase 0 assumes T*20 is a multiple of the workgroup size");
@@ -175,6 +231,7 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
         if (a.lp.log_mode == KM_LOG_LN_EPS) convert(std::integral_constant<int, KM_LOG_LN_EPS>{});
         else convert(std::integral_constant<int, KM_LOG_DB_MAX>{});
         if (tid >= 64 && tid < 64 + (KTP - KT) * 20) dst[KT * 20 + tid - 64] = z4;
+        }
     } else {
         const int tv = a.t_in < T ? a.t_in : T;   // rows beyond T are truncated (:200-202)
         const float4* src = reinterpret_cast<const float4*>(a.mel + (int64_t)b * a.t_in * NK);
@@ -195,7 +252,48 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
     f32x4 acc[5][2];
 #pragma unroll
     for (int mt = 0; mt < 5; ++mt) { acc[mt][0] = f32x4{0, 0, 0, 0}; acc[mt][1] = f32x4{0, 0, 0, 0}; }
-    {
+    if constexpr (NP > 0) {
+        // [wave][k block of 32][column tile][piece][lane] x 16 bytes, one k block prefetched; A = b128 fragments of the X planes
+        const u32x4c* wp = reinterpret_cast<const u32x4c*>(a.wce_s) + (size_t)wave * XKB * 2 * NP * 64 + lane;
+        const unsigned short* Xp = reinterpret_cast<const unsigned short*>(R1) + j * XSB + 8 * g;
+        u32x4c bw[2][NP];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pc = 0; pc < NP; ++pc) bw[t][pc] = wp[(t * NP + pc) * 64];
+        for (int kb = 0; kb < XKB; ++kb) {
+            const int kn = kb + 1 < XKB ? kb + 1 : kb;
+            u32x4c bn[2][NP];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) bn[t][pc] = wp[((kn * 2 + t) * NP + pc) * 64];
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) {
+                bf16x8 ap[NP];
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc)
+                    ap[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4c*>(Xp + pc * (NK * XSB) + 16 * mt * XSB + 32 * kb));
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 c4 = acc[mt][t];
+                    if constexpr (NP == 3) {
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[1], __builtin_bit_cast(bf16x8, bw[t][1]), c4, 0, 0, 0);
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0], __builtin_bit_cast(bf16x8, bw[t][2]), c4, 0, 0, 0);
+                        c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[2], __builtin_bit_cast(bf16x8, bw[t][0]), c4, 0, 0, 0);
+                    }
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0], __builtin_bit_cast(bf16x8, bw[t][1]), c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[1], __builtin_bit_cast(bf16x8, bw[t][0]), c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0], __builtin_bit_cast(bf16x8, bw[t][0]), c4, 0, 0, 0);
+                    acc[mt][t] = c4;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) bw[t][pc] = bn[t][pc];
+        }
+    } else {
         const float4* wp = reinterpret_cast<const float4*>(a.wce_p) + (size_t)wave * KP * 64 + lane;
         float4 bw = wp[0];
         for (int kp = 0; kp < KP; ++kp) {
@@ -866,10 +964,10 @@ int launch_core_fused_db(Context* c, MelPlan* p, int64_t B, int64_t n_frames, co
     const char* split = std::getenv("KM_CORE_SPLIT");
     const int terms = split ? atoi(split) : 0;
     if (terms == 3) {
-        a.qkv_s = dv(c, "qkv_s2");
+        a.qkv_s = dv(c, "qkv_s2"); a.wce_s = dv(c, "wce_s2");
         hipLaunchKernelGGL((core_fused_kernel<false, true, 2>), dim3((unsigned)B), dim3(fused::NT), fused::lds_bytes(2), (hipStream_t)stream, a);
     } else if (terms == 6) {
-        a.qkv_s = dv(c, "qkv_s3");
+        a.qkv_s = dv(c, "qkv_s3"); a.wce_s = dv(c, "wce_s3");
         hipLaunchKernelGGL((core_fused_kernel<false, true, 3>), dim3((unsigned)B), dim3(fused::NT), fused::lds_bytes(3), (hipStream_t)stream, a);
     } else {
         hipLaunchKernelGGL((core_fused_kernel<false, true>), dim3((unsigned)B), dim3(fused::NT), fused::LDS_BYTES, (hipStream_t)stream, a);

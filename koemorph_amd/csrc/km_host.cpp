@@ -359,6 +359,24 @@ int finalize_host(Context* c) {
             std::vector<float> bits(img.size() / 2);
             std::memcpy(bits.data(), img.data(), img.size() * sizeof(uint16_t));
             put(c, NP == 2 ? "qkv_s2" : "qkv_s3", std::move(bits));
+            // the channel encoder the same way: [wave][k block of 32 (9: K = 259 padded to 288)][column tile 0 / 1][piece][lane][8 bf16]
+            std::vector<uint16_t> enc((size_t)8 * 9 * 2 * NP * 64 * 8);
+            for (int w = 0; w < 8; ++w)
+                for (int kb = 0; kb < 9; ++kb)
+                    for (int t = 0; t < 2; ++t)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 8; ++e) {
+                                const int g = l >> 4, j = l & 15, k = 32 * kb + 8 * g + e, n = 32 * w + 16 * t + j;
+                                float wv = k < KT ? Wce[(size_t)n * KT + k] : 0.0f;
+                                for (int pc = 0; pc < NP; ++pc) {
+                                    const uint16_t b16 = bf16_rne(wv);
+                                    enc[(((((size_t)w * 9 + kb) * 2 + t) * NP + pc) * 64 + l) * 8 + e] = b16;
+                                    wv -= bf16_to_float(b16);
+                                }
+                            }
+            std::vector<float> ebits(enc.size() / 2);
+            std::memcpy(ebits.data(), enc.data(), enc.size() * sizeof(uint16_t));
+            put(c, NP == 2 ? "wce_s2" : "wce_s3", std::move(ebits));
         }
     }
     c->host_finalized = true;
