@@ -218,8 +218,12 @@ class KoeMorphModel(nn.Module):
             valid = audio_mask.to(device=dev, dtype=torch.uint8).contiguous()
         smooth = apply_smoothing and self.use_temporal_smoothing
         if smooth and (self._smoother_state is None or self._smoother_state.shape[0] != B):
-            # decoder.py:282-283: the (1, 52) state is expanded to the batch (zeros after a reset)
-            first = torch.zeros(1, nb, device=dev) if self._smoother_state is None else self._smoother_state[:1]
+            # decoder.py:282-283: the (1, 52) state is expanded to the batch (zeros after a reset); a state that already
+            # holds another batch size cannot be expanded -- torch raises there, and so does this mirror
+            if self._smoother_state is not None and self._smoother_state.shape[0] != 1:
+                raise RuntimeError(f"temporal smoother holds state for batch {self._smoother_state.shape[0]}, got batch {B}: "
+                                   "call reset_temporal_state() between sequences (the reference's expand() fails the same way)")
+            first = torch.zeros(1, nb, device=dev) if self._smoother_state is None else self._smoother_state
             self._smoother_state = first.expand(B, -1).contiguous()
         out = torch.empty(B, nb, device=dev)
         raw = torch.empty(B, nb, device=dev)

@@ -105,6 +105,12 @@ def test_error_paths():
         m(torch.zeros(1, 4, 80).cuda(), torch.zeros(1, 5, 8).cuda())
     with torch.no_grad():
         assert m(torch.zeros(2, 4, 80).cuda(), torch.zeros(2, 4, 8).cuda())["blendshapes"].shape == (2, 52)
+        with pytest.raises(RuntimeError, match="reset_temporal_state"):       # smoother state of batch 2, now batch 3
+            m(torch.zeros(3, 4, 80).cuda(), torch.zeros(3, 4, 8).cuda())
+        m.reset_temporal_state()
+        assert m(torch.zeros(3, 4, 80).cuda(), torch.zeros(3, 4, 8).cuda())["blendshapes"].shape == (3, 52)
+        m.reset_temporal_state()
+        m(torch.zeros(2, 4, 80).cuda(), torch.zeros(2, 4, 8).cuda())
     lib = _lib.load()
     h = m._h
     with pytest.raises(_lib.KoeMorphError):               # workspace was reserved for 2 x 4 frames
