@@ -357,6 +357,15 @@ int km_stream_reset(km_handle h, void* stream);
 int km_enable_stage_timing(km_handle h, int32_t enable);
 int km_stage_times(km_handle h, float* ms3);
 
+/* ---- run-time switches ---------------------------------------------------------------------------
+ * Replaces what would be module attributes / environment switches on the reference side (the reference has none on
+ * this path: every switch selects between two implementations of the SAME arithmetic, for A/B timing and for the
+ * tests that pin one path against the other).  Names: "core_split" (0 | 3 | 6, experimental split-bf16 core),
+ * "seq_per_window", "generic_staged", "mel_two_frame", "emotion_separate", "no_ln_fusion", "no_db_fusion",
+ * "no_score_fusion", "no_out_fusion", "no_v_fusion", "overlap".  A handle's switches start from the environment
+ * variables KM_<NAME> read ONCE in km_create; no launch path reads the environment.  Unknown name: KM_ERR_INVALID_ARG. */
+int km_set_option(km_handle h, const char* name, int64_t value);
+
 /* ---- introspection used by the tests ------------------------------------------------- */
 /* Copy a named host-side folded/packed buffer (after km_finalize_host) into out; returns its
  * length in floats via *n when out == NULL. */

@@ -116,6 +116,7 @@ SIGNATURES = {
     "km_stream_push": (C.c_int, [_h, _p, _i64, _p]),
     "km_stream_tick": (C.c_int, [_h, _p, _p, _p, _p]),
     "km_stream_reset": (C.c_int, [_h, _p]),
+    "km_set_option": (C.c_int, [_h, C.c_char_p, _i64]),
     "km_enable_stage_timing": (C.c_int, [_h, _i32]),
     "km_stage_times": (C.c_int, [_h, C.POINTER(C.c_float)]),
     "km_debug_buffer": (C.c_int, [_h, C.c_char_p, _p, C.POINTER(_i64)]),
@@ -133,9 +134,14 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     if build_if_missing and _build.is_stale():
         try:
             _build.build_library()
-        except Exception:
-            if not os.path.exists(path):
+        except Exception as exc:
+            # A stale library that cannot be rebuilt (a GPU box without write access, say) is still loaded, but never
+            # silently: the ABI check below catches a changed interface, this warning covers changed kernels.
+            if not os.path.exists(path) or os.environ.get("KM_STRICT_BUILD"):
                 raise
+            import warnings
+            warnings.warn(f"libkoemorph_hip.so is OLDER than its sources and the rebuild failed ({exc}); "
+                          "loading the stale library", RuntimeWarning, stacklevel=2)
     if not os.path.exists(path):
         raise KoeMorphError(KM_ERR_HIP, f"{path} is missing: run `python -m koemorph_amd.build` "
                                         "(there is no CPU fallback)")

@@ -69,6 +69,7 @@ static int free_ws(Context* c) {
     c->ws_zemo = c->ws_zemo_win = c->ws_melpow = c->ws_mel = c->ws_short = c->ws_generic = nullptr;
     c->ws_melmax = nullptr;
     c->ws_windows = c->ws_samples = c->ws_frames = 0;
+    c->ws_mels = 0;
     return KM_OK;
 }
 
@@ -84,7 +85,7 @@ int km_reserve(km_handle h, int64_t max_windows, int64_t max_samples) {
     }
     const int64_t frames = max_samples > 0 ? 1 + max_samples / min_hop : 0;
     const bool need_generic = c->host_finalized && !c->fused_ok;
-    if (max_windows <= c->ws_windows && frames <= c->ws_frames && (c->ws_generic || !need_generic)) return KM_OK;
+    if (max_windows <= c->ws_windows && frames <= c->ws_frames && max_mels <= c->ws_mels && (c->ws_generic || !need_generic)) return KM_OK;
     const int64_t W = max_windows > c->ws_windows ? max_windows : c->ws_windows;
     const int64_t F = frames > c->ws_frames ? frames : c->ws_frames;
     const int64_t S = max_samples > c->ws_samples ? max_samples : c->ws_samples;
@@ -101,7 +102,7 @@ int km_reserve(km_handle h, int64_t max_windows, int64_t max_samples) {
         const int64_t per = c->kind == 1 ? legacy_ws_floats(c, F > 0 ? F : 1) : generic_ws_floats(c);
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_generic), (size_t)W * per * sizeof(float)));
     }
-    c->ws_windows = W; c->ws_frames = F; c->ws_samples = S;
+    c->ws_windows = W; c->ws_frames = F; c->ws_samples = S; c->ws_mels = max_mels;
     c->melmax_dirty = true;
     return KM_OK;
 }
@@ -156,6 +157,11 @@ int km_mel_extract(km_handle h, const km_mel_config* cfg, const float* audio_dev
     if (!p) {   // first use of this configuration: build + upload (allocates; not capturable)
         p = find_or_add_plan(h, *cfg);
         if (int rc = upload_mel_plan(p)) return rc;
+        if (cfg->n_mels > h->ws_mels && h->ws_windows > 0) {
+            // the workspace rows were sized for narrower plans: regrow it now (this first-use path allocates anyway)
+            HIP_TRY(hipDeviceSynchronize());
+            if (int rc = km_reserve(h, h->ws_windows, h->ws_samples)) return rc;
+        }
     }
     return launch_mel(h, p, audio_dev, B, L, out_frames, mel_dev, nullptr, stream);
 }
@@ -444,7 +450,7 @@ int km_forward_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L, 
                     (long long)B, (long long)L);
     if (!c->fused_ok) {     // generic shapes: staged front end, GEMM-chain core, stand-alone EMA
         if (!c->ws_generic) return fail(KM_ERR_WORKSPACE, "generic workspace missing: call km_reserve after km_finalize");
-        const bool power_path = generic_core_takes_power(c) && std::getenv("KM_GENERIC_STAGED") == nullptr;
+        const bool power_path = generic_core_takes_power(c) && !c->opt.generic_staged;
         const bool fuse_emo = power_path && mel_fuses_emotion(c, c->mel_plans[0]);   // emotion logits inside the front-end kernel
         if (!fuse_emo)
             if (int rc = launch_emotion(c, emotion_dev, B, c->ws_zemo, stream)) return rc;
@@ -454,7 +460,7 @@ int km_forward_audio(km_handle h, const float* audio_dev, int64_t B, int64_t L, 
                                           fuse_emo ? emotion_dev : nullptr, fuse_emo ? c->ws_zemo : nullptr)) return rc;
             if (int rc = launch_core_generic_power(c, c->mel_plans[0], B, n_frames, c->ws_zemo, out_dev, nullptr,
                                                    nullptr, stream)) return rc;
-        } else if (c->NK == 80 && std::getenv("KM_GENERIC_STAGED") == nullptr) {
+        } else if (c->NK == 80 && !c->opt.generic_staged) {
             // log-mel written straight into the packed encoder input; long + short-term rows in one contraction
             float* xp = generic_packed_x(c, B);
             if (int rc = launch_mel_packed(c, c->mel_plans[0], audio_dev, B, L, xp, c->T, (c->KT + 15) / 16 * 16, stream)) return rc;
@@ -712,8 +718,8 @@ int km_sequence_forward(km_handle h, const float* audio_dev, int64_t B, int64_t 
     // i*stride + f for f = 1 .. T-1; only frame 0 and frame T see the zero padding at the window boundary.  The STFT
     // of the clip is computed once (N-1)*stride + T + 1 frames instead of N * (T+1)), the two edge frames per window
     // separately, and the core reads its rows from both images.  Results are bit-identical to the per-window path.
-    const bool dedup = std::getenv("KM_SEQ_PER_WINDOW") == nullptr;       // read per call: tests compare both paths
-    if (c->fused_ok && dedup && c->cfg.mel.n_fft == 1024 && std::getenv("KM_MEL_TWO_FRAME") == nullptr && N < (1 << 24)) {
+    const bool dedup = !c->opt.seq_per_window;       // km_set_option: tests compare both paths
+    if (c->fused_ok && dedup && c->cfg.mel.n_fft == 1024 && !c->opt.mel_two_frame && N < (1 << 24)) {
         hipStream_t st = (hipStream_t)stream;
         const int64_t nfc = (N - 1) * stride_frames + n_frames;                 // clip frames any window touches
         if (B * nfc > c->seq_pow_cap) {                                           // grow-only; may allocate (not capturable)

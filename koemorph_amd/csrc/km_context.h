@@ -52,8 +52,35 @@ struct MelPlan {
     bool uploaded = false;
 };
 
+// Run-time switches (km_set_option).  Seeded ONCE per handle, at creation, from the KM_* environment variables of
+// the same name in upper case (tools/ab_*.sh); nothing on a launch path reads the environment.
+struct Options {
+    int core_split = 0;            // 3 / 6: split-bf16 variant of the fused core (experimental, never the default)
+    int seq_per_window = 0;        // 1: sequence mode recomputes every window's STFT (the reference's schedule)
+    int generic_staged = 0;        // 1: generic core from a staged log-mel image instead of the power-mel workspace
+    int mel_two_frame = 0;         // 1: two-frames-per-wave front end (A/B baseline)
+    int emotion_separate = 0;      // 1: emotion logits in their own kernel
+    int no_ln_fusion = 0, no_db_fusion = 0, no_score_fusion = 0, no_out_fusion = 0, no_v_fusion = 0;   // generic chain A/B
+    int overlap = 1;               // 1: km_forward_audio runs the co-resident front-end/core schedule where available
+};
+void options_from_env(Options& o);
+int set_option(struct Context* c, const char* name, long long value);
+
+// hipFuncSetAttribute applies to the CURRENT device: one bit per device and call site, not one per process
+struct PerDeviceOnce {
+    unsigned long long seen[4] = {0, 0, 0, 0};
+    bool first(int device) {
+        if (device < 0 || device >= 256) return true;
+        const unsigned long long bit = 1ull << (device & 63);
+        if (seen[device >> 6] & bit) return false;
+        seen[device >> 6] |= bit;
+        return true;
+    }
+};
+
 struct Context {
     km_config cfg{};
+    Options opt{};
     int kind = 0;                                // 0 dual-stream production model, 1 legacy SimplifiedKoeMorphModel, 2 legacy KoeMorphModel
     int legacy_hidden = 128;
     km_koemorph_config kmm{};                    // kind 2
@@ -80,6 +107,7 @@ struct Context {
     float* ws_short = nullptr;     // (windows, 3, 80)
     float* ws_generic = nullptr;   // generic (non-fused) core intermediates, generic_ws_floats() per window
     int64_t ws_frames = 0;
+    int ws_mels = 0;               // mel bins per frame the power-mel / log-mel / short-term workspaces were sized for
     // streaming state (km_stream_*): device-resident per-stream audio rings (MelAudioBuffer semantics)
     int64_t n_streams = 0, ring_len = 0;
     int ring_hop = 0;

@@ -861,12 +861,10 @@ int launch_emotion(Context* c, const float* emo, int64_t B, float* zemo, void* s
     const size_t p1 = (size_t)EKQ1 * EWPB * c->d, p2 = (size_t)EKQ2 * EWPB * c->DH;
     const size_t lds = ((size_t)EWPB * (c->ED + c->d) + (p1 > p2 ? p1 : p2)) * sizeof(float);
     if (lds > 160 * 1024) return fail(KM_ERR_UNSUPPORTED, "emotion_dim/d_model too large for the emotion kernel");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    if (once.first(c->device))
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&emotion_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     const unsigned grid = (unsigned)((B + EWPB - 1) / EWPB);
     if (c->d == 256 && c->DH == 128 && c->ED <= 256) {
         hipLaunchKernelGGL(emotion_kernel_d256, dim3(grid), dim3(ENT), 0, (hipStream_t)stream, emo, B, c->ED,
@@ -882,9 +880,9 @@ int launch_emotion(Context* c, const float* emo, int64_t B, float* zemo, void* s
     return KM_OK;
 }
 
-static int core_attrs() {
-    static bool attr_set = false;
-    if (!attr_set) {
+static int core_attrs(Context* c) {
+    static PerDeviceOnce once;
+    if (once.first(c->device)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&core_fused_kernel<false, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, fused::LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&core_fused_kernel<true, false>),
@@ -895,7 +893,6 @@ static int core_attrs() {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, fused::lds_bytes(2)));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&core_fused_kernel<false, true, 3>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, fused::lds_bytes(3)));
-        attr_set = true;
     }
     return KM_OK;
 }
@@ -910,7 +907,7 @@ static void core_weights(Context* c, CoreArgs& a) {
 int launch_core_fused(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short,
                       const float* zemo, float* out, float* raw, float* attn, float* state, int first,
                       void* stream) {
-    if (int rc = core_attrs()) return rc;
+    if (int rc = core_attrs(c)) return rc;
     CoreArgs a{};
     core_weights(c, a);
     a.mel = mel; a.mel_short = mel_short; a.zemo = zemo; a.t_in = (int)T_in;
@@ -952,7 +949,7 @@ int launch_seq_window_max(Context* c, const unsigned* fmax, const unsigned* emax
 int launch_core_fused_db(Context* c, MelPlan* p, int64_t B, int64_t n_frames, const float* zemo, float* out,
                          float* state, int first, void* stream, int64_t win0, int zemo_div, int64_t n_use,
                          const unsigned char* ready, unsigned char* started, const SeqCore* seq) {
-    if (int rc = core_attrs()) return rc;
+    if (int rc = core_attrs(c)) return rc;
     CoreArgs a{};
     core_weights(c, a);
     a.zemo = zemo; a.t_in = (int)n_frames;
@@ -960,9 +957,8 @@ int launch_core_fused_db(Context* c, MelPlan* p, int64_t B, int64_t n_frames, co
     a.melpow = c->ws_melpow; a.melmax = c->ws_melmax; a.n_frames = (int)n_frames; a.lp = plan_log_params(p);
     a.n_use = (int)(n_use > 0 ? n_use : n_frames); a.ready = ready; a.started = started;
     if (seq) { a.seq_pow = seq->pow; a.seq_edge = seq->edge; a.seq_nfc = seq->nfc; a.seq_stride = seq->stride; a.seq_n = seq->n_per_clip; }
-    // experimental, off by default: KM_CORE_SPLIT = 3 / 6 runs phases 2+3 as split-bf16 products (read per call: tests A/B it)
-    const char* split = std::getenv("KM_CORE_SPLIT");
-    const int terms = split ? atoi(split) : 0;
+    // experimental, off by default: option core_split = 3 / 6 runs phases 1 and 2+3 as split-bf16 products
+    const int terms = c->opt.core_split;
     if (terms == 3) {
         a.qkv_s = dv(c, "qkv_s2"); a.wce_s = dv(c, "wce_s2");
         hipLaunchKernelGGL((core_fused_kernel<false, true, 2>), dim3((unsigned)B), dim3(fused::NT), fused::lds_bytes(2), (hipStream_t)stream, a);

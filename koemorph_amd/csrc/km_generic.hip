@@ -1142,7 +1142,7 @@ int launch_core_generic_packed(Context* c, const float* xp, int64_t B, const flo
     const int d = c->d, NKk = c->NK, KP = (c->KT + 15) / 16 * 16;
     if (NKk != 80) return fail(KM_ERR_UNSUPPORTED, "packed encoder path needs 80 mel channels");
     float* Y = c->ws_generic;
-    static const bool fuse_ln = std::getenv("KM_GENERIC_NO_LN_FUSION") == nullptr;
+    const bool fuse_ln = !c->opt.no_ln_fusion;
     hipStream_t st = (hipStream_t)stream;
     bool ln_done = fuse_ln;
     if (fuse_ln && d == 512)
@@ -1166,8 +1166,7 @@ int launch_core_generic_packed(Context* c, const float* xp, int64_t B, const flo
 // the generic core fed directly by the front end's power-mel workspace (dB conversion inside the encoder kernel);
 // returns KM_ERR_UNSUPPORTED for shapes without an encoder_ln_kernel instantiation (callers then use the packed image)
 bool generic_core_takes_power(Context* c) {
-    return c->NK == 80 && (c->d == 512 || c->d == 256 || c->d == 64) && std::getenv("KM_GENERIC_NO_LN_FUSION") == nullptr &&
-           std::getenv("KM_GENERIC_NO_DB_FUSION") == nullptr;
+    return c->NK == 80 && (c->d == 512 || c->d == 256 || c->d == 64) && !c->opt.no_ln_fusion && !c->opt.no_db_fusion;
 }
 
 LogParams plan_log_params(MelPlan* p);
@@ -1216,7 +1215,7 @@ int launch_core_generic(Context* c, const float* mel, int64_t B, int64_t T_in, c
                         float* out, float* raw, float* attn, void* stream) {
     const int d = c->d, T = c->T, KT = c->KT, NKk = c->NK;
     if (NKk > 128) return fail(KM_ERR_UNSUPPORTED, "more than 128 mel channels");
-    if (NKk == 80 && std::getenv("KM_GENERIC_STAGED") == nullptr && (reinterpret_cast<uintptr_t>(mel) & 15) == 0 &&
+    if (NKk == 80 && !c->opt.generic_staged && (reinterpret_cast<uintptr_t>(mel) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(mel_short) & 15) == 0) {
         const int KP = (KT + 15) / 16 * 16;
         float* xp = generic_packed_x(c, B);
@@ -1254,7 +1253,7 @@ static int core_generic_after_encoder(Context* c, int64_t B, const float* zemo, 
     if (!ln_done)
         hipLaunchKernelGGL(ln_rows_kernel, dim3((unsigned)((B * NKk + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Y,
                            B * NKk, d, dv(c, "ln_g"), dv(c, "ln_b"), (float*)nullptr, (float*)nullptr);
-    const bool fused_scores = d == 512 && NKk == 80 && c->packed.count("qk_pg") && std::getenv("KM_GENERIC_NO_SCORE_FUSION") == nullptr;
+    const bool fused_scores = d == 512 && NKk == 80 && c->packed.count("qk_pg") && !c->opt.no_score_fusion;
     if (fused_scores) {
         hipLaunchKernelGGL(scores_softmax_kernel<512>, dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream, Y, dv(c, "qk_pg"), S, H * 28);
         HIP_TRY(hipGetLastError());
@@ -1277,14 +1276,13 @@ static int core_generic_after_encoder(Context* c, int64_t B, const float* zemo, 
                            B, H, 28 * NKk);
     }
     if (d == 512 && DH == 256 && NKk == 80 && H == 8 && c->packed.count("wf_pg") && c->packed.count("wv_pg") &&
-        std::getenv("KM_GENERIC_NO_OUT_FUSION") == nullptr && std::getenv("KM_GENERIC_NO_V_FUSION") == nullptr) {
+        !c->opt.no_out_fusion && !c->opt.no_v_fusion) {
         // heads of 64 columns: the value projection happens inside the output kernel, O_h = (P_h Y) Wv_h^T
         constexpr int lds = (2 * 32 * (512 + 8) + 8 * 32) * (int)sizeof(float);
-        static bool attr = false;
-        if (!attr) {
+        static PerDeviceOnce once;
+        if (once.first(c->device))
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_out_v_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr = true;
-        }
+
         hipLaunchKernelGGL(attn_out_v_kernel<512>, dim3((unsigned)B), dim3(512), lds, (hipStream_t)stream, S, Y, dv(c, "wv_pg"),
                            dv(c, "wf_pg"), dv(c, "bf"), dv(c, "w2"), dv(c, "b2"), zemo, dv(c, "wsum"), out, raw);
         HIP_TRY(hipGetLastError());
@@ -1297,14 +1295,13 @@ static int core_generic_after_encoder(Context* c, int64_t B, const float* zemo, 
     g.C = V; g.c_rs = d; g.M = (int)(B * NKk); g.N = d; g.K = d;
     if (int rc = launch_gemm(g, 1, stream)) return rc;
     if (d == 512 && DH == 256 && NKk == 80 && (H == 8 || H == 16) && c->packed.count("wf_pg") &&
-        std::getenv("KM_GENERIC_NO_OUT_FUSION") == nullptr) {
+        !c->opt.no_out_fusion) {
         // P V, the decoder fold and the tail in one kernel per window
         constexpr int lds = (32 * (512 + 8) + 8 * 32) * (int)sizeof(float);
-        static bool attr = false;
-        if (!attr) {
+        static PerDeviceOnce once;
+        if (once.first(c->device))
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_out_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr = true;
-        }
+
         hipLaunchKernelGGL(attn_out_kernel<512>, dim3((unsigned)B), dim3(512), lds, (hipStream_t)stream, S, V, dv(c, "wf_pg"), dv(c, "bf"),
                            dv(c, "w2"), dv(c, "b2"), zemo, dv(c, "wsum"), out, raw, H);
         HIP_TRY(hipGetLastError());

@@ -12,7 +12,9 @@
 //   * the emotion stream attends over ONE key (:234-239): softmax == 1, so its output is
 //     out_proj(Wv e + bv) for every query; everything after the emotion LayerNorm folds into one
 //     (d x d/2) matrix.
+#include <cctype>
 #include <cmath>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -481,6 +483,42 @@ using namespace km;
 
 namespace km { const char* last_error(); }
 
+namespace km {
+namespace {
+struct OptName { const char* name; int Options::*field; };
+const OptName kOptNames[] = {
+    {"core_split", &Options::core_split}, {"seq_per_window", &Options::seq_per_window},
+    {"generic_staged", &Options::generic_staged}, {"mel_two_frame", &Options::mel_two_frame},
+    {"emotion_separate", &Options::emotion_separate}, {"no_ln_fusion", &Options::no_ln_fusion},
+    {"no_db_fusion", &Options::no_db_fusion}, {"no_score_fusion", &Options::no_score_fusion},
+    {"no_out_fusion", &Options::no_out_fusion}, {"no_v_fusion", &Options::no_v_fusion}, {"overlap", &Options::overlap},
+};
+}  // namespace
+
+void options_from_env(Options& o) {
+    for (const OptName& n : kOptNames) {
+        std::string env = "KM_";
+        for (const char* p = n.name; *p; ++p) env += (char)std::toupper((unsigned char)*p);
+        if (const char* v = std::getenv(env.c_str())) o.*(n.field) = *v ? std::atoi(v) : 1;
+    }
+    // historical names of the generic-chain switches
+    if (std::getenv("KM_GENERIC_NO_LN_FUSION")) o.no_ln_fusion = 1;
+    if (std::getenv("KM_GENERIC_NO_DB_FUSION")) o.no_db_fusion = 1;
+    if (std::getenv("KM_GENERIC_NO_SCORE_FUSION")) o.no_score_fusion = 1;
+    if (std::getenv("KM_GENERIC_NO_OUT_FUSION")) o.no_out_fusion = 1;
+    if (std::getenv("KM_GENERIC_NO_V_FUSION")) o.no_v_fusion = 1;
+}
+
+int set_option(Context* c, const char* name, long long value) {
+    for (const OptName& n : kOptNames)
+        if (std::strcmp(n.name, name) == 0) {
+            c->opt.*(n.field) = (int)value;
+            return KM_OK;
+        }
+    return fail(KM_ERR_INVALID_ARG, "km_set_option: unknown option '%s'", name);
+}
+}  // namespace km
+
 extern "C" {
 
 int km_abi_version(void) { return KM_ABI_VERSION; }
@@ -505,6 +543,12 @@ static int check_mel_cfg(const km_mel_config& m) {
     return KM_OK;
 }
 
+
+int km_set_option(km_handle h, const char* name, int64_t value) {
+    if (!h || !name) return km::fail(KM_ERR_INVALID_ARG, "km_set_option: NULL argument");
+    return km::set_option(h, name, (long long)value);
+}
+
 int km_create(const km_config* cfg, km_handle* out) {
     if (!cfg || !out) return fail(KM_ERR_INVALID_ARG, "km_create: NULL argument");
     if (cfg->abi_version != KM_ABI_VERSION) return fail(KM_ERR_INVALID_ARG, "km_config.abi_version %d != %d", cfg->abi_version, KM_ABI_VERSION);
@@ -517,6 +561,7 @@ int km_create(const km_config* cfg, km_handle* out) {
     if (cfg->num_mel_channels != cfg->mel.n_mels) return fail(KM_ERR_INVALID_ARG, "num_mel_channels != mel.n_mels");
     if (int rc = check_mel_cfg(cfg->mel)) return rc;
     km_context* c = new km_context();
+    options_from_env(c->opt);
     c->cfg = *cfg;
     c->d = cfg->d_model; c->H = cfg->num_heads; c->hd = c->d / c->H; c->T = cfg->mel_sequence_length;
     c->KT = c->T + cfg->mel_temporal_frames; c->ED = cfg->emotion_dim; c->DH = c->d / 2;
@@ -574,6 +619,7 @@ int km_koemorph_create(const km_koemorph_config* cfg, km_handle* out) {
     if (cfg->use_constraints && cfg->num_blendshapes < 27)
         return fail(KM_ERR_INVALID_ARG, "the default exclusion pairs (25, 26), (20, 21) need >= 27 blendshapes");
     km_context* c = new km_context();
+    options_from_env(c->opt);
     c->kind = 2;
     c->kmm = *cfg;
     c->cfg.abi_version = KM_ABI_VERSION; c->cfg.d_model = cfg->d_model; c->cfg.num_heads = cfg->num_heads;
@@ -646,6 +692,7 @@ int km_legacy_create(const km_legacy_config* cfg, km_handle* out) {
         return fail(KM_ERR_INVALID_ARG, "bad decoder_hidden / num_blendshapes");
     if (int rc = check_mel_cfg(cfg->mel)) return rc;
     km_context* c = new km_context();
+    options_from_env(c->opt);
     c->kind = 1;
     c->cfg.abi_version = KM_ABI_VERSION; c->cfg.d_model = cfg->d_model; c->cfg.num_heads = cfg->num_heads;
     c->cfg.num_mel_channels = cfg->mel.n_mels; c->cfg.num_blendshapes = cfg->num_blendshapes; c->cfg.mel = cfg->mel;

@@ -818,7 +818,7 @@ static LogParams log_params(const km_mel_config& m) {
 // power-mel (B, n_frames, n_mels) + per-window max into the workspace
 // true when launch_mel_power can compute the per-window emotion logits inside the front-end kernel
 bool mel_fuses_emotion(Context* c, MelPlan* p) {
-    static const bool use_rp = std::getenv("KM_MEL_TWO_FRAME") == nullptr && std::getenv("KM_EMOTION_SEPARATE") == nullptr;
+    const bool use_rp = !c->opt.mel_two_frame && !c->opt.emotion_separate;
     auto pow2 = [](int v) { return v >= 64 && v <= 1024 && (v & (v - 1)) == 0; };
     static const bool generic_ok = std::getenv("KM_EMOTION_GENERIC_SEPARATE") == nullptr;
     const bool d256 = c->d == 256 && c->DH == 128;
@@ -835,11 +835,13 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     if (!seq && (B > c->ws_windows || n_frames > c->ws_frames))
         return fail(KM_ERR_WORKSPACE, "workspace holds %lld windows x %lld frames, need %lld x %lld: call km_reserve",
                     (long long)c->ws_windows, (long long)c->ws_frames, (long long)B, (long long)n_frames);
-    if (seq && !(m.n_fft == 1024 && std::getenv("KM_MEL_TWO_FRAME") == nullptr))
+    if (!seq && m.n_mels > c->ws_mels)
+        return fail(KM_ERR_WORKSPACE, "workspace rows hold %d mel bins, this plan has %d: call km_reserve", c->ws_mels, m.n_mels);
+    if (seq && !(m.n_fft == 1024 && !c->opt.mel_two_frame))
         return fail(KM_ERR_UNSUPPORTED, "shared-frame sequence mode needs the 1024-point front end");
     if (!p->uploaded) return fail(KM_ERR_NOT_FINALIZED, "mel plan not uploaded (km_finalize / km_reserve first)");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    if (once.first(c->device)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_kernel<1024, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)mel_lds_bytes(1024)));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_kernel<512, false>),
@@ -852,7 +854,6 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_rp_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
     // ws_melmax is all-zero on entry unless a previous non-fused call left its maxima behind
@@ -888,7 +889,7 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     if (per_window > n_chunks) per_window = n_chunks;
     if (per_window < 1) per_window = 1;
     const dim3 grid((unsigned)per_window, (unsigned)B);
-    static const bool use_rp = std::getenv("KM_MEL_TWO_FRAME") == nullptr;   // A/B switch: the two-frames-per-wave kernel
+    const bool use_rp = !c->opt.mel_two_frame;   // A/B switch: the two-frames-per-wave kernel
     if (m.n_fft == 1024 && use_rp) {
         const size_t ldsrp = melrp_lds_bytes(a.fb4_nnz);     // 78 KB at the production shape: two workgroups per CU
         if (!ring_start) hipLaunchKernelGGL((mel_power_rp_kernel<false>), grid, dim3(melrp::NT), ldsrp, st, a);

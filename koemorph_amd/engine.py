@@ -281,6 +281,10 @@ class Engine:
                                              1 if first else 0, _stream_ptr(audio.device)))
         return out
 
+    def set_option(self, name: str, value: int) -> None:
+        """Run-time switch of this handle (km_set_option): e.g. ("seq_per_window", 1), ("core_split", 3)."""
+        check(self._lib.km_set_option(self._h, name.encode(), int(value)))
+
     def enable_stage_timing(self, enable: bool = True) -> None:
         check(self._lib.km_enable_stage_timing(self._h, 1 if enable else 0))
 

@@ -148,6 +148,14 @@ class DualStreamCrossAttention(nn.Module):
             self._engine_sig = sig
         return self._engine
 
+    def require_eval_mode(self) -> None:
+        """The inference kernels implement eval-mode arithmetic (dropout is the identity, the projections are folded).
+        A module in train() mode with autograd on would silently optimise a different objective, so it raises; the
+        train-mode forward + backward (dropout included) is koemorph_amd.training.Trainer."""
+        if self.training and torch.is_grad_enabled() and self.dropout > 0:
+            raise RuntimeError("the HIP forward implements eval-mode arithmetic (dropout is the identity); call "
+                               ".eval() or use torch.no_grad() -- training goes through koemorph_amd.training")
+
     # ---- reference API --------------------------------------------------------------------------
     def forward(
         self,
@@ -159,9 +167,7 @@ class DualStreamCrossAttention(nn.Module):
         """mel_features (B, T, 80), mel_temporal_features (B, 3, 80), emotion_features (B, emotion_dim)
         -> {'blendshapes': (B, 52)[, 'mel_attention_weights' (B, 28, 80), 'emotion_attention_weights'
         (B, 24, 1), 'mel_blendshapes', 'emotion_blendshapes']}   (reference :162-280)."""
-        if self.training and torch.is_grad_enabled() and self.dropout > 0:
-            raise RuntimeError("the HIP forward implements eval-mode arithmetic (dropout is the identity); call "
-                               ".eval() or use torch.no_grad() -- training goes through koemorph_amd.training")
+        self.require_eval_mode()
         eng = self.engine()
         out = eng.core_forward(mel_features, mel_temporal_features, emotion_features, return_attention)
         result = {'blendshapes': out['blendshapes']}

@@ -53,6 +53,7 @@ class SequentialDualStreamModel(SimplifiedDualStreamModel):
             emotion_features, emotion_metadata = self.extract_emotion_features(audio)
         eng = self.dual_stream_attention.engine()
         self.reset_temporal_state()                                    # :99
+        self.dual_stream_attention.require_eval_mode()
         results: Dict[str, object] = {}
         if not return_attention:
             seq = eng.sequence_forward(audio, emotion_features, self.stride_frames,

@@ -152,6 +152,7 @@ class SimplifiedDualStreamModel(nn.Module):
         """audio (B, T) -> {'blendshapes': (B, 52)[, attention extras]}   (reference :370-415)."""
         if audio.dim() != 2:
             raise ValueError(f"Expected 2D input, got {audio.dim()}D")
+        self.dual_stream_attention.require_eval_mode()      # the fused path below never reaches that module's forward
         if emotion_features is None:
             emotion_features, _ = self.extract_emotion_features(audio)
         eng = self.dual_stream_attention.engine()

@@ -76,10 +76,17 @@ def sharded_apply(fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], audi
     return torch.cat([p[: h - l] for p, (l, h) in zip(parts, sizes)], dim=0)
 
 
-def allreduce_gradients(flat_grad: torch.Tensor, average: bool = True) -> torch.Tensor:
-    """The training step's single collective: sum (then mean) of the flat gradient bucket, in place."""
+def allreduce_gradients(flat_grad: torch.Tensor, average: bool = True, weight: Optional[float] = None) -> torch.Tensor:
+    """The training step's single collective: sum of the flat gradient bucket over the ranks, in place.
+
+    Every rank's loss kernel normalises by its LOCAL window count, so the bucket holds the gradient of a per-rank
+    mean.  ``weight`` = n_local / n_global turns the sum into the gradient of the GLOBAL-batch mean whatever the
+    shard sizes are (3/3/2 windows, the short last batch of a clip, a rank with no window at all: weight 0);
+    without it the ranks are assumed to hold equal shares and the sum is divided by the world size."""
+    if weight is not None:
+        flat_grad.mul_(float(weight))
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
-        if average:
+        if average and weight is None:
             flat_grad.div_(dist.get_world_size())
     return flat_grad

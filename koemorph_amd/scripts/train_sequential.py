@@ -76,11 +76,14 @@ class SequentialTrainer:
                 self.current_file_idx = file_idx
                 self.trainer.reset_temporal_state()
             share, nb = self._my_share(batch)
-            if nb == 0:                                      # fewer windows than ranks: contribute a zero gradient
+            B_global = batch["audio"].shape[0]
+            if nb == 0:                                      # fewer windows than ranks: weight 0 in the global mean
                 self.trainer.flat_grad.zero_()
-                self.trainer.optimizer_step()
+                self.trainer.optimizer_step(weight=0.0)
                 continue
-            loss = self.trainer.step(share["audio"], self._emotion(share), share["target"])
+            # every rank's gradient is weighted by its share of the GLOBAL batch (shares differ by one window when the
+            # batch does not divide, and the last batch of a clip is short): the sum is the full-batch gradient
+            loss = self.trainer.step(share["audio"], self._emotion(share), share["target"], global_batch=B_global)
             total += float(loss.item())
             n += 1
             self.global_step += 1

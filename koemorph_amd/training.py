@@ -157,17 +157,20 @@ class Trainer:
                                             _stream_ptr(self.device)))
         return self.loss
 
-    def optimizer_step(self):
-        parallel.allreduce_gradients(self.flat_grad)         # the ONE collective of the training step
+    def optimizer_step(self, weight: Optional[float] = None):
+        """All-reduce + clip + AdamW.  ``weight`` = this rank's windows / windows of the global batch when the ranks'
+        shares differ (see parallel.allreduce_gradients); None = equal shares."""
+        parallel.allreduce_gradients(self.flat_grad, weight=weight)         # the ONE collective of the training step
         self.step_count += 1
         check(self._lib.km_train_adamw(self._h, _ptr(self.flat_grad), self.lr, self.betas[0], self.betas[1], self.eps,
                                        self.weight_decay, self.grad_clip if self.grad_clip else 0.0, self.step_count,
                                        _stream_ptr(self.device)))
 
-    def step(self, audio, emotion, target) -> torch.Tensor:
-        """forward + loss + backward + all-reduce + clip + AdamW on this rank's windows; returns the loss (device)."""
+    def step(self, audio, emotion, target, global_batch: Optional[int] = None) -> torch.Tensor:
+        """forward + loss + backward + all-reduce + clip + AdamW on this rank's windows; returns the loss (device).
+        ``global_batch`` = windows of the whole batch over all ranks (None: every rank holds the same number)."""
         self.forward_backward(audio, emotion, target)
-        self.optimizer_step()
+        self.optimizer_step(None if global_batch is None else audio.shape[0] / float(global_batch))
         return self.loss
 
     # ---- hipGraph replay of the ~60 launches of forward + backward -----------------------------------

@@ -136,19 +136,19 @@ def test_smooth_kernel_matches_oracle():
 
 
 @pytest.mark.parametrize("terms,tol", [(3, 5e-6), (6, 2e-7)])
-def test_split_bf16_variant_is_opt_in_and_close(terms, tol, monkeypatch):
-    """The experimental split-bf16 form of phases 2+3 (KM_CORE_SPLIT): off by default, and when asked for it
+def test_split_bf16_variant_is_opt_in_and_close(terms, tol):
+    """The experimental split-bf16 form of phases 2+3 (option core_split): off by default, and when asked for it
     stays within the error study's bounds of the fp32 kernel on trained-like weights (contract: 1e-4)."""
     from koemorph_amd import synth
     from koemorph_amd.engine import Engine
     eng = Engine(); eng.load_state_dict(synth.make_core_params(12, style="trained")); eng.finalize(); eng.reserve(8, 136448)
     audio = torch.from_numpy(synth.make_audio(3, 8, 136448, "speech")).cuda()
     emo = torch.from_numpy(synth.normal(4, (8, 256))).cuda()
-    monkeypatch.delenv("KM_CORE_SPLIT", raising=False)
+    eng.set_option("core_split", 0)
     ref = eng.forward_audio(audio, emo).clone()
-    monkeypatch.setenv("KM_CORE_SPLIT", str(terms))
+    eng.set_option("core_split", terms)
     got = eng.forward_audio(audio, emo).clone()
-    monkeypatch.delenv("KM_CORE_SPLIT")
+    eng.set_option("core_split", 0)
     again = eng.forward_audio(audio, emo)
     assert torch.equal(again, ref)
     err = float((got - ref).abs().max())

@@ -96,6 +96,29 @@ def test_torchaudio_front_end(eng):
     assert np.array_equal(got2[:, 256:], np.repeat(got2[:, 255:256], 4, axis=1))
 
 
+def test_mel_extract_wider_than_the_reserved_workspace():
+    """A 128-bin plan registered AFTER the workspace was sized for 80 bins, at B == the reserved window count: the
+    workspace must be regrown (km_mel_extract) -- before the fix the front end wrote B*frames*128 floats into rows sized
+    for 80 (round-1 advisor finding)."""
+    e = Engine()
+    e.load_state_dict(synth.make_core_params(7, style="trained"))
+    e.finalize()
+    B, L = 6, 32000
+    e.reserve(B, L)                                       # rows of 80 bins
+    audio = synth.make_audio(21, B, L)
+    guard = torch.full((1 << 20,), 7.0, device="cuda")    # a neighbour allocation that must stay untouched
+    cfg = MelConfig.sliding_window(n_mels=128)
+    got = e.mel_extract(cfg, dev(audio)).cpu().numpy()
+    want = np.stack([omel.mel_sliding_window(a, n_mels=128, context_window=(1 + L // 532) * 0.0333 + 1e-6) for a in audio])
+    assert got.shape == want.shape == (B, 1 + L // 532, 128)
+    d = np.abs(got - want)
+    assert d.max() < 0.04 and d.mean() < 2e-3, (d.max(), d.mean())
+    assert bool(torch.all(guard == 7.0))
+    # and the 80-bin production path still works on the regrown workspace
+    l80, _ = e.mel_batch(dev(audio))
+    assert l80.shape == (B, 1 + L // 533, 80) and bool(torch.isfinite(l80).all())
+
+
 def test_end_to_end_from_audio(eng):
     """audio -> 52 coefficients, three consecutive calls with the EMA state (contract: 1e-4 abs)."""
     params = synth.make_core_params(7, style="trained")

@@ -56,6 +56,12 @@ def test_simplified_model_forward_and_smoothing():
         want = orc.forward(audio, emo)["blendshapes"]
         got = m(dev(audio), emotion_features=dev(emo))["blendshapes"].cpu().numpy()
         assert np.abs(got - want).max() < 5e-6
+    # a freshly constructed module is in train() mode: the fused path must refuse it like the attention module does
+    fresh = SimplifiedDualStreamModel().cuda()
+    with pytest.raises(RuntimeError, match="eval"):
+        fresh(dev(audio), emotion_features=dev(emo))
+    with torch.no_grad():
+        assert fresh(dev(audio), emotion_features=dev(emo))["blendshapes"].shape == (3, 52)
     # attention path goes through the staged kernels and the stand-alone smoothing kernel
     m.reset_temporal_state(); orc.reset_temporal_state()
     audio = synth.make_audio(80, 2, 136448); emo = synth.normal(81, (2, 256))
@@ -113,8 +119,7 @@ def test_sequence_tiling_is_invisible():
 @pytest.mark.parametrize("extra_hops,stride,clips", [(20, 1, 3), (33, 3, 2), (-40, 1, 2), (0, 1, 1)])
 def test_shared_frame_sequence_path_is_bit_identical_to_per_window(extra_hops, stride, clips):
     """km_sequence_forward computes the clip's STFT once and the two boundary frames of every window separately;
-    the per-window evaluation (the reference's schedule, KM_SEQ_PER_WINDOW=1) must give the same bits."""
-    import os
+    the per-window evaluation (the reference's schedule, option seq_per_window) must give the same bits."""
     params = synth.make_core_params(54, style="trained")
     audio = dev(synth.make_audio(94, clips, 136448 + 533 * extra_hops + 77))
     emo = dev(synth.normal(95, (clips, 256)))
@@ -122,11 +127,11 @@ def test_shared_frame_sequence_path_is_bit_identical_to_per_window(extra_hops, s
     m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
     eng = m.engine()
     shared = eng.sequence_forward(audio, emo, stride, True, max_tile=16)
-    os.environ["KM_SEQ_PER_WINDOW"] = "1"
+    eng.set_option("seq_per_window", 1)
     try:
         per_window = eng.sequence_forward(audio, emo, stride, True, max_tile=16)
     finally:
-        del os.environ["KM_SEQ_PER_WINDOW"]
+        eng.set_option("seq_per_window", 0)
     assert shared.shape[0] == clips and shared.shape[2] == 52
     assert torch.equal(shared, per_window)
 
@@ -243,11 +248,11 @@ def test_generic_packed_encoder_path_matches_staged_path(d, T, H, fps, L):
     eng.reserve(B, L)
     audio, emo = dev(synth.make_audio(101, B, L)), dev(synth.normal(102, (B, 256)))
     packed = eng.forward_audio(audio, emo).clone()
-    os.environ["KM_GENERIC_STAGED"] = "1"
+    eng.set_option("generic_staged", 1)
     try:
         staged = eng.forward_audio(audio, emo).clone()
     finally:
-        del os.environ["KM_GENERIC_STAGED"]
+        eng.set_option("generic_staged", 0)
     assert packed.shape == (B, 52) and float((packed - staged).abs().max()) < 1e-6
 
 

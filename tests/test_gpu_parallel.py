@@ -32,16 +32,21 @@ def _setup(B):
     return synth, eng, tr, audio, emo, target
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_global=8):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     import torch.distributed as dist
     from koemorph_amd import parallel
     dist.init_process_group("gloo", rank=rank, world_size=world)
     synth, eng, tr, audio, emo, target = _setup(4)
-    lo, hi = parallel.shard_range(8, rank, world)
+    lo, hi = parallel.shard_range(n_global, rank, world)
     losses = []
     for _ in range(3):
-        losses.append(float(tr.step(audio[lo:hi], emo[lo:hi], target[lo:hi]).item()))
+        if hi == lo:                                   # fewer windows than ranks (SequentialTrainer.train_epoch)
+            tr.flat_grad.zero_()
+            tr.optimizer_step(weight=0.0)
+            losses.append(0.0)
+            continue
+        losses.append(float(tr.step(audio[lo:hi], emo[lo:hi], target[lo:hi], global_batch=n_global).item()))
     shapes = {k: v.shape for k, v in synth.make_core_params(3, style="trained").items()}
     q.put((rank, losses, {k: v for k, v in tr.params(shapes).items()}))
     dist.barrier()
@@ -71,6 +76,31 @@ def test_two_rank_training_matches_single_process():
         assert abs(0.5 * (res[0][1][s] + res[1][1][s]) - ref_losses[s]) < 2e-6 * max(1.0, abs(ref_losses[s]))
     worst = max(float(np.abs(res[0][2][k] - ref[k]).max()) for k in ref)
     assert worst < 2e-5, worst          # 3 AdamW steps at lr 1e-3 move weights by ~3e-3; summation order differs between the runs
+
+
+@pytest.mark.parametrize("n_global", [5, 1])
+def test_two_rank_training_with_unequal_shares(n_global):
+    """3 + 2 windows, and 1 + 0 windows: the reduced gradient must be the GLOBAL-batch mean (each rank's local-mean
+    gradient weighted by n_local / n_global), not a mean of per-rank means."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, n_global)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    synth, eng, tr, audio, emo, target = _setup(8)
+    for _ in range(3):
+        tr.step(audio[:n_global], emo[:n_global], target[:n_global])
+    shapes = {k: v.shape for k, v in synth.make_core_params(3, style="trained").items()}
+    ref = tr.params(shapes)
+    for k in ref:
+        assert np.array_equal(res[0][2][k], res[1][2][k]), k
+    worst = max(float(np.abs(res[0][2][k] - ref[k]).max()) for k in ref)
+    assert worst < 2e-5, worst
 
 
 def test_bench_two_rank_rehearsal():

@@ -43,6 +43,14 @@ def _worker(rank, world, port, q):
     grad = torch.full((837738,), float(rank + 1))               # the flat gradient bucket of the d=256 model
     parallel.allreduce_gradients(grad)
     ok_grad = bool(torch.all(grad == 1.5))
+    # unequal shares (3 + 2 of 5 windows): each rank's local-mean gradient weighted by its share -> the global mean
+    grad = torch.full((1024,), float(rank + 1))
+    parallel.allreduce_gradients(grad, weight=(3 if rank == 0 else 2) / 5)
+    ok_grad = ok_grad and bool(torch.allclose(grad, torch.full((1024,), 0.6 * 1 + 0.4 * 2)))
+    # a rank without any window contributes weight 0 and the other rank's gradient passes through unchanged
+    grad = torch.full((16,), 7.0 if rank == 0 else 123.0)
+    parallel.allreduce_gradients(grad, weight=1.0 if rank == 0 else 0.0)
+    ok_grad = ok_grad and bool(torch.all(grad == 7.0))
     q.put((rank, ok_gather, ok_local, ok_grad))
     dist.barrier()
     dist.destroy_process_group()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sequence mode (SequentialDualStreamModel.forward): output frames/s of km_sequence_forward at stride 1,
-shared-frame path vs per-window STFT (KM_SEQ_PER_WINDOW=1)."""
+shared-frame path vs per-window STFT (option seq_per_window)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,8 +14,7 @@ audio = torch.from_numpy(synth.make_audio(1, clips, L, "uniform")).cuda()
 emo = torch.from_numpy(synth.normal(2, (clips, 256))).cuda()
 res = {}
 for mode in ("shared", "per_window"):
-    if mode == "per_window": os.environ["KM_SEQ_PER_WINDOW"] = "1"
-    else: os.environ.pop("KM_SEQ_PER_WINDOW", None)
+    eng.set_option("seq_per_window", 1 if mode == "per_window" else 0)
     out = eng.sequence_forward(audio, emo, stride, True, max_tile=256)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
