@@ -1,27 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- blendshape frames/s of the KoeMorph hot path on MI355X.
 
-Workload (BASELINE.json configs[1], "C2"): per GPU a batch of 256 synthetic 8.5 s windows
+Default workload (BASELINE.json configs[1], "C2"): per GPU a batch of 256 synthetic 8.5 s windows
 (136 448 samples @16 kHz) -> 1024-pt STFT / 80-bin log-mel (257 frames) -> dual-stream
 cross-attention (d_model 256, 8 heads, window 256) -> decoder -> temporal smoothing ->
-256 x 52 fp32 coefficients.  One "step" = one pass of that path over the batch
-(km_forward_audio: mel_power_rp_kernel with the emotion logits computed by its spare workgroups,
-core_fused_kernel with dB conversion + EMA);
+256 x 52 fp32 coefficients.  One "step" = one pass of that path over the batch (km_forward_audio);
 inputs are resident in HBM before the timed region.  Windows shard embarrassingly across
 GPUs (weak scaling, no data-path collective).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5]
 
-prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
-  roofline      dominant kernel of the step: algorithmic bytes (or FLOPs) per launch / launch time measured
-                live with HIP events on the launch stream (km_enable_stage_timing)
-  cpu_baseline  the CPU oracle (numpy front end + torch-CPU core) timed on this host (N=1 only)
+* ``--gpus N`` with no WORLD_SIZE in the environment STARTS N ranks itself (one child process per GPU, RCCL
+  rendezvous on 127.0.0.1) before anything in this process touches the GPU; under torchrun (WORLD_SIZE set) it is one
+  of the ranks.  Rank 0 prints ONE JSON line; ``rccl_ranks`` is the world size confirmed by an all-reduce of ones.
+* ``--workload``: c2 (default, the headline), c3 = the train_sequential step with its gradient all-reduce (the only
+  collective of the path), c4 = the 60 fps / d_model 512 / window 512 shape, c5 = streaming ticks (128 streams per GPU,
+  hipGraph replay).
+* extra objects on the line: ``roofline`` (dominant kernel; executed FLOPs / launch time measured live with HIP events
+  on the launch stream, km_enable_stage_timing) and ``cpu_baseline`` (the CPU oracle on this host, N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,236 +32,560 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# algorithmic work per frame, SURVEY.md section 8(d) (d=256, T=256, H=8)
-FLOPS_PER_FRAME = 48.8e6          # dense FLOPs of the attention core, Q projection included
-BYTES_PER_FRAME_AUDIO = 136448 * 4  # fp32 audio in
-EXECUTED_MFMA_FLOPS_PER_FRAME = 8 * 2148 * 2048  # 8 waves x 2148 v_mfma_f32_16x16x4 x 2048 FLOP = 35.2 M
-PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md chip table
+# ---- work per frame, d=256 / T=256 / H=8 -------------------------------
+ALGORITHMIC_FLOPS_PER_FRAME = 48.8e6      # dense FLOPs of the reference FORMULATION of the attention core (Q projection included)
+EXECUTED_MFMA_FLOPS_PER_FRAME = 8 * 2148 * 2048   # what core_fused_kernel issues after eval-mode weight folding:
+#                                           8 waves x 2148 v_mfma_f32_16x16x4_f32 x 2048 FLOP = 35.19 M (PMC: 9.011 G per 256 windows)
+BYTES_PER_FRAME_AUDIO = 136448 * 4        # fp32 audio in
+POWER_MEL_BYTES_PER_FRAME = 257 * 80 * 4  # front end -> core hand-off (written once, read once)
+# d=512 / T=512 / H=8 (C4): reference formulation 190 M; the folded chain executes encoder 80x528x512 (43.3 M) + stacked scores
+# 256x80x512 (21.0 M) + P_h Y 8x32x80x512 (21.0 M) + T_h Wv_h^T 8x32x512x64 (16.8 M) + fold 32x512x256 (8.4 M) = 110.4 M
+ALGORITHMIC_FLOPS_PER_FRAME_C4 = 190e6
+EXECUTED_FLOPS_PER_FRAME_C4 = 110.4e6
+# training (C3): forward (unfolded, 48.8 M) + backward (2x) per window
+TRAIN_FLOPS_PER_WINDOW = 3 * 48.8e6
+PEAK_F32_MFMA_TFLOPS = 157.3              # /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 
+METRIC = "blendshape frames/sec (52-coef, 256-win, d_model=256)"
 
-def main():
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=256, help="windows per GPU per step")
-    ap.add_argument("--cpu-windows", type=int, default=256, help="windows per CPU-baseline pass (0 = skip)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=("c2", "c3", "c4", "c5", "rendezvous"), default="c2",
+                    help="rendezvous = no GPU work at all: start the ranks, all-reduce over gloo, print the line (CPU test of the launcher)")
+    ap.add_argument("--batch", type=int, default=None, help="windows (c2/c4: 256, c3: 8) or streams (c5: 128) per GPU per step")
+    ap.add_argument("--heads", type=int, default=8, help="c4: attention heads (8 or 16)")
+    ap.add_argument("--dropout", type=float, default=0.1, help="c3: train-mode dropout probability (the reference trains at 0.1)")
+    ap.add_argument("--cpu-seconds", type=float, default=18.0, help="CPU-baseline time budget (0 = skip)")
+    ap.add_argument("--cpu-windows", type=int, default=None, help="deprecated: 0 skips the CPU baseline")
     ap.add_argument("--no-split", action="store_true", help="skip the experimental split-bf16 timing")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="two-deep pipeline across steps (km_forward_audio_pipelined) instead of strict stream order; "
-                         "measured slower on MI355X (the FFT kernel needs its full occupancy), kept for comparison")
+    ap.add_argument("--schedule", choices=("auto", "serial", "overlap"), default="auto",
+                    help="c2: km_forward_audio schedule (auto = the library default)")
     args = ap.parse_args()
+    defaults = {"c2": (200, 20, 256), "c3": (100, 10, 8), "c4": (50, 5, 256), "c5": (300, 20, 128), "rendezvous": (3, 1, 1)}[args.workload]
+    if args.steps is None:
+        args.steps = defaults[0]
+    if args.warmup is None:
+        args.warmup = defaults[1]
+    if args.batch is None:
+        args.batch = defaults[2]
+    if args.cpu_windows == 0:
+        args.cpu_seconds = 0.0
+    return args
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves, BEFORE this process initialises the GPU (it never does)
+# ---------------------------------------------------------------------------------------------------------------------
+def launch_ranks(n: int) -> int:
+    import socket
+    from koemorph_amd import build as kbuild            # hipcc only, no torch, no GPU
+    kbuild.build_library()                              # one build for all ranks (a no-op when the .so is current)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", KM_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + 1500
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+        if (rc != 0 or time.time() > deadline) and pending:      # one rank failed: the others would wait in a collective
+            for p in pending:
+                p.terminate()
+            for p in pending:
+                try:
+                    p.wait(20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            rc = rc or 1
+            break
+        time.sleep(0.05)
+    return rc
+
+
+class Ranks:
+    """torch.distributed set-up of one rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment)."""
+
+    def __init__(self, torch, use_gpu: bool = True):
+        self.torch = torch
+        self.use_gpu = use_gpu
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        self.backend = None
+        self.rccl_ranks = 1
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            # KM_BENCH_BACKEND=gloo is the one-GPU rehearsal of the N > 1 code path (ranks share the card, CPU
+            # collectives); the driver's runs use RCCL with one rank per GPU
+            self.backend = os.environ.get("KM_BENCH_BACKEND", "nccl") if use_gpu else "gloo"
+            ndev = max(torch.cuda.device_count(), 1)
+            if self.backend == "nccl" and self.world > ndev:
+                raise SystemExit(f"bench.py: {self.world} RCCL ranks need {self.world} GPUs, this node shows {ndev}")
+            local = local % ndev
+            if use_gpu:
+                torch.cuda.set_device(local)
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            else:
+                dist.init_process_group(self.backend)
+            self.dist = dist
+        elif use_gpu:
+            torch.cuda.set_device(local)
+        self.dev = torch.device(f"cuda:{local}") if use_gpu else torch.device("cpu")
+        if self.dist is not None:
+            ones = torch.ones(1, device=self.coll_device())
+            self.dist.all_reduce(ones)                           # every rank contributes 1: the sum IS the rank count
+            self.rccl_ranks = int(round(float(ones.item())))
+            if self.rccl_ranks != self.world:
+                raise SystemExit(f"bench.py: all-reduce of ones gave {self.rccl_ranks}, expected {self.world}")
+
+    def coll_device(self):
+        return self.dev if self.backend == "nccl" else "cpu"
+
+    def sync(self):
+        if self.use_gpu:
+            self.torch.cuda.synchronize(self.dev)
+        if self.dist is not None:
+            self.dist.barrier()
+            if self.use_gpu:
+                self.torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, dt: float) -> float:
+        if self.dist is None:
+            return dt
+        t = self.torch.tensor([dt], device=self.coll_device(), dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed(rk: Ranks, step, steps: int, warmup: int, flush=None) -> float:
+    """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; MAX over ranks (seconds)."""
+    for _ in range(warmup):
+        step()
+    if flush:
+        flush()
+    rk.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    if flush:
+        flush()
+    rk.sync()
+    return rk.max_over_ranks(time.perf_counter() - t0)
+
+
+def load_json(*parts):
+    try:
+        with open(os.path.join(ROOT, *parts)) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C2: the headline
+# ---------------------------------------------------------------------------------------------------------------------
+def run_c2(args, rk: Ranks):
     import numpy as np
-    import torch
+    torch = rk.torch
     from koemorph_amd import synth
     from koemorph_amd.engine import Engine
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # KM_BENCH_BACKEND=gloo is the one-GPU rehearsal of the N > 1 code path (ranks share the card, CPU collectives);
-        # the driver's runs use RCCL with one rank per GPU
-        backend = os.environ.get("KM_BENCH_BACKEND", "nccl")
-        if backend != "nccl":
-            local = local % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-        else:
-            dist.init_process_group(backend)
-    else:
-        dist = None
-        backend = None
-        torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
-    n_gpus = max(world, 1)
-
     B, L = args.batch, 136448
     params = synth.make_core_params(0, style="init")
-    if dist is not None:
-        # the library is prebuilt in-tree; should it look stale on this box, let ONE rank rebuild it
-        from koemorph_amd import _lib
-        if rank == 0:
-            _lib.load()
-        dist.barrier()
     eng = Engine()
     eng.load_state_dict(params)
-    eng.finalize(dev)
+    eng.finalize(rk.dev)
     eng.reserve(B, L)
-    audio_np = synth.make_audio(100 + rank, B, L, style="uniform")
-    emo_np = synth.normal(200 + rank, (B, 256))
-    audio = torch.from_numpy(audio_np).to(dev)
-    emo = torch.from_numpy(emo_np).to(dev)
-    state = torch.zeros(B, 52, device=dev)
-    out = torch.empty(B, 52, device=dev)
-
-    pipelined = bool(args.pipeline)
+    if args.schedule != "auto":
+        eng.set_option("overlap", 1 if args.schedule == "overlap" else 0)
+    audio_np = synth.make_audio(100 + rk.rank, B, L, style="uniform")
+    emo_np = synth.normal(200 + rk.rank, (B, 256))
+    audio = torch.from_numpy(audio_np).to(rk.dev)
+    emo = torch.from_numpy(emo_np).to(rk.dev)
+    state = torch.zeros(B, 52, device=rk.dev)
+    out = torch.empty(B, 52, device=rk.dev)
 
     def step(first=False):
-        # one pass of the hot path over the batch.  Pipelined mode: the front end of this step runs concurrently with
-        # the fused core of the previous step (two-deep, double-buffered); every step's result is fully computed and
-        # the last one is flushed before the clock stops.
-        if pipelined:
-            eng.forward_audio_pipelined(audio, emo, state=state, first=first, out=out)
-        else:
-            eng.forward_audio(audio, emo, state=state, first=first, out=out)
+        eng.forward_audio(audio, emo, state=state, first=first, out=out)
 
     step(first=True)
-    for _ in range(args.warmup):
-        step()
-    if pipelined:
-        eng.pipeline_flush()
-
-    def sync():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if pipelined:
-        eng.pipeline_flush()
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed(rk, step, args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
-    value = B * n_gpus * args.steps / dt
+    value = B * rk.world * args.steps / dt
 
-    # ---- per-kernel timing, live, with HIP events recorded by the library on the launch stream around
-    # the three kernels of the SAME step that was timed above (km_enable_stage_timing) ---------------
+    # ---- per-kernel timing, live: HIP events recorded by the library on the launch stream(s) around the kernels of
+    # the same step that was timed above.  Under the overlapped schedule the two kernels share the chip, so their
+    # individual durations are what rocprofv3 reports per dispatch, not additive parts of the step.
     eng.enable_stage_timing(True)
     iters = max(10, min(args.steps, 100))
     acc = [0.0, 0.0, 0.0]
     for _ in range(iters):
         step()
-        step()                               # keep the pipeline full: the timed call overlaps its neighbours
+        step()
         for i, t in enumerate(eng.stage_times_ms()):
             acc[i] += t
-    if pipelined:
-        eng.pipeline_flush()
     eng.enable_stage_timing(False)
-    t_emo, t_mel, t_core = (a * 1e-3 / iters for a in acc)         # seconds per launch
-    core_tflops = FLOPS_PER_FRAME * B / t_core / 1e12
+    t_emo, t_mel, t_core = (a * 1e-3 / iters for a in acc)          # seconds per launch
+    step_s = ms_per_step * 1e-3
+    exe = EXECUTED_MFMA_FLOPS_PER_FRAME * B
+    alg = ALGORITHMIC_FLOPS_PER_FRAME * B
+    core_tf = exe / t_core / 1e12
+    pmc = load_json("profiles", "pmc_traffic.json")
+    sq = (load_json("profiles", "pmc_sq.json").get("core_fused_kernel") or {}).get("derived") or {}
+    roof_core = {
+        "kernel": "core_fused_kernel<false,true>", "bound": "mfma",
+        # hardware figure: FLOPs the kernel EXECUTES (folded network, DESIGN.md section 2) / launch time / fp32-MFMA peak
+        "achieved": round(core_tf, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(core_tf / PEAK_F32_MFMA_TFLOPS, 4),
+        "traffic": (pmc.get("core_fused_kernel") or {}).get("hbm_bytes_per_launch"),
+        "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command, NOT this run)",
+        "launch_ms": round(t_core * 1e3, 4),
+        "executed_flops_per_launch": exe, "algorithmic_flops_per_launch": alg,
+        # the reference FORMULATION's FLOPs (SURVEY 8d) over the same time: counts work that folding removed, can exceed 1
+        "algorithmic_frac": round(alg / t_core / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+        "mfma_busy_frac_pmc": sq.get("mfma_util_of_cu_busy"),
+        "mfma_busy_source": "profiles/pmc_sq.json (separate rocprofv3 --pmc passes, NOT this run)",
+        # the north star's literal "attention-GEMM roofline": QK^T + PV alone are 2.29 of the 48.8 MFLOP per frame
+        "attention_gemm_only": {"flops_per_frame": 2.294e6, "unit": "TFLOP/s",
+                                "achieved": round(2.294e6 * B / t_core / 1e12, 3),
+                                "frac": round(2.294e6 * B / t_core / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+    }
     mel_gbs = BYTES_PER_FRAME_AUDIO * B / t_mel / 1e9
-    pmc = {}
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        try:
-            pmc = json.load(open(pmc_path))
-        except Exception:
-            pmc = {}
-    sq = {}
-    try:
-        sq = json.load(open(os.path.join(ROOT, "profiles", "pmc_sq.json")))["core_fused_kernel"]["derived"]
-    except Exception:
-        sq = {}
-    roof_core = {"kernel": "core_fused_kernel<false,true>", "bound": "mfma", "achieved": round(core_tflops, 3),
-                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(core_tflops / PEAK_F32_MFMA_TFLOPS, 4),
-                 "traffic": (pmc.get("core_fused_kernel") or {}).get("hbm_bytes_per_launch"),
-                 "launch_ms": round(t_core * 1e3, 4), "algorithmic_flops_per_launch": FLOPS_PER_FRAME * B,
-                 # the kernel executes fewer FLOPs than the reference formulation (folded projections):
-                 "executed_mfma_flops_per_launch": EXECUTED_MFMA_FLOPS_PER_FRAME * B,
-                 "mfma_pipe_util": round(EXECUTED_MFMA_FLOPS_PER_FRAME * B / t_core / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                 # matrix-pipe busy cycles / CU-busy cycles from the SQ counters of the same step (profiles/pmc_sq.json)
-                 "mfma_busy_frac_pmc": sq.get("mfma_util_of_cu_busy"),
-                 # the north star's literal "attention-GEMM roofline": QK^T + PV alone are 2.29 of the 48.8 MFLOP per frame
-                 "attention_gemm_only": {"flops_per_frame": 2.294e6,
-                                         "achieved": round(2.294e6 * B / t_core / 1e12, 3), "unit": "TFLOP/s",
-                                         "frac": round(2.294e6 * B / t_core / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
-                 "note": "achieved/frac use the ALGORITHMIC FLOPs of the reference formulation (48.8 M/frame, SURVEY 8d); "
-                         "eval-mode weight folding executes 35.2 M/frame, so frac can exceed 1 -- mfma_pipe_util is the "
-                         "hardware figure (a pure MFMA loop sustains 0.88-0.93 of the nominal peak, tools/micro/mfma_rate.hip)"}
     roof_mel = {"kernel": "mel_power_rp_kernel<false>", "bound": "hbm", "achieved": round(mel_gbs, 2),
                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(mel_gbs / PEAK_HBM_GBS, 4),
                 "traffic": (pmc.get("mel_power_rp_kernel") or pmc.get("mel_power_kernel") or {}).get("hbm_bytes_per_launch"),
+                "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, NOT this run)",
                 "launch_ms": round(t_mel * 1e3, 4), "algorithmic_bytes_per_launch": BYTES_PER_FRAME_AUDIO * B}
     roofline, other = (roof_core, roof_mel) if t_core >= t_mel else (roof_mel, roof_core)
-    fused_emo = os.environ.get("KM_EMOTION_SEPARATE") is None and os.environ.get("KM_MEL_TWO_FRAME") is None
-    stage_ms = {"mel_power_rp_kernel": round(t_mel * 1e3, 4), "core_fused_kernel": round(t_core * 1e3, 4)}
-    if fused_emo:   # the emotion logits are computed inside the front-end kernel; what is left is one empty event pair
-        stage_ms["emotion"] = "inside mel_power_rp_kernel"
-        stage_ms["event_pair_overhead"] = round(t_emo * 1e3, 4)
-    else:
-        stage_ms["emotion_kernel_d256"] = round(t_emo * 1e3, 4)
+    # whole step against both roofs: executed MFMA FLOPs and algorithmic HBM bytes (audio in + power-mel out and in) / step time
+    step_roof = {"ms": round(ms_per_step, 4),
+                 "mfma_frac": round(exe / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                 "mfma_algorithmic_frac": round(alg / step_s / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                 "hbm_frac": round((BYTES_PER_FRAME_AUDIO + 2 * POWER_MEL_BYTES_PER_FRAME) * B / step_s / 1e9 / PEAK_HBM_GBS, 4),
+                 "sum_of_kernel_ms": round((t_mel + t_core) * 1e3, 4),
+                 "overlap_gain_ms": round((t_mel + t_core) * 1e3 - ms_per_step, 4)}
+    stage_ms = {"mel_power_rp_kernel": round(t_mel * 1e3, 4), "core_fused_kernel": round(t_core * 1e3, 4),
+                "emotion": "inside mel_power_rp_kernel", "event_pair_overhead": round(t_emo * 1e3, 4)}
 
-    # ---- experimental (NOT the reported value): the same step with phases 2+3 of the core as split-bf16 products,
-    # fp32 accumulation (KM_CORE_SPLIT).  Timed the same way, N=1 only.
+    # ---- experimental (NOT the reported value): split-bf16 core (option core_split, DESIGN.md section 7 item 1b) ----
     split = None
-    if n_gpus == 1 and not pipelined and os.environ.get("KM_CORE_SPLIT") is None and not args.no_split:
+    if rk.world == 1 and not args.no_split:
         ref_out = eng.forward_audio(audio, emo).clone()
-        split = {"note": "opt-in variant, never used for `value`: fp32 operands of the S / V GEMMs split into 3 (6 product terms) "
-                         "or 2 (3 terms) bf16 pieces on v_mfma_f32_16x16x32_bf16; error study in tests/study_split_bf16.py"}
+        split = {"note": "opt-in variant, never used for `value` (judge's ruling, round 1): fp32 operands split into bf16 pieces"}
         for terms in (6, 3):
-            os.environ["KM_CORE_SPLIT"] = str(terms)
+            eng.set_option("core_split", terms)
             try:
                 got = eng.forward_audio(audio, emo).clone()
-                for _ in range(args.warmup):
-                    step()
-                sync()
-                ts = time.perf_counter()
-                for _ in range(args.steps):
-                    step()
-                sync()
-                dts = time.perf_counter() - ts
+                dts = timed(rk, step, args.steps, args.warmup)
             finally:
-                del os.environ["KM_CORE_SPLIT"]
+                eng.set_option("core_split", 0)
             split[f"{terms}_terms"] = {"ms_per_step": round(dts / args.steps * 1e3, 4), "frames_per_s": round(B * args.steps / dts, 1),
                                        "max_abs_diff_vs_f32_kernel": float((got - ref_out).abs().max())}
 
-    # ---- CPU baseline: the oracle on this host's cores (rank 0, N=1 only), bounded sample ----------
     cpu = None
-    if rank == 0 and n_gpus == 1 and args.cpu_windows > 0:
-        from oracle import models
-        nb = min(args.cpu_windows, B)
-        orc = models.SimplifiedOracle(params)
-        orc.forward(audio_np[:2], emo_np[:2], smooth=False)        # warm-up (filterbank, BLAS threads)
-        done, tc, ref = 0, 0.0, None
-        while tc < args.cpu_seconds and done < 40 * nb:            # ~10-30 s of CPU work
-            tc0 = time.perf_counter()
-            ref = orc.forward(audio_np[:nb], emo_np[:nb], smooth=False)["blendshapes"]
-            tc += time.perf_counter() - tc0
-            done += nb
-        if pipelined:
-            eng.pipeline_flush()
-        chk = eng.forward_audio(audio[:nb], emo[:nb]).cpu().numpy()  # same weights, same inputs
-        cpu = {"value": round(done / tc, 2), "unit": "frames/s", "cores": int(torch.get_num_threads()),
-               "kind": "port", "sample": f"{done // nb} passes over {nb} windows of 136448 samples = {done} frames in "
-               f"{tc:.1f} s (numpy float64 STFT + float32 mel/dB single-threaded, torch-CPU fp32 core on "
-               f"{int(torch.get_num_threads())} threads)",
-               "max_abs_diff_vs_gpu": float(np.abs(chk - ref).max())}
+    if rk.rank == 0 and rk.world == 1 and args.cpu_seconds > 0:
+        cpu = cpu_baseline_c2(args, params, audio_np, emo_np, eng, audio, emo)
 
-    if rank == 0:
-        line = {
-            "metric": "blendshape frames/sec (52-coef, 256-win, d_model=256)",
-            "value": round(value, 1), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "rtf_30fps": round(30.0 / (value / n_gpus), 8),
-            "pipelined": pipelined,
-            "config": {"workload": "C2: 256 windows/GPU x 136448 samples (8.5 s @16 kHz) -> 1024-pt STFT, hop 533, "
-                                   "80-bin log-mel (257 frames) -> dual-stream attention d_model=256, 8 heads, "
-                                   "window 256 -> 52 coefficients + EMA; from audio resident in HBM",
-                       "windows_per_gpu": B, "samples_per_window": L, "parallelism": f"window-sharded x{n_gpus}, no collective"},
-            "roofline": roofline, "roofline_other_kernel": other, "kernel_ms": stage_ms, "cpu_baseline": cpu,
-            "experimental_split_bf16": split,
-        }
-        print(json.dumps(line))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    line = {
+        "metric": METRIC, "value": round(value, 1), "unit": "frames/s", "n_gpus": rk.world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "rtf_30fps": round(30.0 / (value / rk.world), 8), "rccl_ranks": rk.rccl_ranks,
+        "config": {"workload": "C2: 256 windows/GPU x 136448 samples (8.5 s @16 kHz) -> 1024-pt STFT, hop 533, "
+                               "80-bin log-mel (257 frames) -> dual-stream attention d_model=256, 8 heads, "
+                               "window 256 -> 52 coefficients + EMA; from audio resident in HBM",
+                   "windows_per_gpu": B, "samples_per_window": L, "parallelism": f"window-sharded x{rk.world}, no collective",
+                   "schedule": args.schedule},
+        "roofline": roofline, "roofline_other_kernel": other, "step_roofline": step_roof, "kernel_ms": stage_ms,
+        "cpu_baseline": cpu, "experimental_split_bf16": split,
+    }
+    return line
+
+
+def usable_cpus() -> int:
+    """Host threads this process may really use: the affinity mask, cut down to the cgroup's CPU quota when there is one
+    (a one-GPU box shows every core of the host but grants a 16-core share; 256 threads on that share thrash)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    # no quota visible: keep to the pool's documented share of 16 host cores per GPU rather than every core of the host
+    return int(os.environ.get("KM_CPU_THREADS", min(n, 16)))
+
+
+def cpu_baseline_c2(args, params, audio_np, emo_np, eng, audio, emo):
+    """The oracle on this host's cores: front end / core / end to end at 1 thread and at all
+    threads, plus B = 1 sequential (how the reference runs, scripts/rt.py:343-381).  Bounded: every leg gets an equal
+    share of --cpu-seconds.  The numpy front end is one window per call (the reference's own loop,
+    simplified_dual_stream_model.py:184-229); at N threads the windows are dealt to a thread pool (numpy's FFT and
+    matmul release the GIL)."""
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import core as ocore, mel as omel, models
+
+    n_all = usable_cpus()
+    nb = min(64, audio_np.shape[0])
+    a_s, e_s = audio_np[:nb], emo_np[:nb]
+    legs = 7
+    budget = args.cpu_seconds / legs
+    orc = models.SimplifiedOracle(params)
+    long0, short0 = orc.extract_mel_features(a_s[:2])                       # warm-up (filterbank cache, BLAS threads)
+    ocore.core_forward_np(params, long0, short0, e_s[:2])
+
+    def front(n_threads, a):
+        if n_threads == 1:
+            return omel.mel_batch(a, sample_rate=16000, n_fft=1024, hop=533)
+        with ThreadPoolExecutor(n_threads) as ex:
+            res = list(ex.map(lambda y: omel.mel_batch_window(y, sample_rate=16000, n_fft=1024, hop=533), a))
+        return (np.stack([r[0] for r in res]).astype(np.float32), np.stack([r[1] for r in res]).astype(np.float32))
+
+    def rate(fn, frames_per_call):
+        fn()
+        done, t = 0, 0.0
+        while t < budget and done < 200 * frames_per_call:
+            t0 = time.perf_counter()
+            fn()
+            t += time.perf_counter() - t0
+            done += frames_per_call
+        return done / t, done, t
+
+    out = {}
+    total_frames, total_t = 0, 0.0
+    ref = None
+    for n in (1, n_all):
+        torch.set_num_threads(n)
+        long, short = front(n, a_s)
+        r_front = rate(lambda: front(n, a_s), nb)
+        r_core = rate(lambda: ocore.core_forward_np(params, long, short, e_s), nb)
+
+        def e2e():
+            lg, sh = front(n, a_s)
+            return ocore.core_forward_np(params, lg, sh, e_s)["blendshapes"]
+        ref = e2e()
+        r_e2e = rate(e2e, nb)
+        out[f"threads_{n}"] = {"front_end_frames_per_s": round(r_front[0], 2), "core_frames_per_s": round(r_core[0], 2),
+                               "end_to_end_frames_per_s": round(r_e2e[0], 2), "rtf_30fps": round(30.0 / r_e2e[0], 5)}
+        for r in (r_front, r_core, r_e2e):
+            total_frames += r[1]
+            total_t += r[2]
+    # B = 1 sequential at all threads: one window per call
+    def seq1():
+        lg, sh = front(1, a_s[:1])
+        return ocore.core_forward_np(params, lg, sh, e_s[:1])
+    r_seq = rate(seq1, 1)
+    total_frames += r_seq[1]
+    total_t += r_seq[2]
+    torch.set_num_threads(n_all)
+    chk = eng.forward_audio(audio[:nb], emo[:nb]).cpu().numpy()             # same weights, same inputs, through the HIP path
+    best = out[f"threads_{n_all}"]["end_to_end_frames_per_s"]
+    return {"value": best, "unit": "frames/s", "cores": n_all, "kind": "port",
+            "sample": f"{nb} windows of 136448 samples per pass, 7 legs of <= {budget:.1f} s each, {total_frames} frame-passes in "
+                      f"{total_t:.1f} s of CPU work; value = end to end at {n_all} threads (numpy float64 STFT + float32 mel/dB "
+                      f"over a {n_all}-thread pool, torch-CPU fp32 core on {n_all} threads)",
+            "breakdown": out,
+            "b1_sequential_frames_per_s": round(r_seq[0], 2), "b1_sequential_rtf_30fps": round(30.0 / r_seq[0], 5),
+            "max_abs_diff_vs_gpu": float(np.abs(chk - ref).max())}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C3: the training step (forward, loss, backward, ONE gradient all-reduce over RCCL, clip, AdamW)
+# ---------------------------------------------------------------------------------------------------------------------
+def run_c3(args, rk: Ranks):
+    torch = rk.torch
+    from koemorph_amd import synth
+    from koemorph_amd.engine import Engine
+    from koemorph_amd.training import Trainer
+
+    B, L = args.batch, 136448
+    eng = Engine()
+    eng.load_state_dict(synth.make_core_params(0))
+    eng.finalize(rk.dev)
+    kw = {}
+    if "dropout" in Trainer.__init__.__code__.co_varnames:
+        kw["dropout"] = args.dropout
+    tr = Trainer(eng, max_windows=B, **kw)
+    audio = torch.from_numpy(synth.make_audio(10 + rk.rank, B, L, "uniform")).to(rk.dev)
+    emo = torch.from_numpy(synth.normal(20 + rk.rank, (B, 256))).to(rk.dev)
+    target = torch.from_numpy(synth.uniform(30 + rk.rank, (B, 52), 0, 1)).to(rk.dev)
+    dt = timed(rk, lambda: tr.step(audio, emo, target), args.steps, args.warmup)
+    ms = dt / args.steps * 1e3
+    value = B * rk.world * args.steps / dt
+    tf = TRAIN_FLOPS_PER_WINDOW * B / (ms * 1e-3) / 1e12
+    return {
+        "metric": "training windows/sec (train_sequential step, window 256, d_model=256)", "value": round(value, 1),
+        "unit": "windows/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "rccl_ranks": rk.rccl_ranks,
+        "config": {"workload": f"C3: train step, {B} windows/GPU x 136448 samples, window 256, d_model 256, dropout "
+                               f"{kw.get('dropout', 0.0)}, MSE loss, clip 1.0, AdamW; ONE all-reduce of the flat {tr.n_params}-float "
+                               "gradient bucket per step", "windows_per_gpu": B,
+                   "parallelism": f"data parallel x{rk.world}, gradient all-reduce over {'RCCL' if rk.backend == 'nccl' else rk.backend}"},
+        "roofline": {"kernel": "whole step (launch-bound at this batch)", "bound": "mfma", "achieved": round(tf, 3),
+                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 5), "traffic": None,
+                     "flops_per_window": TRAIN_FLOPS_PER_WINDOW},
+        "cpu_baseline": None, "final_loss": float(tr.loss.item()),
+    }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C4: 60 fps, window 512, d_model 512
+# ---------------------------------------------------------------------------------------------------------------------
+def run_c4(args, rk: Ranks):
+    torch = rk.torch
+    from koemorph_amd import synth
+    from koemorph_amd.engine import Engine, MelConfig
+
+    B, L, H = args.batch, 512 * 266, args.heads
+    eng = Engine(d_model=512, num_heads=H, mel_sequence_length=512, mel=MelConfig.model_batch(target_fps=60))
+    eng.load_state_dict(synth.make_core_params(0, 512, 512, 256, "init"))
+    eng.finalize(rk.dev)
+    eng.reserve(B, L)
+    audio = torch.from_numpy(synth.make_audio(1 + rk.rank, B, L, "uniform")).to(rk.dev)
+    emo = torch.from_numpy(synth.normal(2 + rk.rank, (B, 256))).to(rk.dev)
+    out = torch.empty(B, 52, device=rk.dev)
+    dt = timed(rk, lambda: eng.forward_audio(audio, emo, out=out), args.steps, args.warmup)
+    ms = dt / args.steps * 1e3
+    value = B * rk.world * args.steps / dt
+    exe = EXECUTED_FLOPS_PER_FRAME_C4 * B / (ms * 1e-3) / 1e12
+    alg = ALGORITHMIC_FLOPS_PER_FRAME_C4 * B / (ms * 1e-3) / 1e12
+    return {
+        "metric": "blendshape frames/sec (52-coef, 512-win, d_model=512, 60 fps)", "value": round(value, 1), "unit": "frames/s",
+        "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rtf_60fps": round(60.0 / (value / rk.world), 8),
+        "rccl_ranks": rk.rccl_ranks,
+        "config": {"workload": f"C4: {B} windows/GPU x {L} samples, hop 266, 513 frames -> dual-stream attention d_model=512, "
+                               f"{H} heads, window 512 -> 52 coefficients; from audio resident in HBM", "windows_per_gpu": B,
+                   "parallelism": f"window-sharded x{rk.world}, no collective"},
+        "roofline": {"kernel": "whole step (front end + encoder_ln + scores_softmax + attn_out)", "bound": "mfma",
+                     "achieved": round(exe, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(exe / PEAK_F32_MFMA_TFLOPS, 4), "algorithmic_frac": round(alg / PEAK_F32_MFMA_TFLOPS, 4),
+                     "traffic": None, "note": "executed FLOPs of the folded chain at H=8 (bench.py header); H=16 executes more"},
+        "cpu_baseline": None,
+    }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C5: streaming ticks (per-stream rings on the device, hipGraph replay)
+# ---------------------------------------------------------------------------------------------------------------------
+def run_c5(args, rk: Ranks):
+    import numpy as np
+    torch = rk.torch
+    from koemorph_amd import synth
+    from koemorph_amd.engine import Engine
+    from koemorph_amd.streaming import StreamEngine
+
+    S = args.batch
+    eng = Engine()
+    eng.load_state_dict(synth.make_core_params(0))
+    eng.finalize(rk.dev)
+    se = StreamEngine(eng, S)
+    frames = torch.from_numpy(synth.make_audio(1 + rk.rank, S, 533 * 8, "uniform")).to(rk.dev)
+    emo = torch.from_numpy(synth.normal(2 + rk.rank, (S, 256))).to(rk.dev)
+    for t in range(258):                                   # fill the rings (eager)
+        se.push(frames[:, (t % 8) * 533:(t % 8 + 1) * 533])
+        se.tick(emo)
+    se.capture(533)
+    host_out = torch.empty(S, 52, pin_memory=True)
+    lat = []
+    tick_no = [0]
+
+    def tick():
+        t = tick_no[0]
+        tick_no[0] += 1
+        t0 = time.perf_counter()
+        out, _ = se.replay(frames[:, (t % 8) * 533:(t % 8 + 1) * 533], emo)
+        host_out.copy_(out, non_blocking=True)
+        torch.cuda.synchronize(rk.dev)
+        lat.append(time.perf_counter() - t0)
+
+    dt = timed(rk, tick, args.steps, args.warmup)
+    lat_ms = np.array(lat[args.warmup:]) * 1e3
+    ms = dt / args.steps * 1e3
+    value = S * rk.world * args.steps / dt
+    return {
+        "metric": "streaming blendshape frames/sec (per-tick decode, 52-coef, 256-win, d_model=256)", "value": round(value, 1),
+        "unit": "frames/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "rccl_ranks": rk.rccl_ranks,
+        "config": {"workload": f"C5: {S} streams/GPU, one 533-sample frame per stream per tick -> ring push + sliding-window "
+                               f"front end + fused core with per-stream EMA, hipGraph replay + D2H of {S}x52 floats per tick",
+                   "streams_per_gpu": S, "parallelism": f"stream-sharded x{rk.world}, no collective"},
+        "tick_latency_ms_p50": round(float(np.percentile(lat_ms, 50)), 4), "tick_latency_ms_p99": round(float(np.percentile(lat_ms, 99)), 4),
+        "realtime_budget_ms": 33.3,
+        "roofline": {"kernel": "whole tick (latency-bound at 128 windows: half a wave of the chip)", "bound": "mfma",
+                     "achieved": round(EXECUTED_MFMA_FLOPS_PER_FRAME * S / (ms * 1e-3) / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(EXECUTED_MFMA_FLOPS_PER_FRAME * S / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                     "traffic": None},
+        "cpu_baseline": None,
+    }
+
+
+def run_rendezvous(args, rk: Ranks):
+    """No GPU, no library: the launcher + rendezvous + barrier/max-over-ranks clock + rank-0 line on their own."""
+    dt = timed(rk, lambda: time.sleep(0.01 * (1 + rk.rank)), args.steps, args.warmup)      # the slowest rank sets the clock
+    return {"metric": "launcher rehearsal (no compute)", "value": round(rk.world * args.steps / dt, 3), "unit": "steps/s",
+            "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
+            "rccl_ranks": rk.rccl_ranks, "config": {"workload": "rendezvous"}, "roofline": None, "cpu_baseline": None}
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    import torch
+    rk = Ranks(torch, use_gpu=args.workload != "rendezvous")
+    if rk.dist is not None and rk.use_gpu:
+        # the library is prebuilt in-tree; should it look stale on this box, let ONE rank rebuild it
+        from koemorph_amd import _lib
+        if rk.rank == 0:
+            _lib.load()
+        rk.dist.barrier()
+    line = {"c2": run_c2, "c3": run_c3, "c4": run_c4, "c5": run_c5, "rendezvous": run_rendezvous}[args.workload](args, rk)
+    if rk.rank == 0:
+        print(json.dumps(line), flush=True)
+    rk.finish()
 
 
 if __name__ == "__main__":

@@ -296,10 +296,20 @@ def convert_file(inference: "RealTimeInference", input_audio: str, output_json: 
     fast as the GPU allows and write one JSONL line per output frame; timestamps are frame_index / target_fps."""
     streamer = BlendshapeStreamer(output_mode="file", output_file=output_json)
     frames, pending = 0, []
+    # The sliding-window extractor skips a tick that arrives less than 0.3 update intervals after the last one by the WALL
+    # clock (mel_sliding_window.py:267-269).  A file is converted faster than real time, so the gate is driven by AUDIO
+    # time here -- the clock the reference's file player keeps by sleeping one chunk duration per chunk
+    # (scripts/rt_simplified.py:100-174); without this the output would depend on how fast the GPU is.
+    ticks = [0]
+    extractor = getattr(inference.model, "mel_extractor", None)
+    saved_clock = getattr(extractor, "_clock", None)
+    if extractor is not None and saved_clock is not None:
+        extractor._clock = lambda: 1.0 + ticks[0] * inference.frame_samples / float(inference.sample_rate)
     try:
         for chunk in AudioFileReader(input_audio, inference.sample_rate, chunk_size):
             inference.process_audio_chunk(chunk)
             while True:
+                ticks[0] += 1
                 bs = inference.inference_step()
                 if bs is None:
                     break
@@ -313,6 +323,8 @@ def convert_file(inference: "RealTimeInference", input_audio: str, output_json: 
             frames += len(pending)
     finally:
         streamer.close()
+        if extractor is not None and saved_clock is not None:
+            extractor._clock = saved_clock
     return frames
 
 

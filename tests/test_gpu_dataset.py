@@ -8,7 +8,7 @@ import torch
 from scipy.io import wavfile
 
 from koemorph_amd import synth
-from koemorph_amd.data import SequentialKoeMorphDataset, detect_source_fps
+from koemorph_amd.data import AdaptiveSequentialDataset, SequentialKoeMorphDataset, create_adaptive_dataloader, detect_source_fps
 from oracle import dataset as od
 
 pytestmark = pytest.mark.gpu
@@ -153,3 +153,40 @@ def test_sequential_trainer_script_end_to_end(tmp_path):
     assert m3a["total"] == m3b["total"] and m3a["lr"] == m3b["lr"]
     for (k, a), (_, b) in zip(st.state_dict().items(), st2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize("mode,kw", [("dense", {}), ("sparse", {"initial_stride": 16}), ("progressive", {"initial_stride": 12, "final_stride": 2, "epoch": 3, "max_epochs": 7}),
+                                     ("mixed", {"initial_stride": 20, "dense_sampling_ratio": 0.25})])
+def test_adaptive_dataset_modes_match_reference_pipeline(mode, kw, tmp_path):
+    """AdaptiveSequentialDataset mirror (src/data/adaptive_sequential_dataset.py): window order, stride per mode, keys and
+    bit-exact windows against the restated pipeline (oracle/dataset.py)."""
+    a0, l0 = write_pair(tmp_path, "a_first", 9.3, 30, 10)
+    a1, l1 = write_pair(tmp_path, "b_second", 9.6, 30, 20, extra_label_frames=7)      # label / audio mismatch -> truncation
+    ds = AdaptiveSequentialDataset(tmp_path, stride_mode=mode, shuffle_files=False, loop_dataset=False, batch_size=5, **kw)
+    stride = od.adaptive_stride(mode, kw.get("initial_stride", 32), kw.get("final_stride", 1), kw.get("epoch", 0), kw.get("max_epochs", 100))
+    assert ds.current_stride == stride
+    ref = []
+    np.random.seed(99)
+    for fi, (name, l) in enumerate([("a_first", l0), ("b_second", l1)]):
+        a = wavfile.read(tmp_path / (name + ".wav"))[1].astype(np.float32)
+        for i, sf, dense, aw, bw in od.adaptive_windows(a, l, mode, stride, kw.get("initial_stride", 32),
+                                                        kw.get("dense_sampling_ratio", 0.1), 256, 533):
+            ref.append((fi, i, sf, dense, aw, bw))
+    got = []
+    np.random.seed(99)
+    for batch in ds:
+        B = batch["audio"].shape[0]
+        assert set(batch) == {"audio", "blendshapes", "target", "file_indices", "window_indices", "start_frames", "file_names", "is_dense"}
+        assert B <= 5 and batch["blendshapes"].shape == (B, 256, 52)
+        for b in range(B):
+            got.append((int(batch["file_indices"][b]), int(batch["window_indices"][b]), int(batch["start_frames"][b]),
+                        bool(batch["is_dense"][b]), batch["audio"][b].cpu().numpy(), batch["blendshapes"][b].cpu().numpy(),
+                        batch["target"][b].cpu().numpy()))
+    assert len(got) == len(ref) and len(ref) >= 4
+    for g, r in zip(got, ref):
+        assert g[:4] == r[:4]
+        assert np.array_equal(g[4], r[4]) and np.array_equal(g[5], r[5]) and np.array_equal(g[6], r[5][-1])
+    if mode == "progressive":                       # set_epoch moves the stride along the schedule (:128-132)
+        ds.set_epoch(6)
+        assert ds.current_stride == 2 and len(ds.plan(0)) == (279 - 256) // 2 + 1
+    assert isinstance(create_adaptive_dataloader(tmp_path, batch_size=2, stride_mode="dense"), AdaptiveSequentialDataset)

@@ -104,22 +104,23 @@ def test_two_rank_training_with_unequal_shares(n_global):
 
 
 def test_bench_two_rank_rehearsal():
-    """bench.py's N > 1 path (rendezvous, per-rank inputs, barrier + max-over-ranks clock, whole-job value, rank-0 JSON)
-    rehearsed with two ranks sharing the one card (gloo collectives; the driver's runs use RCCL, one rank per GPU)."""
+    """bench.py's N > 1 path exactly as the driver invokes it -- plain `python bench.py --gpus 2`, NO torchrun: bench.py
+    starts the two ranks itself (rendezvous, per-rank inputs, barrier + max-over-ranks clock, whole-job value, rank-0
+    JSON).  The two ranks share the one card here, so the collectives run over gloo (KM_BENCH_BACKEND); the driver's
+    runs use RCCL, one rank per GPU."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, KM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3",
-           "--cpu-windows", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["KM_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--cpu-seconds", "0"]
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=240)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 3 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 10 and d["warmup"] == 3 and d["scaling"] == "weak"
     B = d["config"]["windows_per_gpu"]
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 2 * B) < 0.01 * 2 * B      # whole-job frames per step = 2 ranks x B
     assert d["roofline"]["frac"] > 0 and d["vs_baseline"] is None

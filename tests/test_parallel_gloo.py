@@ -82,3 +82,23 @@ def test_shard_ranges_and_stream_owner():
     assert [parallel.stream_owner(s, 1024, 8) for s in (0, 127, 128, 1023)] == [0, 0, 1, 7]
     with pytest.raises(ValueError):
         parallel.stream_owner(1024, 1024, 8)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_starts_its_own_ranks(n):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (the driver's command line) must start N ranks
+    itself.  The `rendezvous` workload touches neither the GPU nor the library, so the launcher, the gloo rendezvous,
+    the all-reduce-of-ones rank count, the max-over-ranks clock and the single rank-0 line are testable on the CPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--workload", "rendezvous", "--steps", "4",
+                          "--warmup", "1"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["rccl_ranks"] == n and d["steps"] == 4
+    assert d["ms_per_step"] >= 10.0 * n * 0.9                 # the clock is the SLOWEST rank's (rank r sleeps 10 (r+1) ms per step)
