@@ -308,11 +308,14 @@ def convert_file(inference: "RealTimeInference", input_audio: str, output_json: 
     try:
         for chunk in AudioFileReader(input_audio, inference.sample_rate, chunk_size):
             inference.process_audio_chunk(chunk)
-            while True:
+            # drain every whole frame the ring holds: inference_step also returns None while the 8.5 s context is still
+            # filling, so "None" cannot end this loop (one read per 1024-sample chunk would let the 2 s ring overflow
+            # and silently drop audio, scripts/rt.py:61-64)
+            while inference.audio_buffer.available >= inference.frame_samples:
                 ticks[0] += 1
                 bs = inference.inference_step()
                 if bs is None:
-                    break
+                    continue
                 pending.append(np.asarray(bs, np.float32))
                 if len(pending) == 256:
                     streamer.send_batch(np.stack(pending), (frames + np.arange(len(pending))) / inference.target_fps)
