@@ -295,3 +295,9 @@ def make_koemorph_params(seed: int, c: KoeMorphConfig, scale: float = 1.0) -> Di
     return out
 
 
+
+
+def make_av_features(seed: int, B: int, T: int = 40, D: int = 80) -> np.ndarray:
+    """audio_features (B, T, D) for the audio-visual term of the reference's PerceptualBlendshapeLoss
+    (src/model/losses.py:340-378): mel-like rows whose overall level differs from window to window."""
+    return (uniform(seed * 3 + 7, (B, T, D), 0.0, 1.0) * uniform(seed * 3 + 8, (B, 1, 1), 0.2, 2.0)).astype(np.float32)

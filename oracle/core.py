@@ -61,9 +61,15 @@ def core_forward(params: Dict[str, "np.ndarray | torch.Tensor"],
                  mel_features, mel_temporal_features, emotion_features,
                  num_heads: int = 8, mel_sequence_length: int = 256,
                  temperature: float = 1.0, return_attention: bool = False,
-                 dtype=torch.float32, return_intermediates: bool = False
+                 dtype=torch.float32, return_intermediates: bool = False,
+                 dropout_p: float = 0.0, drop_masks: Optional[Dict[str, "np.ndarray | torch.Tensor"]] = None
                  ) -> Dict[str, torch.Tensor]:
-    """DualStreamCrossAttention.forward (dual_stream_attention.py:162-280)."""
+    """DualStreamCrossAttention.forward (dual_stream_attention.py:162-280).
+
+    Training mode: the module holds three dropouts (p = ``dropout``, :106, :115, :153) -- on the attention weights of
+    both nn.MultiheadAttention modules (after the softmax, before P V) and on the decoder's hidden layer (after the
+    ReLU).  ``drop_masks`` = {"mel": (B,H,28,80), "emo": (B,H,24,1), "dec": (B,52,d/2)} of 0/1 keep flags makes them
+    explicit; kept values are scaled by 1/(1-p) as torch.nn.functional.dropout does."""
     P = {k: _t(v, dtype) for k, v in params.items()}
     mel = _t(mel_features, dtype)
     short = _t(mel_temporal_features, dtype)
@@ -90,14 +96,15 @@ def core_forward(params: Dict[str, "np.ndarray | torch.Tensor"],
     qm = P["mouth_queries"].unsqueeze(0).expand(B, -1, -1)
     qe = P["expression_queries"].unsqueeze(0).expand(B, -1, -1)
     # :225-231
+    dm = {k: _t(v, dtype) for k, v in (drop_masks or {}).items()}
     mo, mw = mha_forward(qm, y, P["mel_attention.in_proj_weight"], P["mel_attention.in_proj_bias"],
                          P["mel_attention.out_proj.weight"], P["mel_attention.out_proj.bias"],
-                         num_heads, return_attention)
+                         num_heads, return_attention, dropout_p, dm.get("mel"))
     mo = F.linear(mo, P["mel_output_proj.weight"], P["mel_output_proj.bias"])
     # :234-240
     eo, ew = mha_forward(qe, e, P["emotion_attention.in_proj_weight"], P["emotion_attention.in_proj_bias"],
                          P["emotion_attention.out_proj.weight"], P["emotion_attention.out_proj.bias"],
-                         num_heads, return_attention)
+                         num_heads, return_attention, dropout_p, dm.get("emo"))
     eo = F.linear(eo, P["emotion_output_proj.weight"], P["emotion_output_proj.bias"])
     # :243-245
     nb = P["mel_weights"].shape[0]
@@ -106,6 +113,8 @@ def core_forward(params: Dict[str, "np.ndarray | torch.Tensor"],
     comb[:, EXPRESSION_INDICES] = eo
     # :248 (decoder :150-156; Dropout is identity in eval)
     h = torch.relu(F.linear(comb, P["blendshape_decoder.0.weight"], P["blendshape_decoder.0.bias"]))
+    if "dec" in dm:                                    # nn.Dropout(dropout) of the decoder (:153), training mode
+        h = h * dm["dec"] / (1.0 - dropout_p)
     z = F.linear(h, P["blendshape_decoder.3.weight"], P["blendshape_decoder.3.bias"]).squeeze(-1)
     bs = torch.sigmoid(z)
     # :252-253
@@ -144,7 +153,7 @@ PERCEPTUAL_GROUPS = (("mouth", range(12, 32), 2.0), ("eye", range(0, 12), 1.0), 
 
 def koemorph_loss(pred, target, mse_weight=1.0, l1_weight=0.1, perceptual_weight=0.5, temporal_weight=0.2,
                   sparsity_weight=0.01, smoothness_weight=0.1, landmark_weight=0.3, velocity_weight=0.05,
-                  prev_pred=None, prev_target=None, landmark_w=None):
+                  prev_pred=None, prev_target=None, landmark_w=None, audio_features=None):
     """KoeMorphLoss.forward restated (src/model/losses.py:89-178) for audio_features=None: the weighted sum of
     mse (:113-117), l1 (:119-123), perceptual = group-weighted MSEs (:326-338), temporal (:185-200), velocity
     (:202-217), sparsity (:219-224), smoothness = total variation along the 52 coefficients (:226-234) and landmark
@@ -159,6 +168,13 @@ def koemorph_loss(pred, target, mse_weight=1.0, l1_weight=0.1, perceptual_weight
         for _, idx, w in PERCEPTUAL_GROUPS:
             idx = list(idx)
             per = per + w * F.mse_loss(pred[:, idx], target[:, idx])
+        if audio_features is not None:                  # audio-visual consistency (:340-378): 1 - cos(mouth activation, audio energy)
+            mouth = pred[:, list(range(12, 32))].mean(dim=1)
+            energy = audio_features.norm(dim=2).mean(dim=1) if audio_features.dim() == 3 else audio_features.norm(dim=1)
+            mouth_n = F.normalize(mouth.unsqueeze(0), dim=1).squeeze(0)
+            audio_n = F.normalize(energy.unsqueeze(0), dim=1).squeeze(0)
+            corr = F.cosine_similarity(mouth_n.unsqueeze(0), audio_n.unsqueeze(0))
+            per = per + 0.5 * (1 - corr.mean())
         total = total + perceptual_weight * per
     if prev_pred is not None and prev_target is not None:
         if temporal_weight > 0:
@@ -175,25 +191,28 @@ def koemorph_loss(pred, target, mse_weight=1.0, l1_weight=0.1, perceptual_weight
 
 
 def core_full_loss_and_grads(params, mel, short, emo, target, prev_pred, prev_target, landmark_w, weights=None,
-                             num_heads=8, mel_sequence_length=256, dtype=torch.float32):
+                             num_heads=8, mel_sequence_length=256, dtype=torch.float32, audio_features=None,
+                             dropout_p=0.0, drop_masks=None):
     """Full KoeMorphLoss (defaults of losses.py:36-47 unless `weights` overrides) of the core's prediction and
     d loss / d param through torch.autograd on the restated forward (eval mode)."""
     P = {k: _t(v, dtype).clone().requires_grad_(True) for k, v in params.items()}
-    out = core_forward(P, mel, short, emo, num_heads=num_heads, mel_sequence_length=mel_sequence_length, dtype=dtype)
+    out = core_forward(P, mel, short, emo, num_heads=num_heads, mel_sequence_length=mel_sequence_length, dtype=dtype,
+                       dropout_p=dropout_p, drop_masks=drop_masks)
     loss = koemorph_loss(out["blendshapes"], _t(target, dtype), prev_pred=_t(prev_pred, dtype),
-                         prev_target=_t(prev_target, dtype), landmark_w=_t(landmark_w, dtype), **(weights or {}))
+                         prev_target=_t(prev_target, dtype), landmark_w=_t(landmark_w, dtype),
+                         audio_features=None if audio_features is None else _t(audio_features, dtype), **(weights or {}))
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).detach().numpy() for k, v in P.items()}
     return float(loss.detach()), grads, out["blendshapes"].detach().numpy()
 
 
 def core_loss_and_grads(params, mel, short, emo, target, num_heads=8,
-                        mel_sequence_length=256, dtype=torch.float32):
+                        mel_sequence_length=256, dtype=torch.float32, dropout_p=0.0, drop_masks=None):
     """MSE(blendshapes, target) and d loss / d param for every state-dict tensor, through
-    torch.autograd on the restated forward (eval mode, dropout off) -- golden G7."""
+    torch.autograd on the restated forward (eval mode, dropout off, unless masks are given) -- golden G7."""
     P = {k: _t(v, dtype).clone().requires_grad_(True) for k, v in params.items()}
     out = core_forward(P, mel, short, emo, num_heads=num_heads,
-                       mel_sequence_length=mel_sequence_length, dtype=dtype)
+                       mel_sequence_length=mel_sequence_length, dtype=dtype, dropout_p=dropout_p, drop_masks=drop_masks)
     loss = F.mse_loss(out["blendshapes"], _t(target, dtype))
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).detach().numpy()

@@ -42,7 +42,27 @@ CASES = [
     # full KoeMorphLoss (src/model/losses.py, default weights) with prev tensors and a seeded landmark matrix
     dict(name="core_d64_T32_H4_fullloss", d=64, T=32, H=4, B=5, t_in=33, pstyle="trained", istyle="randn", seed=51, grads="full"),
     dict(name="core_d256_T256_H8_fullloss", d=256, T=256, H=8, B=8, t_in=257, pstyle="trained", istyle="mel01", seed=52, grads="full"),
+    # TRAINING mode (model.train(), dropout 0.1 in both attentions and the decoder, src/train_sequential.py:118): the three
+    # dropout masks are reproduced from the seed (see train_masks) and stored with the outputs and gradients
+    dict(name="core_d64_T32_H4_train", d=64, T=32, H=4, B=5, t_in=33, pstyle="trained", istyle="randn", seed=71, grads=True, train=0.1),
+    dict(name="core_d256_T256_H8_train", d=256, T=256, H=8, B=8, t_in=257, pstyle="trained", istyle="mel01", seed=72, grads=True, train=0.1),
+    # ... and the full KoeMorphLoss WITH audio_features, i.e. including the audio-visual term of PerceptualBlendshapeLoss
+    dict(name="core_d256_T256_H8_train_fullloss_av", d=256, T=256, H=8, B=8, t_in=257, pstyle="trained", istyle="mel01", seed=73,
+         grads="full", train=0.1, av=True),
+    dict(name="core_d64_T32_H4_fullloss_av", d=64, T=32, H=4, B=5, t_in=33, pstyle="trained", istyle="randn", seed=74, grads="full", av=True),
 ]
+
+
+def train_masks(seed, B, H, d, p):
+    """The keep masks torch draws in DualStreamCrossAttention.forward under model.train() after torch.manual_seed(seed), in
+    call order: attention-weight dropout of mel_attention (B,H,28,80), of emotion_attention (B,H,24,1), then the
+    decoder's nn.Dropout on (B,52,d/2).  F.dropout on a tensor of ones yields keep/(1-p) with the same generator
+    consumption; main() asserts that the oracle fed with these masks reproduces the reference's training-mode output."""
+    torch.manual_seed(seed)
+    out = {}
+    for key, shape in (("mel", (B, H, 28, 80)), ("emo", (B, H, 24, 1)), ("dec", (B, 52, d // 2))):
+        out[key] = (torch.nn.functional.dropout(torch.ones(shape), p, True) > 0).numpy()
+    return out
 
 
 def full_loss_inputs(synth, seed, B):
@@ -65,7 +85,8 @@ def main():
         mel, short, emo = synth.make_core_inputs(c["seed"], c["B"], c["t_in"], style=c["istyle"])
         if os.environ.get("KM_GOLDEN_ONLY") and os.environ["KM_GOLDEN_ONLY"] not in c["name"]:
             continue
-        m = DualStreamCrossAttention(d_model=c["d"], num_heads=c["H"], mel_sequence_length=c["T"]).eval()
+        m = DualStreamCrossAttention(d_model=c["d"], num_heads=c["H"], mel_sequence_length=c["T"],
+                                     dropout=c.get("train", 0.1)).eval()
         m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
         with torch.no_grad():
             o = m(torch.from_numpy(mel), torch.from_numpy(short), torch.from_numpy(emo), return_attention=True)
@@ -80,7 +101,26 @@ def main():
         }
         if c["grads"]:
             m.zero_grad()
+            masks = None
+            if c.get("train"):
+                m.train()
+                torch.manual_seed(1000 + c["seed"])
             out = m(torch.from_numpy(mel), torch.from_numpy(short), torch.from_numpy(emo))["blendshapes"]
+            if c.get("train"):
+                from oracle import core as ocore
+                masks = train_masks(1000 + c["seed"], c["B"], c["H"], c["d"], c["train"])
+                chk = ocore.core_forward(params, mel, short, emo, num_heads=c["H"], mel_sequence_length=c["T"],
+                                         dropout_p=c["train"], drop_masks=masks)["blendshapes"]
+                err = float((chk - out.detach()).abs().max())
+                assert err < 2e-6, f"{c['name']}: the reproduced dropout masks do not explain the reference's training-mode output ({err})"
+                rec["train_blendshapes"] = out.detach().numpy()
+                rec["dropout_p"] = np.float64(c["train"])
+                for mk, mv in masks.items():
+                    rec["mask/" + mk] = np.packbits(mv.reshape(-1))
+                    rec["maskshape/" + mk] = np.array(mv.shape, np.int64)
+            af = None
+            if c.get("av"):      # audio_features (B, T, D): the reference's trainers pass the mel features here
+                af = synth.make_av_features(c["seed"], c["B"])
             if c["grads"] == "full":
                 from src.model.losses import KoeMorphLoss  # reference, read-only
                 target, prev_pred, prev_target, lw = full_loss_inputs(synth, c["seed"], c["B"])
@@ -88,7 +128,8 @@ def main():
                 with torch.no_grad():
                     crit.landmark_loss.bs_to_landmark_weights.copy_(torch.from_numpy(lw))
                 loss, metrics = crit(out, torch.from_numpy(target), prev_pred=torch.from_numpy(prev_pred),
-                                     prev_target=torch.from_numpy(prev_target))
+                                     prev_target=torch.from_numpy(prev_target),
+                                     audio_features=None if af is None else torch.from_numpy(af.astype(np.float32)))
                 for mk in ("mse", "l1", "perceptual", "temporal", "velocity", "sparsity", "smoothness", "landmark"):
                     rec["metric/" + mk] = np.float64(metrics[mk])
             else:

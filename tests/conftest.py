@@ -49,6 +49,16 @@ def full_loss_inputs(seed, B):
             synth.uniform(seed * 3 + 3, (B, 52), 0.0, 1.0), (0.01 * synth.normal(seed * 3 + 4, (136, 52))).astype(np.float32))
 
 
+def golden_masks(g):
+    """The three dropout keep masks of a training-mode fixture ({"mel","emo","dec"} -> bool arrays), unpacked."""
+    import numpy as np
+    out = {}
+    for k in ("mel", "emo", "dec"):
+        shape = tuple(int(v) for v in g["maskshape/" + k])
+        out[k] = np.unpackbits(g["mask/" + k])[:int(np.prod(shape))].reshape(shape).astype(bool)
+    return out
+
+
 def assert_grads_match(grads, g, tol):
     """grads vs a golden record holding grad/<key> (small tensors) or gradsample/<key> + gradnorm/<key>."""
     import numpy as np

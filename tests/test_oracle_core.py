@@ -82,3 +82,44 @@ def test_oracle_full_koemorph_loss_matches_reference(name):
         v = float(core.koemorph_loss(P, T, prev_pred=torch.from_numpy(prev_pred), prev_target=torch.from_numpy(prev_target),
                                      landmark_w=torch.from_numpy(lw), **k2))
         assert abs(v - float(g["metric/" + term])) <= 2e-6 * max(1.0, abs(float(g["metric/" + term]))), term
+
+
+@pytest.mark.parametrize("name", ["core_d64_T32_H4_train", "core_d256_T256_H8_train"])
+def test_oracle_training_mode_dropout_matches_reference(name):
+    """model.train(): the restated forward with the fixture's three dropout masks reproduces the reference module's
+    training-mode output and autograd gradients (dual_stream_attention.py:106,115,153; train_sequential.py:118)."""
+    from conftest import assert_grads_match, golden_masks
+    from koemorph_amd import synth
+    c, params, (mel, short, emo), g = golden_case(name)
+    masks, p = golden_masks(g), float(g["dropout_p"])
+    assert abs(masks["mel"].mean() - (1 - p)) < 0.01 and abs(masks["dec"].mean() - (1 - p)) < 0.02
+    target = synth.uniform(c["seed"] * 3 + 1, (c["B"], 52), 0.0, 1.0)
+    loss, grads, out = core.core_loss_and_grads(params, mel, short, emo, target, num_heads=c["H"], mel_sequence_length=c["T"],
+                                                dropout_p=p, drop_masks=masks)
+    np.testing.assert_allclose(out, g["train_blendshapes"], atol=2e-7, rtol=1e-5)
+    assert np.abs(out - g["blendshapes"]).max() > 1e-5            # ... which is NOT the eval-mode output
+    assert abs(loss - float(g["loss"])) < 1e-6 * max(1.0, abs(float(g["loss"])))
+    assert_grads_match(grads, g, 1e-4)
+    # the query / key projections of the emotion attention stay gradient-free under dropout (softmax over ONE key)
+    assert not grads["expression_queries"].any() and not grads["emotion_attention.in_proj_weight"][:2 * c["d"]].any()
+
+
+@pytest.mark.parametrize("name", ["core_d64_T32_H4_fullloss_av", "core_d256_T256_H8_train_fullloss_av"])
+def test_oracle_audio_visual_term_matches_reference(name):
+    """KoeMorphLoss with audio_features: the audio-visual consistency term of PerceptualBlendshapeLoss (losses.py:340-378)."""
+    from conftest import assert_grads_match, full_loss_inputs, golden_masks
+    from koemorph_amd import synth
+    c, params, (mel, short, emo), g = golden_case(name)
+    target, prev_pred, prev_target, lw = full_loss_inputs(c["seed"], c["B"])
+    af = synth.make_av_features(c["seed"], c["B"])
+    kw = {}
+    if "dropout_p" in g:
+        kw = dict(dropout_p=float(g["dropout_p"]), drop_masks=golden_masks(g))
+    loss, grads, out = core.core_full_loss_and_grads(params, mel, short, emo, target, prev_pred, prev_target, lw,
+                                                     num_heads=c["H"], mel_sequence_length=c["T"], audio_features=af, **kw)
+    assert abs(loss - float(g["loss"])) < 1e-6 * max(1.0, abs(float(g["loss"])))
+    assert_grads_match(grads, g, 1e-4)
+    per = float(core.koemorph_loss(torch.from_numpy(out), torch.from_numpy(target), mse_weight=0, l1_weight=0, perceptual_weight=1.0,
+                                   temporal_weight=0, sparsity_weight=0, smoothness_weight=0, landmark_weight=0, velocity_weight=0,
+                                   audio_features=torch.from_numpy(af)))
+    assert abs(per - float(g["metric/perceptual"])) <= 2e-6 * max(1.0, abs(float(g["metric/perceptual"])))
