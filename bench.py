@@ -63,8 +63,6 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=18.0, help="CPU-baseline time budget (0 = skip)")
     ap.add_argument("--cpu-windows", type=int, default=None, help="deprecated: 0 skips the CPU baseline")
     ap.add_argument("--no-split", action="store_true", help="skip the experimental split-bf16 timing")
-    ap.add_argument("--schedule", choices=("auto", "serial", "overlap"), default="auto",
-                    help="c2: km_forward_audio schedule (auto = the library default)")
     args = ap.parse_args()
     defaults = {"c2": (200, 20, 256), "c3": (100, 10, 8), "c4": (50, 5, 256), "c5": (300, 20, 128), "rendezvous": (3, 1, 1)}[args.workload]
     if args.steps is None:
@@ -223,8 +221,6 @@ def run_c2(args, rk: Ranks):
     eng.load_state_dict(params)
     eng.finalize(rk.dev)
     eng.reserve(B, L)
-    if args.schedule != "auto":
-        eng.set_option("overlap", 1 if args.schedule == "overlap" else 0)
     audio_np = synth.make_audio(100 + rk.rank, B, L, style="uniform")
     emo_np = synth.normal(200 + rk.rank, (B, 256))
     audio = torch.from_numpy(audio_np).to(rk.dev)
@@ -322,7 +318,7 @@ def run_c2(args, rk: Ranks):
                                "80-bin log-mel (257 frames) -> dual-stream attention d_model=256, 8 heads, "
                                "window 256 -> 52 coefficients + EMA; from audio resident in HBM",
                    "windows_per_gpu": B, "samples_per_window": L, "parallelism": f"window-sharded x{rk.world}, no collective",
-                   "schedule": args.schedule},
+                   },
         "roofline": roofline, "roofline_other_kernel": other, "step_roofline": step_roof, "kernel_ms": stage_ms,
         "cpu_baseline": cpu, "experimental_split_bf16": split,
     }

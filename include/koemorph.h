@@ -258,8 +258,30 @@ typedef struct km_loss_config {
     const float* prev_pred_dev;
     const float* prev_target_dev;
     const float* landmark_w_dev;
+    const float* audio_energy_dev;   /* (B) per-window audio energy (km_audio_energy) or NULL: adds the audio-visual term
+                                        0.5 * (1 - cos(mean mouth activation, audio energy)) to the perceptual loss
+                                        (PerceptualBlendshapeLoss.forward with audio_features, losses.py:340-378) */
 } km_loss_config;
 int km_train_set_loss(km_handle h, const km_loss_config* cfg);
+/* (B, T, D) or (B, 1, D) audio features -> (B) energies for km_loss_config.audio_energy_dev: mean over T of the L2 norm
+ * over D, as PerceptualBlendshapeLoss._compute_audiovisual_loss reduces its audio_features (losses.py:352-358). */
+int km_audio_energy(const float* features_dev, int64_t B, int64_t T, int64_t D, float* energy_dev, void* stream);
+
+/* Training-mode dropout: the reference trains under model.train() (src/train_sequential.py:118) with dropout p = 0.1 on
+ * the attention weights of both nn.MultiheadAttention modules and on the decoder's hidden layer
+ * (src/model/dual_stream_attention.py:106, :115, :153).  p = 0 (the state after km_train_init) is eval-mode arithmetic.
+ *   km_train_set_dropout        p in [0, 1); masks are drawn per step by a counter-based Philox4x32-10 generator keyed by
+ *                               `seed` and a device-side step counter (a captured step draws fresh masks on every replay);
+ *                               external_masks != 0: the step uses the masks last given to km_train_set_dropout_masks
+ *                               (parity tests replay the masks of reference-generated fixtures)
+ *   km_train_get_dropout_masks  keep flags (1 = kept) of the most recent step, for B windows: mel (B, H, 28, n_mels),
+ *                               emo (B, H, 24), dec (B, 52, d_model / 2) bytes on the host -- the layout of
+ *                               oracle.core.core_forward(drop_masks=...)
+ *   km_train_set_dropout_masks  the reverse (host -> device) */
+int km_train_set_dropout(km_handle h, float p, uint64_t seed, int32_t external_masks);
+int km_train_get_dropout_masks(km_handle h, int64_t B, uint8_t* mel_host, uint8_t* emo_host, uint8_t* dec_host, void* stream);
+int km_train_set_dropout_masks(km_handle h, int64_t B, const uint8_t* mel_host, const uint8_t* emo_host, const uint8_t* dec_host,
+                               void* stream);
 
 /* ---- legacy single-stream variant --------------------------------------------------------------------
  * SimplifiedKoeMorphModel (src/model/simplified_model.py:12-156), used by the reference's src/train.py,
@@ -362,7 +384,7 @@ int km_stage_times(km_handle h, float* ms3);
  * this path: every switch selects between two implementations of the SAME arithmetic, for A/B timing and for the
  * tests that pin one path against the other).  Names: "core_split" (0 | 3 | 6, experimental split-bf16 core),
  * "seq_per_window", "generic_staged", "mel_two_frame", "emotion_separate", "no_ln_fusion", "no_db_fusion",
- * "no_score_fusion", "no_out_fusion", "no_v_fusion", "overlap".  A handle's switches start from the environment
+ * "no_score_fusion", "no_out_fusion", "no_v_fusion", "train_chain" (training step as the launch-per-op chain).  A handle's switches start from the environment
  * variables KM_<NAME> read ONCE in km_create; no launch path reads the environment.  Unknown name: KM_ERR_INVALID_ARG. */
 int km_set_option(km_handle h, const char* name, int64_t value);
 

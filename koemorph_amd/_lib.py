@@ -49,7 +49,8 @@ class KMKoeMorphConfig(C.Structure):
 class KMLossConfig(C.Structure):
     _fields_ = [("perceptual_weight", C.c_float), ("temporal_weight", C.c_float), ("sparsity_weight", C.c_float),
                 ("smoothness_weight", C.c_float), ("landmark_weight", C.c_float), ("velocity_weight", C.c_float),
-                ("prev_pred_dev", C.c_void_p), ("prev_target_dev", C.c_void_p), ("landmark_w_dev", C.c_void_p)]
+                ("prev_pred_dev", C.c_void_p), ("prev_target_dev", C.c_void_p), ("landmark_w_dev", C.c_void_p),
+                ("audio_energy_dev", C.c_void_p)]
 
 
 KM_MEL_SLANEY, KM_MEL_HTK = 0, 1
@@ -100,6 +101,10 @@ SIGNATURES = {
     "km_train_set_params": (C.c_int, [_h, _p, _i64]),
     "km_train_sync": (C.c_int, [_h, _p]),
     "km_train_set_loss": (C.c_int, [_h, C.POINTER(KMLossConfig)]),
+    "km_audio_energy": (C.c_int, [_p, _i64, _i64, _i64, _p, _p]),
+    "km_train_set_dropout": (C.c_int, [_h, C.c_float, C.c_uint64, _i32]),
+    "km_train_get_dropout_masks": (C.c_int, [_h, _i64, _p, _p, _p, _p]),
+    "km_train_set_dropout_masks": (C.c_int, [_h, _i64, _p, _p, _p, _p]),
     "km_train_get_optimizer_state": (C.c_int, [_h, _p, _p, _i64, _p]),
     "km_train_set_optimizer_state": (C.c_int, [_h, _p, _p, _i64, _p]),
     "km_resample_labels": (C.c_int, [_p, C.c_int64, C.c_int32, C.c_int64, _p, _p]),

@@ -213,6 +213,9 @@ static int free_train(Context* c) {
     c->tr_params = c->tr_m = c->tr_v = c->tr_act = c->tr_q = c->tr_dq = c->tr_part = c->tr_gnorm = c->tr_loss = c->tr_red = nullptr;
     c->tr_steps = nullptr;
     if (c->tr_red2) { HIP_TRY(hipFree(c->tr_red2)); c->tr_red2 = nullptr; }
+    if (c->trp_act) { HIP_TRY(hipFree(c->trp_act)); c->trp_act = nullptr; c->trp_act_floats = 0; }
+    if (c->trp_masks) { HIP_TRY(hipFree(c->trp_masks)); c->trp_masks = nullptr; }
+    if (c->trp_drop_ctr) { HIP_TRY(hipFree(c->trp_drop_ctr)); c->trp_drop_ctr = nullptr; }
     if (c->tr_s2) { (void)hipStreamDestroy((hipStream_t)c->tr_s2); c->tr_s2 = nullptr; }
     for (auto& e : c->tr_ev)
         if (e) { (void)hipEventDestroy((hipEvent_t)e); e = nullptr; }
@@ -271,6 +274,17 @@ int km_train_init(km_handle h, int64_t max_windows, void* stream) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tr_steps), 2 * sizeof(int)));
     HIP_TRY(hipMemsetAsync(c->tr_steps, 0, 2 * sizeof(int), (hipStream_t)stream));
     c->tr_windows = max_windows;
+    {   // phased step (km_trainp.hip): packed input first, then a fixed part, then per-window activations; dropout masks
+        int64_t fixed = 0;
+        const int64_t per = trainp_act_floats(c, &fixed);
+        const int64_t KP = (c->KT + 15) / 16 * 16;
+        c->trp_act_floats = max_windows * (per + KP * c->NK) + fixed + 4096;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_act), (size_t)c->trp_act_floats * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->trp_masks, (size_t)trainp_mask_alloc_bytes(c)));
+        HIP_TRY(hipMemsetAsync(c->trp_masks, 1, (size_t)trainp_mask_alloc_bytes(c), (hipStream_t)stream));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_drop_ctr), sizeof(int)));
+        HIP_TRY(hipMemsetAsync(c->trp_drop_ctr, 0, sizeof(int), (hipStream_t)stream));
+    }
     return upload_train_params(c, stream);
 }
 
@@ -297,6 +311,10 @@ int km_train_step(km_handle h, const float* mel_dev, int64_t B, int64_t T_in, co
     if (int rc = need_train(h, B)) return rc;
     if (!mel_dev || !mel_short_dev || !emotion_dev || !target_dev || !flat_grad_dev || !loss_dev || T_in <= 0)
         return fail(KM_ERR_INVALID_ARG, "km_train_step: bad argument");
+    if (!h->opt.train_chain)
+        return train_forward_backward_phased(h, mel_dev, B, T_in, mel_short_dev, nullptr, emotion_dev, target_dev, mse_weight,
+                                             l1_weight, flat_grad_dev, loss_dev, out_dev, ema_state_dev, ema_first, stream);
+    if (h->tr_dropout_p > 0.f) return fail(KM_ERR_UNSUPPORTED, "the launch-per-op training chain has no dropout: unset train_chain");
     return train_forward_backward(h, mel_dev, B, T_in, mel_short_dev, emotion_dev, target_dev, mse_weight, l1_weight,
                                   flat_grad_dev, loss_dev, out_dev, ema_state_dev, ema_first, stream);
 }
@@ -311,9 +329,42 @@ int km_train_step_audio(km_handle h, const float* audio_dev, int64_t B, int64_t 
     const int64_t n_frames = 1 + L / c->cfg.mel.hop_length;
     if (B > c->ws_windows || n_frames > c->ws_frames)
         return fail(KM_ERR_WORKSPACE, "workspace too small for %lld windows x %lld samples: call km_reserve", (long long)B, (long long)L);
+    if (!c->opt.train_chain) {
+        // front end straight into the packed encoder input (B, KP, n_mels) at the head of the phased workspace
+        const int KP = (c->KT + 15) / 16 * 16;
+        if (int rc = launch_mel_packed(c, c->mel_plans[0], audio_dev, B, L, c->trp_act, c->T, KP, stream)) return rc;
+        return train_forward_backward_phased(c, nullptr, B, n_frames, nullptr, c->trp_act, emotion_dev, target_dev, mse_weight,
+                                             l1_weight, flat_grad_dev, loss_dev, out_dev, ema_state_dev, ema_first, stream);
+    }
+    if (c->tr_dropout_p > 0.f) return fail(KM_ERR_UNSUPPORTED, "the launch-per-op training chain has no dropout: unset train_chain");
     if (int rc = launch_mel(c, c->mel_plans[0], audio_dev, B, L, 0, c->ws_mel, c->ws_short, stream)) return rc;
     return train_forward_backward(c, c->ws_mel, B, n_frames, c->ws_short, emotion_dev, target_dev, mse_weight, l1_weight,
                                   flat_grad_dev, loss_dev, out_dev, ema_state_dev, ema_first, stream);
+}
+
+int km_train_set_dropout(km_handle h, float p, uint64_t seed, int32_t external_masks) {
+    if (int rc = need_train(h, 1)) return rc;
+    if (!(p >= 0.f && p < 1.f)) return fail(KM_ERR_INVALID_ARG, "dropout probability has to be in [0, 1), but got %g", (double)p);
+    h->tr_dropout_p = p; h->tr_dropout_seed = seed; h->tr_dropout_mode = external_masks ? 1 : 0;
+    return KM_OK;
+}
+
+int km_train_get_dropout_masks(km_handle h, int64_t B, uint8_t* mel_host, uint8_t* emo_host, uint8_t* dec_host, void* stream) {
+    if (int rc = need_train(h, B)) return rc;
+    if (!mel_host || !emo_host || !dec_host) return fail(KM_ERR_INVALID_ARG, "km_train_get_dropout_masks: NULL argument");
+    return trainp_copy_masks(h, B, mel_host, emo_host, dec_host, 0, stream);
+}
+
+int km_train_set_dropout_masks(km_handle h, int64_t B, const uint8_t* mel_host, const uint8_t* emo_host, const uint8_t* dec_host,
+                               void* stream) {
+    if (int rc = need_train(h, B)) return rc;
+    if (!mel_host || !emo_host || !dec_host) return fail(KM_ERR_INVALID_ARG, "km_train_set_dropout_masks: NULL argument");
+    return trainp_copy_masks(h, B, const_cast<uint8_t*>(mel_host), const_cast<uint8_t*>(emo_host), const_cast<uint8_t*>(dec_host), 1, stream);
+}
+
+int km_audio_energy(const float* features_dev, int64_t B, int64_t T, int64_t D, float* energy_dev, void* stream) {
+    if (!features_dev || !energy_dev || B <= 0 || T <= 0 || D <= 0) return fail(KM_ERR_INVALID_ARG, "km_audio_energy: bad argument");
+    return launch_audio_energy(features_dev, B, T, D, energy_dev, stream);
 }
 
 int km_train_set_loss(km_handle h, const km_loss_config* cfg) {

@@ -61,7 +61,7 @@ struct Options {
     int mel_two_frame = 0;         // 1: two-frames-per-wave front end (A/B baseline)
     int emotion_separate = 0;      // 1: emotion logits in their own kernel
     int no_ln_fusion = 0, no_db_fusion = 0, no_score_fusion = 0, no_out_fusion = 0, no_v_fusion = 0;   // generic chain A/B
-    int overlap = 1;               // 1: km_forward_audio runs the co-resident front-end/core schedule where available
+    int train_chain = 0;           // 1: training step as the round-1 launch-per-op chain (A/B reference; no dropout)
 };
 void options_from_env(Options& o);
 int set_option(struct Context* c, const char* name, long long value);
@@ -129,6 +129,13 @@ struct Context {
     int* tr_steps = nullptr;         // device-side AdamW step counters (graph replay safe)
     bool tr_alpha_live = false;      // smoothing_alpha was in the last step's graph (see adamw_kernel)
     km_loss_config tr_loss_cfg{};    // extra KoeMorphLoss terms (all weights 0 = off)
+    // phased training step (km_trainp.hip): its own activation workspace, dropout masks and per-step mask counter
+    float* trp_act = nullptr; int64_t trp_act_floats = 0;
+    void* trp_masks = nullptr;       // bytes: mel (W,H,28,NK) | emo (W,H,24) | dec (W,52,DH), W = tr_windows
+    int* trp_drop_ctr = nullptr;     // device-side step counter of the mask generator (graph-replay safe)
+    float tr_dropout_p = 0.f;        // training-mode dropout probability (0 = eval-mode arithmetic)
+    int tr_dropout_mode = 0;         // 0: masks drawn per step (Philox), 1: masks supplied by the caller (km_train_set_dropout_masks)
+    unsigned long long tr_dropout_seed = 0;
     // side stream of the training step (emotion stream + decoder weight gradients run beside the mel chain)
     void* tr_s2 = nullptr; void* tr_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; float* tr_red2 = nullptr;
     // shared-frame sequence mode buffers (grow-only, allocated by km_sequence_forward)
@@ -182,6 +189,16 @@ int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in
                            float* ema_state, int ema_first, void* stream);
 int train_adamw(Context* c, const float* flat_grad, float lr, float b1, float b2, float eps, float wd, float max_norm,
                 int64_t step, void* stream);
+
+// km_trainp.hip
+int64_t trainp_act_floats(Context* c, int64_t* fixed);
+int64_t trainp_mask_alloc_bytes(Context* c);
+int trainp_mask_sizes(Context* c, int64_t B, int64_t* mel, int64_t* emo, int64_t* dec);
+int trainp_copy_masks(Context* c, int64_t B, unsigned char* mel, unsigned char* emo, unsigned char* dec, int to_device, void* stream);
+int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short, const float* xp_dev,
+                                  const float* emo, const float* target, float mse_w, float l1_w, float* flat_grad, float* loss_dev,
+                                  float* out_dev, float* ema_state, int ema_first, void* stream);
+int launch_audio_energy(const float* feats, int64_t B, int64_t T, int64_t D, float* out, void* stream);
 
 // km_generic.hip
 int64_t generic_ws_floats(Context* c);

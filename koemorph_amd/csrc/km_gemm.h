@@ -19,7 +19,23 @@ struct GemmArgs {
     float alpha, beta;
     int bias_mode;                               // 0 none, 1 bias[n], 2 bias[m]
     int relu;                                    // epilogue activation: 0 none, 1 ReLU, 2 exact-erf GELU
+    // training-mode dropout in the epilogue (after the activation): v *= drop[mask_row(m) * N + n] ? drop_scale : 0.
+    // drop_map: 0 rows map 1:1, 1 rows are (window, mouth slot) -> window * 52 + MOUTH_INDICES[slot], 2 the same for
+    // (window, expression slot).  Only the 64 x 64 tile path (gemm_kernel / gemm_tile_dev) implements it.
+    const unsigned char* drop;
+    float drop_scale;
+    int drop_map;
 };
+
+// row of a (rows, N) activation buffer -> row of the (B, 52, N) dropout mask (see GemmArgs::drop_map)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int64_t gemm_drop_row(int map, int64_t m) {
+    if (map == 1) { const int64_t b = m / 28; const int q = (int)(m - b * 28); return b * 52 + (q < 27 ? 14 + q : 51); }
+    if (map == 2) { const int64_t b = m / 24; const int q = (int)(m - b * 24); return b * 52 + (q < 14 ? q : q + 27); }
+    return m;
+}
 
 int launch_gemm(const GemmArgs& g, int batch, void* stream);
 int launch_softmax_rows(float* x, int64_t rows, int w, void* stream);

@@ -491,7 +491,7 @@ const OptName kOptNames[] = {
     {"generic_staged", &Options::generic_staged}, {"mel_two_frame", &Options::mel_two_frame},
     {"emotion_separate", &Options::emotion_separate}, {"no_ln_fusion", &Options::no_ln_fusion},
     {"no_db_fusion", &Options::no_db_fusion}, {"no_score_fusion", &Options::no_score_fusion},
-    {"no_out_fusion", &Options::no_out_fusion}, {"no_v_fusion", &Options::no_v_fusion}, {"overlap", &Options::overlap},
+    {"no_out_fusion", &Options::no_out_fusion}, {"no_v_fusion", &Options::no_v_fusion}, {"train_chain", &Options::train_chain},
 };
 }  // namespace
 

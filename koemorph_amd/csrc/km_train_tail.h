@@ -1,0 +1,218 @@
+// Loss tail of the training step (decoder output -> prediction -> KoeMorphLoss -> dL/dz), shared by the launch-per-op
+// chain (km_train.hip) and the phased step (km_trainp.hip).  Included inside namespace km of a .hip translation unit.
+#pragma once
+
+__device__ __forceinline__ int tr_mouth_slot(int i) { return (i >= 14 && i <= 40) ? i - 14 : (i == 51 ? 27 : -1); }
+// blendshape index -> expression query slot 0..23 (EXPRESSION_INDICES = 0..13, 41..50; dual_stream_attention.py:14-45)
+__device__ __forceinline__ int tr_expr_slot(int i) { return i < 14 ? i : i - 27; }
+
+struct TailArgs {
+    const float* zrows;   // (B*28 + B) decoder logits of the mouth rows, then of the shared expression rows (rowdot_kernel)
+    const float* h1;      // (B*28, DH) post-ReLU hidden of the mouth rows
+    const float* he;      // (B, DH)    post-ReLU hidden of the (shared) expression row
+    const float* w2; const float* b2;
+    const float* mel_w; const float* emo_w;   // (52) raw stream weights
+    float temperature;
+    const float* target;  // (B, 52)
+    float* bs;            // (B, 52) sigmoid outputs
+    float* out;           // (B, 52) final (after clamp and EMA)
+    float* dz;            // (B, 52) dL/dz
+    float* ema_state;     // (B, 52) or null
+    int ema_first;
+    const float* alpha_p; // smoothing_alpha parameter
+    float mse_w, l1_w;
+    km_loss_config lc;    // extra KoeMorphLoss terms (weights 0 = off)
+    float* fac;           // (B, 52) scratch: d y / d f of the clamp + EMA
+    float* xp;            // (B, 52) scratch: x - previous EMA state
+    float* loss;          // (1)
+    float* d_melw; float* d_emow; float* d_alpha;   // gradients (52), (52), (1)
+    int B, DH;
+    int expr_rows;        // expression rows per window in zrows: 1 (eval-mode arithmetic: the 24 rows are identical) or 24
+    const float* audio_energy;   // (B) or null: per-window audio energy for the audio-visual term (losses.py:340-378)
+};
+
+// One workgroup: decoder output layer, sigmoid, stream weights, clamp, EMA, loss and the gradient of the loss
+// with respect to every pre-sigmoid logit.  B is small in training (8 per GPU), all loops are in a fixed order.
+// Pass A computes the prediction y (B,52); pass B the loss terms of KoeMorphLoss (src/model/losses.py:112-178) and
+// dL/dy -- the smoothness and landmark terms need the whole row of y, hence two passes.
+__device__ __forceinline__ float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }   // torch: d|x|/dx = sign(x)
+
+// 8 waves: wave w owns windows w, w + 8, ...; lane i < 52 owns coefficient i (lanes up to 63 help with the landmark
+// products).  Per-thread partial sums run over a wave's windows in order and are combined across waves in wave order,
+// so the result does not depend on timing.
+constexpr int TAIL_NW = 8;
+constexpr int TAIL_AV_MAX = 1024;     // windows per step the audio-visual term can hold in LDS
+
+template <int NW>
+__device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
+    __shared__ float wsum_s[52], wm_s[52], we_s[52], dws_p[NW][52], red[NW][64], e_s[NW][52], u_s[NW][136];
+    __shared__ float av_g[TAIL_AV_MAX], av_c[2];
+    const int i = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {   // stream weight softmaxes (dual_stream_attention.py:252-253)
+        float mm = -INFINITY, me = -INFINITY;
+        for (int k = 0; k < 52; ++k) { mm = fmaxf(mm, a.mel_w[k] / a.temperature); me = fmaxf(me, a.emo_w[k] / a.temperature); }
+        float sm = 0.f, se = 0.f;
+        for (int k = 0; k < 52; ++k) {
+            wm_s[k] = expf(a.mel_w[k] / a.temperature - mm); sm += wm_s[k];
+            we_s[k] = expf(a.emo_w[k] / a.temperature - me); se += we_s[k];
+        }
+        for (int k = 0; k < 52; ++k) { wm_s[k] /= sm; we_s[k] /= se; wsum_s[k] = 0.5f * wm_s[k] + 0.5f * we_s[k]; }
+    }
+    __syncthreads();
+    const float alpha = 1.0f / (1.0f + expf(-a.alpha_p[0]));
+    const float inv_n = 1.0f / (float)(a.B * 52);
+    const bool ema_on = a.ema_state && !a.ema_first;
+    // ---- pass A: y = EMA(clamp(wsum * sigmoid(z))) ----
+    if (i < 52) {
+        const int slot = tr_mouth_slot(i);
+        for (int b = w; b < a.B; b += NW) {
+            const float z = slot >= 0 ? a.zrows[(int64_t)b * 28 + slot]
+                                      : a.zrows[(int64_t)a.B * 28 + (a.expr_rows == 1 ? b : (int64_t)b * 24 + tr_expr_slot(i))];
+            const float bs = 1.0f / (1.0f + expf(-z));
+            const float f = wsum_s[i] * bs;
+            const float x = fminf(fmaxf(f, 0.f), 1.f);
+            float y = x, dy_dx = 1.f, xp = 0.f;
+            if (a.ema_state) {
+                float* st = a.ema_state + (int64_t)b * 52 + i;
+                if (!a.ema_first) {
+                    const float prev = *st;
+                    y = alpha * x + (1.0f - alpha) * prev;
+                    dy_dx = alpha;
+                    xp = x - prev;          // d y / d smoothing_alpha = (x - prev) * alpha (1 - alpha)
+                }
+                *st = y;
+            }
+            a.bs[(int64_t)b * 52 + i] = bs;
+            a.out[(int64_t)b * 52 + i] = y;
+            a.fac[(int64_t)b * 52 + i] = dy_dx * ((f >= 0.f && f <= 1.f) ? 1.f : 0.f);
+            a.xp[(int64_t)b * 52 + i] = xp;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const km_loss_config& lc = a.lc;
+    // audio-visual consistency (PerceptualBlendshapeLoss._compute_audiovisual_loss, losses.py:340-378):
+    //   1 - cos(m, e), m_b = mean of the 20 mouth coefficients of window b, e_b = audio energy; couples the whole batch.
+    //   d/dy[b, i in 12..31] = -(1/20) (e^_b - cos m^_b) / |m|   (the two F.normalize + cosine_similarity collapse to this)
+    const bool av_on = lc.perceptual_weight > 0.f && a.audio_energy && a.B <= TAIL_AV_MAX;
+    if (av_on) {
+        for (int b = threadIdx.x; b < a.B; b += 64 * NW) {
+            float m = 0.f;
+            for (int k = 12; k < 32; ++k) m += a.out[(int64_t)b * 52 + k];
+            av_g[b] = m * (1.0f / 20.0f);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float nm = 0.f, na = 0.f;
+            for (int b = 0; b < a.B; ++b) { nm += av_g[b] * av_g[b]; na += a.audio_energy[b] * a.audio_energy[b]; }
+            nm = fmaxf(sqrtf(nm), 1e-12f); na = fmaxf(sqrtf(na), 1e-12f);
+            float dot = 0.f, w1 = 0.f, w2 = 0.f;
+            for (int b = 0; b < a.B; ++b) {
+                const float mh = av_g[b] / nm, ah = a.audio_energy[b] / na;
+                dot += mh * ah; w1 += mh * mh; w2 += ah * ah;
+            }
+            const float corr = dot / sqrtf(fmaxf(w1 * w2, 1e-16f));
+            av_c[0] = corr; av_c[1] = nm;
+        }
+        __syncthreads();
+        {
+            const float corr = av_c[0], nm = av_c[1];
+            float na = 0.f;
+            for (int b = 0; b < a.B; ++b) na += a.audio_energy[b] * a.audio_energy[b];
+            na = fmaxf(sqrtf(na), 1e-12f);
+            __syncthreads();                      // every thread has read av_c / will overwrite av_g with the gradient factor
+            for (int b = threadIdx.x; b < a.B; b += 64 * NW)
+                av_g[b] = -lc.perceptual_weight * 0.5f * (1.0f / 20.0f) * (a.audio_energy[b] / na - corr * (av_g[b] / nm)) / nm;
+            __syncthreads();
+        }
+    }
+    // ---- pass B: loss terms and dL/dy, row by row ----
+    const bool have_prev = lc.prev_pred_dev && lc.prev_target_dev;
+    const bool t_on = lc.temporal_weight > 0.f && have_prev, v_on = lc.velocity_weight > 0.f && have_prev;
+    const bool lm_on = lc.landmark_weight > 0.f && lc.landmark_w_dev;
+    // perceptual groups (losses.py:306-338): weight / group size
+    float pg = 0.f;
+    if (i < 52) pg = i < 12 ? 1.0f / 12.f : (i < 32 ? 2.0f / 20.f : (i < 44 ? 1.0f / 12.f : 1.5f / 8.f));
+    float loss_acc = 0.f, dws = 0.f, dal = 0.f;
+    for (int b = w; b < a.B; b += NW) {
+        float y = 0.f, e = 0.f, dy = 0.f;
+        if (i < 52) {
+            y = a.out[(int64_t)b * 52 + i];
+            e = y - a.target[(int64_t)b * 52 + i];
+            loss_acc += (a.mse_w * e * e + a.l1_w * fabsf(e)) * inv_n;
+            dy = (a.mse_w * 2.0f * e + a.l1_w * sgnf(e)) * inv_n;
+            if (lc.perceptual_weight > 0.f) {
+                const float wgt = lc.perceptual_weight * pg / (float)a.B;
+                loss_acc += wgt * e * e;
+                dy += wgt * 2.0f * e;
+                if (av_on && i >= 12 && i < 32) dy += av_g[b];
+            }
+            if (t_on || v_on) {
+                const float dd = (y - lc.prev_pred_dev[(int64_t)b * 52 + i]) -
+                                 (a.target[(int64_t)b * 52 + i] - lc.prev_target_dev[(int64_t)b * 52 + i]);
+                if (t_on) { loss_acc += lc.temporal_weight * dd * dd * inv_n; dy += lc.temporal_weight * 2.0f * dd * inv_n; }
+                if (v_on) { loss_acc += lc.velocity_weight * fabsf(dd) * inv_n; dy += lc.velocity_weight * sgnf(dd) * inv_n; }
+            }
+            if (lc.sparsity_weight > 0.f) { loss_acc += lc.sparsity_weight * fabsf(y) * inv_n; dy += lc.sparsity_weight * sgnf(y) * inv_n; }
+            if (lc.smoothness_weight > 0.f) {   // torch.diff along the 52 coefficients: 51 pairs per row
+                const float wgt = lc.smoothness_weight / (float)(a.B * 51);
+                if (i > 0) { const float dl = y - a.out[(int64_t)b * 52 + i - 1]; loss_acc += wgt * fabsf(dl); dy += wgt * sgnf(dl); }
+                if (i < 51) { const float dr = a.out[(int64_t)b * 52 + i + 1] - y; dy -= wgt * sgnf(dr); }
+            }
+            e_s[w][i] = e;
+        }
+        if (lm_on) {   // u = e W^T (136), loss = mean u^2, dL/de = 2/(B 136) u W; only this wave touches e_s[w], u_s[w]
+            __builtin_amdgcn_wave_barrier();
+            for (int k = i; k < 136; k += 64) {
+                float u = 0.f;
+                for (int jj = 0; jj < 52; ++jj) u += e_s[w][jj] * lc.landmark_w_dev[k * 52 + jj];
+                u_s[w][k] = u;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float wgt = lc.landmark_weight / (float)(a.B * 136);
+            if (i < 52) {
+                float gsum = 0.f;
+                for (int k = 0; k < 136; ++k) gsum += u_s[w][k] * lc.landmark_w_dev[k * 52 + i];
+                dy += wgt * 2.0f * gsum;
+            }
+            if (i == 0) { float q = 0.f; for (int k = 0; k < 136; ++k) q += u_s[w][k] * u_s[w][k]; loss_acc += wgt * q; }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (i < 52) {
+            if (ema_on) dal += dy * a.xp[(int64_t)b * 52 + i] * alpha * (1.0f - alpha);
+            const float df = dy * a.fac[(int64_t)b * 52 + i];
+            const float bs = a.bs[(int64_t)b * 52 + i];
+            dws += df * bs;
+            a.dz[(int64_t)b * 52 + i] = df * wsum_s[i] * bs * (1.0f - bs);
+        }
+    }
+    if (i < 52) dws_p[w][i] = dws;
+    red[w][i] = i < 52 ? loss_acc : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int ww = 0; ww < NW; ++ww)
+            for (int k = 0; k < 52; ++k) s += red[ww][k];
+        if (av_on) s += lc.perceptual_weight * 0.5f * (1.0f - av_c[0]);
+        a.loss[0] = s;
+    }
+    __syncthreads();
+    red[w][i] = i < 52 ? dal : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int ww = 0; ww < NW; ++ww)
+            for (int k = 0; k < 52; ++k) s += red[ww][k];
+        a.d_alpha[0] = s;
+        // softmax backward for both stream-weight vectors: d w_j = (1/tau) w_j (g_j - sum_k g_k w_k), g = 0.5 dwsum
+        float dws_t[52];
+        for (int k = 0; k < 52; ++k) { float t = 0.f; for (int ww = 0; ww < NW; ++ww) t += dws_p[ww][k]; dws_t[k] = t; }
+        float dm = 0.f, de = 0.f;
+        for (int k = 0; k < 52; ++k) { dm += 0.5f * dws_t[k] * wm_s[k]; de += 0.5f * dws_t[k] * we_s[k]; }
+        for (int k = 0; k < 52; ++k) {
+            a.d_melw[k] = wm_s[k] * (0.5f * dws_t[k] - dm) / a.temperature;
+            a.d_emow[k] = we_s[k] * (0.5f * dws_t[k] - de) / a.temperature;
+        }
+    }
+}
+

@@ -1,0 +1,808 @@
+// Phased training step of the dual-stream core for gfx950 (BASELINE config C3).
+//
+// Same arithmetic as km_train.hip (unfolded forward with saved activations, KoeMorphLoss tail, backward into ONE flat
+// gradient bucket), restructured for the shape the reference trains at: 8 windows per GPU.  There every product is a
+// handful of 64 x 64 tiles, so the launch-per-op chain (~70 launches over two streams) was bound by launches and by the
+// load -> LDS -> MFMA latency of each tiny kernel, not by arithmetic (round 1: 0.69 ms, 1 % of the MFMA peak).  Here the
+// step is a PROGRAM of ~19 phases; a phase is ONE launch (phase_kernel) that runs every operation whose inputs are ready
+// -- GEMM tiles, LayerNorm / softmax rows, column reductions -- side by side on different workgroups.  No side stream,
+// no events, no atomics: every reduction is a fixed-order two-stage sum, so a step is bit-reproducible and capturable.
+//
+// Critical path shortened by algebra that leaves every gradient intact:
+//   * out_proj -> mel_output_proj -> decoder[0] have nothing between them (dual_stream_attention.py:231, :248, :150), so the
+//     forward needs only H = relu(A Wf^T + bf) with Wf = W1 Wmo Wo (computed per step, beside the encoder).  O1 = A Wo^T and
+//     O2 = O1 Wmo^T are still produced -- the weight gradients dWmo = dO2^T O1, dW1 = dH^T O2 need them -- but beside the
+//     chain, not in it; likewise dA = dH Wf replaces three dependent products in the backward chain.
+//   * training-mode dropout (p = 0.1 in both nn.MultiheadAttention modules and the decoder, :106, :115, :153): masks are
+//     drawn per step by a Philox4x32-10 generator into byte buffers (or supplied by the caller: parity tests feed the
+//     masks of the reference-generated fixtures), applied in the softmax / GEMM epilogues.  With dropout the 24
+//     expression rows of a window are no longer identical (each (head, query) keeps or drops its single attention
+//     weight), so the emotion stream runs on 24 rows per window here.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <vector>
+
+#include "km_context.h"
+#include "km_device.h"
+#include "km_gemm.h"
+
+namespace km {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define KM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(KM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#include "km_gemm_dev.h"
+#include "km_train_tail.h"
+
+// ---- operations of a phase ------------------------------------------------------------------------------------
+enum OpKind : int {
+    OP_GEMM = 0, OP_ZERO, OP_MASKGEN, OP_PACKX, OP_LN_FWD, OP_LN_BWD, OP_LN_PGRAD, OP_SOFTMAX_DROP, OP_SOFTMAX_BWD, OP_ROWDOT,
+    OP_RELU_OUTER, OP_COLSUM, OP_REDUCE, OP_EMO_EXPAND, OP_EMO_REDUCE
+};
+
+struct ElemArgs {
+    const float *p0, *p1, *p2, *p3, *p4;
+    float *q0, *q1, *q2;
+    const unsigned char* mask;
+    unsigned char* mask_out;
+    int64_t n0, n1;
+    int i0, i1, i2, i3;
+    float f0;
+    unsigned u0, u1;
+};
+
+struct Op {
+    int kind;
+    int gx, gy;            // OP_GEMM: tiles along N and M (blocks = gx * gy * batch)
+    union {
+        GemmArgs g;
+        ElemArgs e;
+    };
+};
+
+constexpr int kMaxOps = 12;
+struct Phase {
+    int n_ops;
+    int block_end[kMaxOps];
+    Op ops[kMaxOps];
+};
+
+// Philox4x32-10 (Salmon et al. 2011): counter (c0..c3), key (k0, k1) -> 4 x 32 random bits
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ int drop_dz_index(int map, int64_t r, int& b_out) {
+    // row of an activation buffer -> (window, blendshape index): map 1 = (window, mouth slot), 2 = (window, expression slot)
+    if (map == 1) { const int64_t b = r / 28; const int q = (int)(r - b * 28); b_out = (int)b; return q < 27 ? 14 + q : 51; }
+    const int64_t b = r / 24; const int q = (int)(r - b * 24); b_out = (int)b; return q < 14 ? q : q + 27;
+}
+
+__device__ __forceinline__ void op_elem(const Op& op, int vb, float* smem) {
+    const ElemArgs& a = op.e;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    switch (op.kind) {
+    case OP_ZERO: {
+        const int64_t i = ((int64_t)vb * 256 + tid) * 4;
+        if (i + 3 < a.n0) *reinterpret_cast<float4*>(a.q0 + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        else for (int64_t k = i; k < a.n0; ++k) a.q0[k] = 0.f;
+        break;
+    }
+    case OP_MASKGEN: {      // mask_out[n0] bytes: keep (1) with probability 1 - p; counter = (byte index / 4, region, step)
+        const int64_t i4 = (int64_t)vb * 256 + tid;
+        if (i4 * 4 >= a.n0) break;
+        const unsigned step = a.p0 ? (unsigned)reinterpret_cast<const int*>(a.p0)[0] : 0u;
+        unsigned r[4];
+        philox4x32_10((unsigned)i4, (unsigned)(i4 >> 32), (unsigned)a.i0, step, a.u0, a.u1, r);
+        const unsigned thr = (unsigned)a.i1;                   // p * 2^32: keep <=> r >= thr
+        unsigned char k4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) k4[k] = r[k] >= thr ? 1 : 0;
+        if (i4 * 4 + 3 < a.n0) *reinterpret_cast<uchar4*>(a.mask_out + i4 * 4) = make_uchar4(k4[0], k4[1], k4[2], k4[3]);
+        else for (int k = 0; i4 * 4 + k < a.n0; ++k) a.mask_out[i4 * 4 + k] = k4[k];
+        break;
+    }
+    case OP_PACKX: {        // xp (B, KP, NK) <- mel (B, t_in, NK) rows [0, tv), zeros to T, 3 short rows, zeros to KP
+        const int64_t i = (int64_t)vb * 256 + tid;           // one float4 each
+        const int nk4 = a.i0 / 4, KP = a.i1, T = a.i2, t_in = a.i3;
+        if (i >= a.n0 * KP * nk4) break;
+        const int64_t row = i / nk4; const int c4 = (int)(i - row * nk4);
+        const int64_t b = row / KP; const int t = (int)(row - b * KP);
+        const int tv = t_in < T ? t_in : T;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < tv) v = reinterpret_cast<const float4*>(a.p0 + (b * t_in + t) * a.i0)[c4];
+        else if (t >= T && t < T + 3) v = reinterpret_cast<const float4*>(a.p1 + (b * 3 + (t - T)) * a.i0)[c4];
+        reinterpret_cast<float4*>(a.q0)[i] = v;
+        break;
+    }
+    case OP_LN_FWD: {       // y = LayerNorm(x), statistics saved; one wave per row
+        const int64_t row = (int64_t)vb * 4 + wv;
+        const int d = a.i0;
+        if (row >= a.n0) break;
+        const float* p = a.p0 + row * d;
+        float s = 0.f;
+        for (int i = lane; i < d; i += 64) s += p[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / d;
+        float v = 0.f;
+        for (int i = lane; i < d; i += 64) { const float t = p[i] - mean; v += t * t; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        const float rstd = 1.0f / sqrtf(v / d + 1e-5f);
+        for (int i = lane; i < d; i += 64) a.q0[row * d + i] = (p[i] - mean) * rstd * a.p1[i] + a.p2[i];
+        if (lane == 0) { a.q1[row] = mean; a.q2[row] = rstd; }
+        break;
+    }
+    case OP_LN_BWD: {       // dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)), dxhat = dy gamma; out of place
+        const int64_t row = (int64_t)vb * 4 + wv;
+        const int d = a.i0;
+        if (row >= a.n0) break;
+        const float mu = a.p3[row], rs = a.p4[row];
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = lane; i < d; i += 64) {
+            const float xh = (a.p1[row * d + i] - mu) * rs, dxh = a.p0[row * d + i] * a.p2[i];
+            s1 += dxh; s2 += dxh * xh;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        s1 /= d; s2 /= d;
+        for (int i = lane; i < d; i += 64) {
+            const float xh = (a.p1[row * d + i] - mu) * rs, dxh = a.p0[row * d + i] * a.p2[i];
+            a.q0[row * d + i] = rs * (dxh - s1 - xh * s2);
+        }
+        break;
+    }
+    case OP_LN_PGRAD: {     // dgamma[c] = sum_rows dy xhat, dbeta[c] = sum_rows dy; vb = split * (d/64) + column block
+        float* sg = smem; float* sb = smem + 256;
+        const int d = a.i0, nbx = (d + 63) / 64;
+        const int y = vb / nbx, bx = vb - y * nbx;
+        const int col = bx * 64 + lane;
+        const int64_t r0 = (int64_t)y * a.n1, r1 = (r0 + a.n1) < a.n0 ? (r0 + a.n1) : a.n0;
+        float ag = 0.f, ab = 0.f;
+        if (col < d)
+            for (int64_t r = r0 + wv; r < r1; r += 4) {
+                const float g = a.p0[r * d + col];
+                ag += g * (a.p1[r * d + col] - a.p2[r]) * a.p3[r];
+                ab += g;
+            }
+        sg[tid] = ag; sb[tid] = ab;
+        __syncthreads();
+        if (wv == 0 && col < d) {
+            a.q0[(int64_t)y * d + col] = sg[lane] + sg[64 + lane] + sg[128 + lane] + sg[192 + lane];
+            a.q1[(int64_t)y * d + col] = sb[lane] + sb[64 + lane] + sb[128 + lane] + sb[192 + lane];
+        }
+        __syncthreads();
+        break;
+    }
+    case OP_SOFTMAX_DROP: { // P = softmax(S) (saved), Pd = P * keep / (1 - p); rows of width w <= 128, one wave per row
+        const int64_t row = (int64_t)vb * 4 + wv;
+        const int w = a.i0;
+        if (row >= a.n0) break;
+        const float* s = a.p0 + row * w;
+        const float v0 = lane < w ? s[lane] : -INFINITY, v1 = lane + 64 < w ? s[lane + 64] : -INFINITY;
+        float m = fmaxf(v0, v1);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        const float e0 = lane < w ? expf(v0 - m) : 0.f, e1 = lane + 64 < w ? expf(v1 - m) : 0.f;
+        float sum = e0 + e1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float p0 = e0 / sum, p1 = e1 / sum;
+        if (lane < w) {
+            a.q0[row * w + lane] = p0;
+            a.q1[row * w + lane] = a.mask ? (a.mask[row * w + lane] ? p0 * a.f0 : 0.f) : p0;
+        }
+        if (lane + 64 < w) {
+            a.q0[row * w + lane + 64] = p1;
+            a.q1[row * w + lane + 64] = a.mask ? (a.mask[row * w + lane + 64] ? p1 * a.f0 : 0.f) : p1;
+        }
+        break;
+    }
+    case OP_SOFTMAX_BWD: {  // dP = dPd keep / (1 - p); dS = P (dP - sum(dP P)); out of place
+        const int64_t row = (int64_t)vb * 4 + wv;
+        const int w = a.i0;
+        if (row >= a.n0) break;
+        auto g_at = [&](int k) { const float g = a.p0[row * w + k]; return a.mask ? (a.mask[row * w + k] ? g * a.f0 : 0.f) : g; };
+        const float p0 = lane < w ? a.p1[row * w + lane] : 0.f, p1 = lane + 64 < w ? a.p1[row * w + lane + 64] : 0.f;
+        const float g0 = lane < w ? g_at(lane) : 0.f, g1 = lane + 64 < w ? g_at(lane + 64) : 0.f;
+        float s = g0 * p0 + g1 * p1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane < w) a.q0[row * w + lane] = p0 * (g0 - s);
+        if (lane + 64 < w) a.q0[row * w + lane + 64] = p1 * (g1 - s);
+        break;
+    }
+    case OP_ROWDOT: {       // z[row] = h[row] . w + b
+        const int64_t row = (int64_t)vb * 4 + wv;
+        const int n = a.i0;
+        if (row >= a.n0) break;
+        float s = 0.f;
+        for (int i = lane; i < n; i += 64) s = fmaf(a.p0[row * n + i], a.p1[i], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) a.q0[row] = s + a.p2[0];
+        break;
+    }
+    case OP_RELU_OUTER: {   // dHpre[r][m] = dz(r) w2[m] scale [H[r][m] > 0]; H is post-ReLU, post-dropout (H > 0 <=> kept and active)
+        const int64_t i = (int64_t)vb * 256 + tid;
+        const int n = a.i0;
+        if (i >= a.n0 * n) break;
+        const int64_t r = i / n; const int m = (int)(i - r * n);
+        int b;
+        const int bi = drop_dz_index(a.i1, r, b);
+        a.q0[i] = a.p1[i] > 0.f ? a.p0[(int64_t)b * 52 + bi] * a.p2[m] * a.f0 : 0.f;
+        break;
+    }
+    case OP_COLSUM: {       // out[y][c] = sum over this split's rows of (weight(r) *) m[r * rs + c]; weight = dz of the row (i3 = map) or 1
+        float* sh = smem;
+        const int n = a.i0, nbx = (n + 63) / 64;
+        const int y = vb / nbx, bx = vb - y * nbx;
+        const int col = bx * 64 + lane;
+        const int64_t chunk = (a.n0 + a.i2 - 1) / a.i2;
+        const int64_t r0 = (int64_t)y * chunk, r1 = (r0 + chunk) < a.n0 ? (r0 + chunk) : a.n0;
+        float acc = 0.f;
+        if (col < n)
+            for (int64_t r = r0 + wv; r < r1; r += 4) {
+                float wgt = 1.f;
+                if (a.i3) { int b; const int bi = drop_dz_index(a.i3, r, b); wgt = a.p1[(int64_t)b * 52 + bi]; }
+                acc = fmaf(wgt, a.p0[r * a.n1 + col], acc);
+            }
+        sh[tid] = acc;
+        __syncthreads();
+        if (wv == 0 && col < n) {
+            const float s = sh[lane] + sh[64 + lane] + sh[128 + lane] + sh[192 + lane];
+            float* o = a.q0 + (int64_t)y * n + col;
+            *o = a.i1 ? *o + s : s;
+        }
+        __syncthreads();
+        break;
+    }
+    case OP_REDUCE: {       // out[c] (+)= sum_y part[y][c], fixed order
+        const int64_t c0 = (int64_t)vb * 256 + tid;
+        if (c0 >= a.n0) break;
+        float s = 0.f;
+        for (int y = 0; y < a.i0; ++y) s += a.p0[(int64_t)y * a.n1 + c0];
+        a.q0[c0] = a.i1 ? a.q0[c0] + s : s;
+        break;
+    }
+    case OP_EMO_EXPAND: {   // Ae[(b, q), c] = Ve[b, c] * keep[b, c / hd, q] / (1 - p): the one-key attention of the emotion stream
+        const int64_t i = (int64_t)vb * 256 + tid;
+        const int d = a.i0, hd = a.i1, H = d / hd;
+        if (i >= a.n0 * 24 * d) break;
+        const int64_t r = i / d; const int cidx = (int)(i - r * d);
+        const int64_t b = r / 24; const int q = (int)(r - b * 24);
+        const float v = a.p0[b * d + cidx];
+        a.q0[i] = a.mask ? (a.mask[(b * H + cidx / hd) * 24 + q] ? v * a.f0 : 0.f) : v;
+        break;
+    }
+    case OP_EMO_REDUCE: {   // dVe[b, c] = sum_q dAe[(b, q), c] * keep / (1 - p)
+        const int64_t i = (int64_t)vb * 256 + tid;
+        const int d = a.i0, hd = a.i1, H = d / hd;
+        if (i >= a.n0 * d) break;
+        const int64_t b = i / d; const int cidx = (int)(i - b * d);
+        float s = 0.f;
+        for (int q = 0; q < 24; ++q) {
+            const float g = a.p0[(b * 24 + q) * d + cidx];
+            s += a.mask ? (a.mask[(b * H + cidx / hd) * 24 + q] ? g * a.f0 : 0.f) : g;
+        }
+        a.q0[i] = s;
+        break;
+    }
+    default: break;
+    }
+}
+
+__global__ __launch_bounds__(256) void phase_kernel(Phase p) {
+    __shared__ __attribute__((aligned(16))) float smem[ggd::LDS_FLOATS];
+    const int vb = blockIdx.x;
+    int i = 0;
+    while (i + 1 < p.n_ops && vb >= p.block_end[i]) ++i;            // workgroup-uniform
+    const int local = vb - (i ? p.block_end[i - 1] : 0);
+    const Op& op = p.ops[i];
+    if (op.kind == OP_GEMM) {
+        const int per = op.gx * op.gy;
+        const int bz = local / per, t = local - bz * per;
+        gemm_tile_dev<4>(op.g, t % op.gx, t / op.gx, bz, smem);
+    } else {
+        op_elem(op, local, smem);
+    }
+}
+
+__global__ __launch_bounds__(256) void trainp_tail_kernel(TailArgs a, float* d_b2, int* drop_ctr) {
+    train_tail_dev<4>(a);
+    // decoder output bias: sum of every logit gradient, in a fixed order (row_grads_kernel of the chain)
+    __shared__ float red[256];
+    __syncthreads();
+    float s = 0.f;
+    for (int i = threadIdx.x; i < a.B * 52; i += 256) s += a.dz[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < 256; ++k) t += red[k];
+        d_b2[0] = t;
+        if (drop_ctr) drop_ctr[0] += 1;           // the next step draws fresh dropout masks
+    }
+}
+
+// ---- host: building and launching the program ----------------------------------------------------------------
+struct Program {
+    std::vector<Phase> phases;
+    Phase cur{};
+    int blocks = 0;
+    int rc = KM_OK;
+    void add(const Op& op, int nblocks) {
+        if (nblocks <= 0) return;
+        if (cur.n_ops >= kMaxOps) { rc = fail(KM_ERR_UNSUPPORTED, "training program: more than %d operations in one phase", kMaxOps); return; }
+        cur.ops[cur.n_ops] = op;
+        blocks += nblocks;
+        cur.block_end[cur.n_ops] = blocks;
+        ++cur.n_ops;
+    }
+    void gemm(const GemmArgs& g, int batch) {
+        Op op{};
+        op.kind = OP_GEMM; op.g = g;
+        op.gx = (g.N + 63) / 64; op.gy = (g.M + 63) / 64;
+        add(op, op.gx * op.gy * batch);
+    }
+    void elem(int kind, const ElemArgs& e, int64_t nblocks) {
+        Op op{};
+        op.kind = kind; op.e = e;
+        add(op, (int)nblocks);
+    }
+    int end_phase(hipStream_t st) {
+        if (rc) return rc;
+        if (cur.n_ops > 0) {
+            hipLaunchKernelGGL(phase_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cur);
+            HIP_TRY(hipGetLastError());
+        }
+        cur = Phase{};
+        blocks = 0;
+        return KM_OK;
+    }
+};
+
+static GemmArgs G(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float* C, int64_t c_rs,
+                  int64_t M, int64_t N, int64_t K) {
+    GemmArgs g{};
+    g.alpha = 1.f; g.batch2 = 1; g.kb_count = 1;
+    g.A = A; g.a_rs = a_rs; g.a_cs = a_cs; g.B = B; g.b_rs = b_rs; g.b_cs = b_cs; g.C = C; g.c_rs = c_rs;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    return g;
+}
+// C (rows x N) = A (rows x K) W^T (+ bias), W stored (N x K) like nn.Linear
+static GemmArgs NT(const float* A, int64_t a_rs, const float* W, int64_t K, float* C, int64_t c_rs, int64_t rows, int64_t N,
+                   const float* bias, int relu) {
+    GemmArgs g = G(A, a_rs, 1, W, 1, K, C, c_rs, rows, N, K);
+    g.bias = bias; g.bias_mode = bias ? 1 : 0; g.relu = relu;
+    return g;
+}
+// C (rows x N) = A (rows x K) W, W stored (K x N)
+static GemmArgs NN(const float* A, int64_t a_rs, const float* W, int64_t w_rs, float* C, int64_t c_rs, int64_t rows, int64_t N, int64_t K) {
+    return G(A, a_rs, 1, W, w_rs, 1, C, c_rs, rows, N, K);
+}
+// C (M x N) = A^T B with A (rows x M), B (rows x N)
+static GemmArgs TN(const float* A, int64_t a_rs, const float* B, int64_t b_rs, float* C, int64_t c_rs, int64_t M, int64_t N, int64_t rows) {
+    return G(A, 1, a_rs, B, b_rs, 1, C, c_rs, M, N, rows);
+}
+
+static int split_rows(int64_t rows) {
+    int S = (int)((rows + 511) / 512);
+    return S < 1 ? 1 : (S > 32 ? 32 : S);
+}
+
+int64_t trainp_mask_bytes(Context* c) { return (int64_t)c->H * 28 * c->NK + (int64_t)c->H * 24 + 52 * (int64_t)c->DH; }
+
+// floats per window + a fixed part (returned through *fixed)
+int64_t trainp_act_floats(Context* c, int64_t* fixed) {
+    const int64_t d = c->d, H = c->H, NKk = c->NK, DH = c->DH, KP = (c->KT + 15) / 16 * 16;
+    const int64_t per = KP * NKk + 2 * NKk * d + 2 * NKk + 2 * NKk * d /* KV */ + 3 * H * 28 * NKk /* P, Pd, dP */ + H * 28 * NKk /* dS */ +
+                        3 * 28 * d + 28 * DH + 3 * 24 * d + 24 * DH + 64 /* z */ + (28 + 24) * DH /* dH */ + 6 * (28 + 24) * d / 2 /* dA dO2 dO1 x2 */ +
+                        2 * NKk * d /* dKV */ + 2 * NKk * d /* dY dY0 */ + 8 * d + 8 + 5 * 52 + 4 + d * c->KT /* dWce partial */ + 28 * d /* dQ partial */ +
+                        (trainp_mask_bytes(c) + 3) / 4 + 64;
+    if (fixed) *fixed = 2 * 28 * d + 2 * d * d + 2 * DH * d + 2 * d + 2 * DH + 64 /* folds */ + 32 * (4 * d + 2 * DH + 4 * d) /* split partials */ + 1024;
+    return per;
+}
+
+struct MaskSet { unsigned char *mel, *emo, *dec; };
+static MaskSet mask_ptrs(Context* c, int64_t B) {
+    unsigned char* base = reinterpret_cast<unsigned char*>(c->trp_masks);
+    MaskSet m;
+    m.mel = base;
+    m.emo = m.mel + (size_t)c->tr_windows * c->H * 28 * c->NK;
+    m.dec = m.emo + (((size_t)c->tr_windows * c->H * 24 + 15) / 16) * 16;
+    (void)B;
+    return m;
+}
+
+int trainp_mask_sizes(Context* c, int64_t B, int64_t* mel, int64_t* emo, int64_t* dec) {
+    *mel = B * c->H * 28 * c->NK; *emo = B * c->H * 24; *dec = B * 52 * c->DH;
+    return KM_OK;
+}
+
+int trainp_copy_masks(Context* c, int64_t B, unsigned char* mel, unsigned char* emo, unsigned char* dec, int to_device, void* stream) {
+    int64_t nm, ne, nd;
+    trainp_mask_sizes(c, B, &nm, &ne, &nd);
+    const MaskSet m = mask_ptrs(c, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (to_device) {
+        HIP_TRY(hipMemcpyAsync(m.mel, mel, (size_t)nm, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(m.emo, emo, (size_t)ne, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(m.dec, dec, (size_t)nd, hipMemcpyHostToDevice, st));
+    } else {
+        HIP_TRY(hipMemcpyAsync(mel, m.mel, (size_t)nm, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(emo, m.emo, (size_t)ne, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(dec, m.dec, (size_t)nd, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return KM_OK;
+}
+
+int64_t trainp_mask_alloc_bytes(Context* c) {
+    return (int64_t)c->tr_windows * (c->H * 28 * c->NK + c->H * 24 + 52 * c->DH) + 64;
+}
+
+#define RUN(expr) do { if (int rc_ = (expr)) return rc_; } while (0)
+
+// xp_dev: packed encoder input (B, KP, NK) when the caller (the from-audio step) produced it, else null and it is packed
+// here from mel / mel_short.
+int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short, const float* xp_dev,
+                                  const float* emo, const float* target, float mse_w, float l1_w, float* flat_grad, float* loss_dev,
+                                  float* out_dev, float* ema_state, int ema_first, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t d = c->d, H = c->H, hd = c->hd, T = c->T, KT = c->KT, DH = c->DH, NKk = c->NK, ED = c->ED;
+    const int64_t KP = (KT + 15) / 16 * 16;
+    const int64_t R = B * NKk, Rm = B * 28, Re = B * 24;
+    if (NKk % 4 != 0 || NKk > 128) return fail(KM_ERR_UNSUPPORTED, "phased training step needs num_mel_channels <= 128, a multiple of 4");
+    c->tr_alpha_live = ema_state != nullptr && !ema_first;
+    auto P = [&](const char* k) -> const float* { return c->tr_params + c->tr_offset.at(k); };
+    auto Gd = [&](const char* k) -> float* { return flat_grad + c->tr_offset.at(k); };
+    float* w = c->trp_act;
+    auto take = [&](int64_t n) { float* p = w; w += (n + 3) / 4 * 4; return p; };
+    float* xp = take(c->tr_windows * KP * NKk);            // first: km_train_step_audio writes the packed input here
+    // fixed part
+    float* Qb = take(28 * d); float* dQb = take(28 * d);
+    float* T1m = take(d * d); float* T1e = take(d * d); float* Wfm = take(DH * d); float* Wfe = take(DH * d);
+    float* t1m = take(d); float* t1e = take(d); float* bfm = take(DH); float* bfe = take(DH);
+    float* part_lnm = take(32 * 2 * d); float* part_lne = take(32 * 2 * d);
+    float* part_a = take(32 * 2 * d); float* part_b = take(32 * 2 * d); float* part_c = take(32 * 2 * d);
+    // per-window part
+    float* Y0 = take(R * d); float* Y = take(R * d); float* mu = take(R); float* rs = take(R);
+    float* KV = take(R * 2 * d);
+    float* Pm = take(B * H * 28 * NKk); float* Pd = take(B * H * 28 * NKk); float* dP = take(B * H * 28 * NKk); float* dS = take(B * H * 28 * NKk);
+    float* A = take(Rm * d); float* O1 = take(Rm * d); float* O2 = take(Rm * d); float* H1 = take(Rm * DH);
+    float* Ae = take(Re * d); float* Oe1 = take(Re * d); float* Oe2 = take(Re * d); float* He = take(Re * DH);
+    float* zrows = take(Rm + Re);
+    float* dH1 = take(Rm * DH); float* dHe = take(Re * DH);
+    float* dA = take(Rm * d); float* dO2 = take(Rm * d); float* dO1 = take(Rm * d);
+    float* dAe = take(Re * d); float* dOe2 = take(Re * d); float* dOe1 = take(Re * d);
+    float* dKV = take(R * 2 * d); float* dY = take(R * d); float* dY0 = take(R * d);
+    float* E0 = take(B * d); float* E = take(B * d); float* Ve = take(B * d); float* dVe = take(B * d); float* dE = take(B * d); float* dE0 = take(B * d);
+    float* emu = take(B); float* ers = take(B);
+    float* bs = take(B * 52); float* outb = take(B * 52); float* dz = take(B * 52); float* tfac = take(B * 52); float* txp = take(B * 52);
+    float* dWce_part = take(B * d * KT);
+    float* dQ_part = take(B * 28 * d);
+    if ((w - c->trp_act) > c->trp_act_floats) return fail(KM_ERR_WORKSPACE, "phased training workspace too small (internal)");
+
+    const float p_drop = c->tr_dropout_p;
+    const bool drop = p_drop > 0.f;
+    const float keep_scale = drop ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const MaskSet ms = mask_ptrs(c, B);
+    const unsigned char* m_mel = drop ? ms.mel : nullptr;
+    const unsigned char* m_emo = drop ? ms.emo : nullptr;
+    const unsigned char* m_dec = drop ? ms.dec : nullptr;
+
+    const float* Wce = P("mel_channel_encoder.weight");
+    const float* inw = P("mel_attention.in_proj_weight"); const float* inb = P("mel_attention.in_proj_bias");
+    const float* einw = P("emotion_attention.in_proj_weight"); const float* einb = P("emotion_attention.in_proj_bias");
+    const float* Wo = P("mel_attention.out_proj.weight"); const float* bo = P("mel_attention.out_proj.bias");
+    const float* Wmo = P("mel_output_proj.weight"); const float* bmo = P("mel_output_proj.bias");
+    const float* Woe = P("emotion_attention.out_proj.weight"); const float* boe = P("emotion_attention.out_proj.bias");
+    const float* Weo = P("emotion_output_proj.weight"); const float* beo = P("emotion_output_proj.bias");
+    const float* W1 = P("blendshape_decoder.0.weight"); const float* b1 = P("blendshape_decoder.0.bias");
+    const float* w2 = P("blendshape_decoder.3.weight"); const float* b2 = P("blendshape_decoder.3.bias");
+    const float scale = 1.0f / std::sqrt((float)hd);
+    float* gin_w = Gd("mel_attention.in_proj_weight"); float* gin_b = Gd("mel_attention.in_proj_bias");
+    float* gein_w = Gd("emotion_attention.in_proj_weight"); float* gein_b = Gd("emotion_attention.in_proj_bias");
+
+    Program pg;
+    auto blocks4 = [](int64_t rows) { return (rows + 3) / 4; };            // one wave per row, 4 rows per block
+    auto blocks256 = [](int64_t n) { return (n + 255) / 256; };
+    auto colsum = [&](const float* m, int64_t rows, int64_t rs_, int n, float* out, int accumulate, int map, const float* dzp) {
+        ElemArgs e{};                                                     // single split: rows are few (<= 512 per split by construction below)
+        e.p0 = m; e.p1 = dzp; e.n0 = rows; e.n1 = rs_; e.i0 = n; e.i1 = accumulate; e.i2 = 1; e.i3 = map; e.q0 = out;
+        pg.elem(OP_COLSUM, e, (n + 63) / 64);
+    };
+    // column sum over many rows: split partials now, the fixed-order sum in a later phase (returns the split count)
+    auto colsum_split = [&](const float* m, int64_t rows, int64_t rs_, int n, float* part) -> int {
+        const int S = split_rows(rows);
+        ElemArgs e{};
+        e.p0 = m; e.n0 = rows; e.n1 = rs_; e.i0 = n; e.i1 = 0; e.i2 = S; e.i3 = 0; e.q0 = part;
+        pg.elem(OP_COLSUM, e, (int64_t)S * ((n + 63) / 64));
+        return S;
+    };
+    auto reduce = [&](const float* part, int S, int64_t n, int64_t stride, float* out, int accumulate) {
+        ElemArgs e{};
+        e.p0 = part; e.i0 = S; e.n0 = n; e.n1 = stride; e.q0 = out; e.i1 = accumulate;
+        pg.elem(OP_REDUCE, e, blocks256(n));
+    };
+
+    // ================= P0: clean bucket, masks, packed input, input-independent products =================
+    {
+        ElemArgs e{};
+        e.q0 = flat_grad; e.n0 = c->tr_nparams;
+        pg.elem(OP_ZERO, e, (c->tr_nparams + 1023) / 1024);
+    }
+    if (drop && c->tr_dropout_mode == 0) {
+        int64_t nm, ne, nd;
+        trainp_mask_sizes(c, B, &nm, &ne, &nd);
+        const unsigned thr = (unsigned)std::llround((double)p_drop * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (double)p_drop * 4294967296.0);
+        unsigned char* regions[3] = {ms.mel, ms.emo, ms.dec};
+        const int64_t sizes[3] = {nm, ne, nd};
+        for (int r = 0; r < 3; ++r) {
+            ElemArgs e{};
+            e.mask_out = regions[r]; e.n0 = sizes[r]; e.i0 = r; e.i1 = (int)thr; e.u0 = (unsigned)c->tr_dropout_seed;
+            e.u1 = (unsigned)(c->tr_dropout_seed >> 32); e.p0 = reinterpret_cast<const float*>(c->trp_drop_ctr);
+            pg.elem(OP_MASKGEN, e, (sizes[r] + 1023) / 1024);
+        }
+    }
+    if (!xp_dev) {
+        ElemArgs e{};
+        e.p0 = mel; e.p1 = mel_short; e.q0 = xp; e.n0 = B; e.i0 = (int)NKk; e.i1 = (int)KP; e.i2 = (int)T; e.i3 = (int)T_in;
+        pg.elem(OP_PACKX, e, blocks256(B * KP * (NKk / 4)));
+    }
+    const float* X = xp_dev ? xp_dev : xp;
+    pg.gemm(NT(P("mouth_queries"), d, inw, d, Qb, d, 28, d, inb, 0), 1);                                  // Q = mq Wq^T + bq
+    pg.gemm(NN(Wmo, d, Wo, d, T1m, d, d, d, d), 1);                                                        // T1 = Wmo Wo
+    pg.gemm(NN(Weo, d, Woe, d, T1e, d, d, d, d), 1);
+    { GemmArgs g = G(Wmo, d, 1, bo, 1, 0, t1m, 1, d, 1, d); g.bias = bmo; g.bias_mode = 2; pg.gemm(g, 1); }   // t1 = Wmo bo + bmo
+    { GemmArgs g = G(Weo, d, 1, boe, 1, 0, t1e, 1, d, 1, d); g.bias = beo; g.bias_mode = 2; pg.gemm(g, 1); }
+    pg.gemm(NT(emo, ED, P("emotion_encoder.weight"), ED, E0, d, B, d, P("emotion_encoder.bias"), 0), 1);
+    RUN(pg.end_phase(st));
+    // ================= P1: channel encoder; folds; emotion LayerNorm =================
+    {   // Y0[b] (NK x d) = X_b^T Wce^T + b over the KT packed rows
+        GemmArgs g = G(X, 1, NKk, Wce, 1, KT, Y0, d, NKk, d, KT);
+        g.a_bs1 = KP * NKk; g.c_bs1 = NKk * d; g.bias = P("mel_channel_encoder.bias"); g.bias_mode = 1;
+        pg.gemm(g, (int)B);
+    }
+    pg.gemm(NN(W1, d, T1m, d, Wfm, d, DH, d, d), 1);                                                        // Wf = W1 T1
+    pg.gemm(NN(W1, d, T1e, d, Wfe, d, DH, d, d), 1);
+    { GemmArgs g = G(W1, d, 1, t1m, 1, 0, bfm, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }     // bf = W1 t1 + b1
+    { GemmArgs g = G(W1, d, 1, t1e, 1, 0, bfe, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }
+    {
+        ElemArgs e{};
+        e.p0 = E0; e.q0 = E; e.n0 = B; e.i0 = (int)d; e.p1 = P("emotion_norm.weight"); e.p2 = P("emotion_norm.bias"); e.q1 = emu; e.q2 = ers;
+        pg.elem(OP_LN_FWD, e, blocks4(B));
+    }
+    RUN(pg.end_phase(st));
+    // ================= P2: LayerNorm; emotion value projection =================
+    {
+        ElemArgs e{};
+        e.p0 = Y0; e.q0 = Y; e.n0 = R; e.i0 = (int)d; e.p1 = P("mel_norm.weight"); e.p2 = P("mel_norm.bias"); e.q1 = mu; e.q2 = rs;
+        pg.elem(OP_LN_FWD, e, blocks4(R));
+    }
+    pg.gemm(NT(E, d, einw + 2 * d * d, d, Ve, d, B, d, einb + 2 * d, 0), 1);
+    RUN(pg.end_phase(st));
+    // ================= P3: [K | V]; emotion attention (one key: weight 1, dropped or kept per head and query) =================
+    pg.gemm(NT(Y, d, inw + d * d, d, KV, 2 * d, R, 2 * d, inb + d, 0), 1);
+    {
+        ElemArgs e{};
+        e.p0 = Ve; e.q0 = Ae; e.n0 = B; e.i0 = (int)d; e.i1 = (int)hd; e.mask = m_emo; e.f0 = keep_scale;
+        pg.elem(OP_EMO_EXPAND, e, blocks256(Re * d));
+    }
+    RUN(pg.end_phase(st));
+    // ================= P4: scores; emotion rows through the folded decoder input + their out_proj =================
+    {
+        GemmArgs g = G(Qb, d, 1, KV, 1, 2 * d, Pm, NKk, 28, NKk, hd);
+        g.alpha = scale; g.batch2 = (int)H; g.a_bs2 = hd; g.b_bs1 = NKk * 2 * d; g.b_bs2 = hd;
+        g.c_bs1 = H * 28 * NKk; g.c_bs2 = 28 * NKk;
+        pg.gemm(g, (int)(B * H));
+    }
+    { GemmArgs g = NT(Ae, d, Wfe, d, He, DH, Re, DH, bfe, 1); g.drop = m_dec; g.drop_scale = keep_scale; g.drop_map = 2; pg.gemm(g, 1); }
+    pg.gemm(NT(Ae, d, Woe, d, Oe1, d, Re, d, boe, 0), 1);
+    RUN(pg.end_phase(st));
+    // ================= P5: softmax + attention dropout; emotion logits; Oe2 =================
+    {
+        ElemArgs e{};
+        e.p0 = Pm; e.q0 = Pm; e.q1 = Pd; e.n0 = B * H * 28; e.i0 = (int)NKk; e.mask = m_mel; e.f0 = keep_scale;
+        pg.elem(OP_SOFTMAX_DROP, e, blocks4(B * H * 28));
+    }
+    {
+        ElemArgs e{};
+        e.p0 = He; e.p1 = w2; e.p2 = b2; e.q0 = zrows + Rm; e.n0 = Re; e.i0 = (int)DH;
+        pg.elem(OP_ROWDOT, e, blocks4(Re));
+    }
+    pg.gemm(NT(Oe1, d, Weo, d, Oe2, d, Re, d, beo, 0), 1);
+    RUN(pg.end_phase(st));
+    // ================= P6: A[b][:, h] = Pd V_h =================
+    {
+        GemmArgs g = G(Pd, NKk, 1, KV + d, 2 * d, 1, A, d, 28, hd, NKk);
+        g.batch2 = (int)H; g.a_bs1 = H * 28 * NKk; g.a_bs2 = 28 * NKk; g.b_bs1 = NKk * 2 * d; g.b_bs2 = hd;
+        g.c_bs1 = 28 * d; g.c_bs2 = hd;
+        pg.gemm(g, (int)(B * H));
+    }
+    RUN(pg.end_phase(st));
+    // ================= P7: decoder hidden through the fold (+ ReLU + dropout); O1 beside it =================
+    { GemmArgs g = NT(A, d, Wfm, d, H1, DH, Rm, DH, bfm, 1); g.drop = m_dec; g.drop_scale = keep_scale; g.drop_map = 1; pg.gemm(g, 1); }
+    pg.gemm(NT(A, d, Wo, d, O1, d, Rm, d, bo, 0), 1);
+    RUN(pg.end_phase(st));
+    // ================= P8: mouth logits; O2 =================
+    {
+        ElemArgs e{};
+        e.p0 = H1; e.p1 = w2; e.p2 = b2; e.q0 = zrows; e.n0 = Rm; e.i0 = (int)DH;
+        pg.elem(OP_ROWDOT, e, blocks4(Rm));
+    }
+    pg.gemm(NT(O1, d, Wmo, d, O2, d, Rm, d, bmo, 0), 1);
+    RUN(pg.end_phase(st));
+    // ================= P9: loss tail =================
+    {
+        TailArgs t{};
+        t.zrows = zrows; t.h1 = H1; t.he = He; t.w2 = w2; t.b2 = b2;
+        t.mel_w = P("mel_weights"); t.emo_w = P("emotion_weights"); t.temperature = c->cfg.temperature; t.target = target;
+        t.bs = bs; t.out = outb; t.dz = dz; t.ema_state = ema_state; t.ema_first = ema_first; t.alpha_p = P("smoothing_alpha");
+        t.mse_w = mse_w; t.l1_w = l1_w; t.lc = c->tr_loss_cfg; t.fac = tfac; t.xp = txp; t.loss = loss_dev;
+        t.d_melw = Gd("mel_weights"); t.d_emow = Gd("emotion_weights"); t.d_alpha = Gd("smoothing_alpha");
+        t.B = (int)B; t.DH = (int)DH; t.expr_rows = 24; t.audio_energy = c->tr_loss_cfg.audio_energy_dev;
+        hipLaunchKernelGGL(trainp_tail_kernel, dim3(1), dim3(256), 0, st, t, Gd("blendshape_decoder.3.bias"),
+                           (drop && c->tr_dropout_mode == 0) ? c->trp_drop_ctr : nullptr);
+        HIP_TRY(hipGetLastError());
+        if (out_dev) HIP_TRY(hipMemcpyAsync(out_dev, outb, (size_t)B * 52 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    // ================= P10: decoder output layer backward =================
+    {
+        ElemArgs e{};
+        e.p0 = dz; e.p1 = H1; e.p2 = w2; e.q0 = dH1; e.n0 = Rm; e.i0 = (int)DH; e.i1 = 1; e.f0 = keep_scale;
+        pg.elem(OP_RELU_OUTER, e, blocks256(Rm * DH));
+        e.p1 = He; e.q0 = dHe; e.n0 = Re; e.i1 = 2;
+        pg.elem(OP_RELU_OUTER, e, blocks256(Re * DH));
+    }
+    colsum(H1, Rm, DH, (int)DH, Gd("blendshape_decoder.3.weight"), 0, 1, dz);                              // dw2 = sum_r dz(r) H1[r]
+    RUN(pg.end_phase(st));
+    // ================= P11: input gradients through the fold; decoder[0] parameter gradients =================
+    pg.gemm(NN(dH1, DH, Wfm, d, dA, d, Rm, d, DH), 1);
+    pg.gemm(NN(dHe, DH, Wfe, d, dAe, d, Re, d, DH), 1);
+    pg.gemm(NN(dH1, DH, W1, d, dO2, d, Rm, d, DH), 1);
+    pg.gemm(NN(dHe, DH, W1, d, dOe2, d, Re, d, DH), 1);
+    pg.gemm(TN(dH1, DH, O2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, Rm), 1);
+    colsum(dH1, Rm, DH, (int)DH, Gd("blendshape_decoder.0.bias"), 0, 0, nullptr);
+    colsum(He, Re, DH, (int)DH, Gd("blendshape_decoder.3.weight"), 1, 2, dz);
+    RUN(pg.end_phase(st));
+    // ================= P12: attention backward (dPd, dV); emotion value gradient; output projections =================
+    {
+        GemmArgs g = G(dA, d, 1, KV + d, 1, 2 * d, dP, NKk, 28, NKk, hd);                                   // dPd = dA_h V_h^T
+        g.batch2 = (int)H; g.a_bs1 = 28 * d; g.a_bs2 = hd; g.b_bs1 = NKk * 2 * d; g.b_bs2 = hd; g.c_bs1 = H * 28 * NKk; g.c_bs2 = 28 * NKk;
+        pg.gemm(g, (int)(B * H));
+        g = G(Pd, 1, NKk, dA, d, 1, dKV + d, 2 * d, NKk, hd, 28);                                           // dV_h = Pd^T dA_h
+        g.batch2 = (int)H; g.a_bs1 = H * 28 * NKk; g.a_bs2 = 28 * NKk; g.b_bs1 = 28 * d; g.b_bs2 = hd; g.c_bs1 = NKk * 2 * d; g.c_bs2 = hd;
+        pg.gemm(g, (int)(B * H));
+    }
+    {
+        ElemArgs e{};
+        e.p0 = dAe; e.q0 = dVe; e.n0 = B; e.i0 = (int)d; e.i1 = (int)hd; e.mask = m_emo; e.f0 = keep_scale;
+        pg.elem(OP_EMO_REDUCE, e, blocks256(B * d));
+    }
+    pg.gemm(NN(dO2, d, Wmo, d, dO1, d, Rm, d, d), 1);
+    pg.gemm(NN(dOe2, d, Weo, d, dOe1, d, Re, d, d), 1);
+    pg.gemm(TN(dO2, d, O1, d, Gd("mel_output_proj.weight"), d, d, d, Rm), 1);
+    pg.gemm(TN(dOe2, d, Oe1, d, Gd("emotion_output_proj.weight"), d, d, d, Re), 1);
+    colsum(dO2, Rm, d, (int)d, Gd("mel_output_proj.bias"), 0, 0, nullptr);
+    colsum(dOe2, Re, d, (int)d, Gd("emotion_output_proj.bias"), 0, 0, nullptr);
+    { GemmArgs g = TN(dHe, DH, Oe2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, Re); g.beta = 1.f; pg.gemm(g, 1); }
+    colsum(dHe, Re, DH, (int)DH, Gd("blendshape_decoder.0.bias"), 1, 0, nullptr);
+    RUN(pg.end_phase(st));
+    // ================= P13: softmax backward; out_proj gradients; emotion value projection backward =================
+    {
+        ElemArgs e{};
+        e.p0 = dP; e.p1 = Pm; e.q0 = dS; e.n0 = B * H * 28; e.i0 = (int)NKk; e.mask = m_mel; e.f0 = keep_scale;
+        pg.elem(OP_SOFTMAX_BWD, e, blocks4(B * H * 28));
+    }
+    pg.gemm(TN(dO1, d, A, d, Gd("mel_attention.out_proj.weight"), d, d, d, Rm), 1);
+    pg.gemm(TN(dOe1, d, Ae, d, Gd("emotion_attention.out_proj.weight"), d, d, d, Re), 1);
+    colsum(dO1, Rm, d, (int)d, Gd("mel_attention.out_proj.bias"), 0, 0, nullptr);
+    colsum(dOe1, Re, d, (int)d, Gd("emotion_attention.out_proj.bias"), 0, 0, nullptr);
+    pg.gemm(TN(dVe, d, E, d, gein_w + 2 * d * d, d, d, d, B), 1);                                           // only the V third of in_proj
+    colsum(dVe, B, d, (int)d, gein_b + 2 * d, 0, 0, nullptr);
+    pg.gemm(NN(dVe, d, einw + 2 * d * d, d, dE, d, B, d, d), 1);
+    RUN(pg.end_phase(st));
+    // ================= P14: dK, dQ (per-window partials); emotion LayerNorm backward =================
+    {
+        GemmArgs g = G(dS, 1, NKk, Qb, d, 1, dKV, 2 * d, NKk, hd, 28);                                      // dK_h = scale dS^T Q_h
+        g.alpha = scale; g.batch2 = (int)H; g.a_bs1 = H * 28 * NKk; g.a_bs2 = 28 * NKk; g.b_bs2 = hd; g.c_bs1 = NKk * 2 * d; g.c_bs2 = hd;
+        pg.gemm(g, (int)(B * H));
+        g = G(dS, NKk, 1, KV, 2 * d, 1, dQ_part, d, 28, hd, NKk);                                           // dQ_h[b] = scale dS K_h
+        g.alpha = scale; g.batch2 = (int)H; g.a_bs1 = H * 28 * NKk; g.a_bs2 = 28 * NKk; g.b_bs1 = NKk * 2 * d; g.b_bs2 = hd;
+        g.c_bs1 = 28 * d; g.c_bs2 = hd;
+        pg.gemm(g, (int)(B * H));
+    }
+    {
+        ElemArgs e{};
+        e.p0 = dE; e.p1 = E0; e.p2 = emu; e.p3 = ers; e.n0 = B; e.n1 = B; e.i0 = (int)d;
+        e.q0 = Gd("emotion_norm.weight"); e.q1 = Gd("emotion_norm.bias");
+        pg.elem(OP_LN_PGRAD, e, (d + 63) / 64);
+        ElemArgs b{};
+        b.p0 = dE; b.p1 = E0; b.p2 = P("emotion_norm.weight"); b.p3 = emu; b.p4 = ers; b.q0 = dE0; b.n0 = B; b.i0 = (int)d;
+        pg.elem(OP_LN_BWD, b, blocks4(B));
+    }
+    RUN(pg.end_phase(st));
+    // ================= P15: dY; in_proj [K | V] gradients; dQ; emotion encoder gradients =================
+    pg.gemm(NN(dKV, 2 * d, inw + d * d, d, dY, d, R, d, 2 * d), 1);
+    pg.gemm(TN(dKV, 2 * d, Y, d, gin_w + d * d, d, 2 * d, d, R), 1);
+    const int S_kv = colsum_split(dKV, R, 2 * d, (int)(2 * d), part_a);
+    reduce(dQ_part, (int)B, 28 * d, 28 * d, dQb, 0);
+    pg.gemm(TN(dE0, d, emo, ED, Gd("emotion_encoder.weight"), ED, d, ED, B), 1);
+    colsum(dE0, B, d, (int)d, Gd("emotion_encoder.bias"), 0, 0, nullptr);
+    RUN(pg.end_phase(st));
+    // ================= P16: LayerNorm backward + its parameter gradients; query-side gradients =================
+    const int S_ln = split_rows(R);
+    {
+        ElemArgs e{};
+        e.p0 = dY; e.p1 = Y0; e.p2 = mu; e.p3 = rs; e.n0 = R; e.n1 = (R + S_ln - 1) / S_ln; e.i0 = (int)d;
+        e.q0 = S_ln == 1 ? Gd("mel_norm.weight") : part_lnm; e.q1 = S_ln == 1 ? Gd("mel_norm.bias") : part_lnm + 32 * d;
+        pg.elem(OP_LN_PGRAD, e, (int64_t)S_ln * ((d + 63) / 64));
+        ElemArgs b{};
+        b.p0 = dY; b.p1 = Y0; b.p2 = P("mel_norm.weight"); b.p3 = mu; b.p4 = rs; b.q0 = dY0; b.n0 = R; b.i0 = (int)d;
+        pg.elem(OP_LN_BWD, b, blocks4(R));
+    }
+    reduce(part_a, S_kv, 2 * d, 2 * d, gin_b + d, 0);
+    pg.gemm(TN(dQb, d, P("mouth_queries"), d, gin_w, d, d, d, 28), 1);
+    colsum(dQb, 28, d, (int)d, gin_b, 0, 0, nullptr);
+    pg.gemm(NN(dQb, d, inw, d, Gd("mouth_queries"), d, 28, d, d), 1);
+    RUN(pg.end_phase(st));
+    // ================= P17: channel encoder gradients (per-window partials) =================
+    {
+        GemmArgs g = G(dY0, 1, d, X, 1, NKk, dWce_part, KT, d, KT, NKk);                                    // dWce[b] = dY0_b^T X_b
+        g.a_bs1 = NKk * d; g.b_bs1 = KP * NKk; g.c_bs1 = d * KT;
+        pg.gemm(g, (int)B);
+    }
+    const int S_ce = colsum_split(dY0, R, d, (int)d, part_b);
+    if (S_ln > 1) {
+        reduce(part_lnm, S_ln, d, d, Gd("mel_norm.weight"), 0);
+        reduce(part_lnm + 32 * d, S_ln, d, d, Gd("mel_norm.bias"), 0);
+    }
+    RUN(pg.end_phase(st));
+    // ================= P18: sum the partials =================
+    reduce(dWce_part, (int)B, d * KT, d * KT, Gd("mel_channel_encoder.weight"), 0);
+    reduce(part_b, S_ce, d, d, Gd("mel_channel_encoder.bias"), 0);
+    RUN(pg.end_phase(st));
+    (void)part_lne; (void)part_c; (void)dQb; (void)gein_w;
+    return KM_OK;
+}
+
+// per-window audio energy for the audio-visual loss term: mean over T of the L2 norm over D (losses.py:352-358)
+__global__ __launch_bounds__(64) void audio_energy_kernel(const float* __restrict__ f, int T, int D, float* __restrict__ out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float* row = f + ((int64_t)b * T + t) * D;
+        float s = 0.f;
+        for (int i = lane; i < D; i += 64) s += row[i] * row[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        acc += sqrtf(s);
+    }
+    if (lane == 0) out[b] = acc / (float)T;
+}
+
+int launch_audio_energy(const float* feats, int64_t B, int64_t T, int64_t D, float* out, void* stream) {
+    hipLaunchKernelGGL(audio_energy_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, feats, (int)T, (int)D, out);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+}  // namespace km

@@ -39,7 +39,9 @@ def cosine_warm_restarts_lr(epoch: int, base_lr: float, T_0: int = 10, T_mult: i
 class Trainer:
     def __init__(self, engine: Engine, max_windows: int = 8, lr: float = 1e-4, weight_decay: float = 1e-5,
                  betas=(0.9, 0.999), eps: float = 1e-8, grad_clip: float = 1.0, mse_weight: float = 1.0,
-                 l1_weight: float = 0.0, use_smoothing: bool = True):
+                 l1_weight: float = 0.0, use_smoothing: bool = True, dropout: float = 0.0, seed: int = 0):
+        """``dropout``: training-mode dropout probability of the two attention modules and the decoder (the reference
+        trains at 0.1 under model.train(), src/train_sequential.py:118); 0 = eval-mode arithmetic."""
         if engine.device is None:
             raise RuntimeError("finalize the Engine first")
         self.engine, self.device = engine, engine.device
@@ -50,6 +52,9 @@ class Trainer:
         self.max_windows = max_windows
         with torch.cuda.device(self.device):
             check(self._lib.km_train_init(self._h, max_windows, _stream_ptr(self.device)))
+        self.dropout = float(dropout)
+        if self.dropout > 0:
+            self.set_dropout(self.dropout, seed)
         self.n_params = int(self._lib.km_train_num_params(self._h))
         self.flat_grad = torch.zeros(self.n_params, device=self.device)
         self.loss = torch.zeros(1, device=self.device)
@@ -108,10 +113,37 @@ class Trainer:
     def reset_temporal_state(self):
         self._ema_batch = None
 
+    # ---- training-mode dropout -------------------------------------------------------------------
+    def set_dropout(self, p: float, seed: int = 0, external_masks: bool = False) -> None:
+        """km_train_set_dropout: Philox masks per step (keyed by ``seed`` and a device-side step counter), or the masks
+        last given to ``set_dropout_masks`` when ``external_masks``."""
+        check(self._lib.km_train_set_dropout(self._h, float(p), int(seed) & (2 ** 64 - 1), 1 if external_masks else 0))
+        self.dropout = float(p)
+
+    def _mask_shapes(self, B: int):
+        e = self.engine
+        return (B, e.num_heads, 28, e.n_mels), (B, e.num_heads, 24, 1), (B, 52, e.d_model // 2)
+
+    def dropout_masks(self, B: int) -> Dict[str, np.ndarray]:
+        """Keep masks of the most recent step as {"mel", "emo", "dec"} boolean arrays (oracle.core.core_forward layout)."""
+        shapes = self._mask_shapes(B)
+        bufs = [np.empty(s, np.uint8) for s in shapes]
+        with torch.cuda.device(self.device):
+            check(self._lib.km_train_get_dropout_masks(self._h, B, bufs[0].ctypes.data, bufs[1].ctypes.data, bufs[2].ctypes.data,
+                                                       _stream_ptr(self.device)))
+        return {k: b.astype(bool) for k, b in zip(("mel", "emo", "dec"), bufs)}
+
+    def set_dropout_masks(self, masks: Dict[str, np.ndarray]) -> None:
+        B = int(masks["mel"].shape[0])
+        bufs = [np.ascontiguousarray(np.asarray(masks[k]).reshape(s), np.uint8) for k, s in zip(("mel", "emo", "dec"), self._mask_shapes(B))]
+        with torch.cuda.device(self.device):
+            check(self._lib.km_train_set_dropout_masks(self._h, B, bufs[0].ctypes.data, bufs[1].ctypes.data, bufs[2].ctypes.data,
+                                                       _stream_ptr(self.device)))
+
     def set_loss_terms(self, perceptual_weight: float = 0.0, temporal_weight: float = 0.0, sparsity_weight: float = 0.0,
                        smoothness_weight: float = 0.0, landmark_weight: float = 0.0, velocity_weight: float = 0.0,
                        prev_pred: Optional[torch.Tensor] = None, prev_target: Optional[torch.Tensor] = None,
-                       landmark_weights: Optional[torch.Tensor] = None) -> None:
+                       landmark_weights: Optional[torch.Tensor] = None, audio_features: Optional[torch.Tensor] = None) -> None:
         """The remaining terms of the reference's KoeMorphLoss (src/model/losses.py:29-178), added to mse/l1.
         prev_pred / prev_target (B,52) and landmark_weights (136,52) are device tensors the trainer keeps alive;
         call with no arguments to switch the extra terms off."""
@@ -124,8 +156,18 @@ class Trainer:
             assert tuple(t.shape[-len(shape_tail):]) == shape_tail, (t.shape, shape_tail)
             keep.append(t)
             return _ptr(t)
+        energy = None
+        if audio_features is not None:     # audio-visual term of the perceptual loss (losses.py:340-378): per-window energy
+            af = audio_features.to(self.device, torch.float32).contiguous()
+            if af.dim() == 2:
+                af = af.unsqueeze(1)
+            energy = torch.empty(af.shape[0], device=self.device)
+            with torch.cuda.device(self.device):
+                check(self._lib.km_audio_energy(_ptr(af), af.shape[0], af.shape[1], af.shape[2], _ptr(energy), _stream_ptr(self.device)))
+            keep.append(energy)
         cfg = KMLossConfig(perceptual_weight, temporal_weight, sparsity_weight, smoothness_weight, landmark_weight,
-                           velocity_weight, dev(prev_pred, (52,)), dev(prev_target, (52,)), dev(landmark_weights, (136, 52)))
+                           velocity_weight, dev(prev_pred, (52,)), dev(prev_target, (52,)), dev(landmark_weights, (136, 52)),
+                           None if energy is None else _ptr(energy))
         self._loss_tensors = keep
         import ctypes
         check(self._lib.km_train_set_loss(self._h, ctypes.byref(cfg)))

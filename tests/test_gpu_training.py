@@ -178,3 +178,96 @@ def test_graph_replay_of_the_train_step_matches_eager():
     assert l0 == l1
     for k in p0:
         assert np.array_equal(p0[k], p1[k]), k
+
+
+# ---- phased step (km_trainp.hip): dropout, audio-visual term, agreement with the launch-per-op chain -------------------
+def test_phased_step_agrees_with_the_launch_per_op_chain():
+    """Default = phased program (19 launches); option train_chain = round 1's ~70-launch chain.  Same arithmetic up to
+    summation order (the phased step folds out_proj / mel_output_proj / decoder[0] for the forward value)."""
+    c, params, (mel, short, emo), g = golden_case("core_d256_T256_H8_grads")
+    target = synth.uniform(c["seed"] * 3 + 1, (c["B"], 52), 0.0, 1.0)
+    shapes = {k: v.shape for k, v in params.items()}
+    e, tr = make(params, c, l1_weight=0.1)
+    l_ph = float(tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target)).item())
+    g_ph, out_ph = tr.grads(shapes), tr.out[:c["B"]].clone()
+    again = float(tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target)).item())
+    assert again == l_ph and all(np.array_equal(v, tr.grads(shapes)[k]) for k, v in g_ph.items())     # no atomics: bit-reproducible
+    e.set_option("train_chain", 1)
+    l_ch = float(tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target)).item())
+    g_ch = tr.grads(shapes)
+    e.set_option("train_chain", 0)
+    assert abs(l_ph - l_ch) < 1e-6 * max(1.0, abs(l_ch)) and float((out_ph - tr.out[:c["B"]]).abs().max()) < 1e-6
+    for k in g_ph:
+        np.testing.assert_allclose(g_ph[k], g_ch[k], atol=1e-8 + 2e-5 * np.abs(g_ch[k]).max(), rtol=2e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["core_d64_T32_H4_train", "core_d256_T256_H8_train"])
+def test_training_mode_dropout_gradients_match_reference(name):
+    """model.train() with dropout 0.1: the step replays the three dropout masks of the fixture (drawn by torch in the
+    reference run) and must reproduce the reference's training-mode output, loss and autograd gradients."""
+    from conftest import golden_masks
+    c, params, (mel, short, emo), g = golden_case(name)
+    masks, p = golden_masks(g), float(g["dropout_p"])
+    target = synth.uniform(c["seed"] * 3 + 1, (c["B"], 52), 0.0, 1.0)
+    e, tr = make(params, c)
+    tr.set_dropout(p, external_masks=True)
+    tr.set_dropout_masks(masks)
+    loss = tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target))
+    np.testing.assert_allclose(tr.out[:c["B"]].cpu().numpy(), g["train_blendshapes"], atol=2e-6)
+    assert abs(float(loss.item()) - float(g["loss"])) < 2e-6 * max(1.0, abs(float(g["loss"])))
+    assert_grads_match(tr.grads({k: v.shape for k, v in params.items()}), g, 2e-4)
+    back = tr.dropout_masks(c["B"])
+    assert all(np.array_equal(back[k], masks[k]) for k in masks)
+    e.set_option("train_chain", 1)            # the chain has no dropout and says so
+    with pytest.raises(Exception, match="dropout"):
+        tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target))
+    e.set_option("train_chain", 0)
+
+
+def test_philox_dropout_masks_and_oracle_parity():
+    """Masks drawn on the device: keep rate 1 - p, fresh every step, reproducible for a seed; and the step that used
+    them matches the oracle fed with the exported masks (gradients <= 1e-5 relative to the largest entry)."""
+    c, params, (mel, short, emo), g = golden_case("core_d256_T256_H8_grads")
+    target = synth.uniform(c["seed"] * 3 + 1, (c["B"], 52), 0.0, 1.0)
+    shapes = {k: v.shape for k, v in params.items()}
+    e, tr = make(params, c, dropout=0.1, seed=1234)
+    loss = float(tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target)).item())
+    m1 = tr.dropout_masks(c["B"])
+    grads = tr.grads(shapes)
+    for k, tol in (("mel", 0.004), ("dec", 0.01), ("emo", 0.03)):
+        assert abs(m1[k].mean() - 0.9) < tol, (k, m1[k].mean())
+    want_loss, want_grads, want_out = core.core_loss_and_grads(params, mel, short, emo, target, num_heads=c["H"],
+                                                               mel_sequence_length=c["T"], dropout_p=0.1, drop_masks=m1)
+    assert abs(loss - want_loss) < 2e-6 * max(1.0, abs(want_loss))
+    np.testing.assert_allclose(tr.out[:c["B"]].cpu().numpy(), want_out, atol=2e-6)
+    for k in grads:
+        scale = max(float(np.abs(want_grads[k]).max()), 1e-12)
+        assert float(np.abs(grads[k] - want_grads[k]).max()) <= 1e-5 * scale + 1e-9, k
+    tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target))
+    m2 = tr.dropout_masks(c["B"])
+    assert (m1["mel"] != m2["mel"]).mean() > 0.1                       # the next step draws different masks
+    e2, tr2 = make(params, c, dropout=0.1, seed=1234)
+    tr2.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target))
+    assert all(np.array_equal(tr2.dropout_masks(c["B"])[k], m1[k]) for k in m1)        # same seed, same first step
+    e3, tr3 = make(params, c, dropout=0.1, seed=99)
+    tr3.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target))
+    assert (tr3.dropout_masks(c["B"])["mel"] != m1["mel"]).mean() > 0.1
+
+
+@pytest.mark.parametrize("name", ["core_d64_T32_H4_fullloss_av", "core_d256_T256_H8_train_fullloss_av"])
+def test_audio_visual_term_and_full_loss_match_reference(name):
+    """KoeMorphLoss with audio_features (audio-visual consistency term, losses.py:340-378), with and without dropout."""
+    from conftest import golden_masks
+    c, params, (mel, short, emo), g = golden_case(name)
+    target, prev_pred, prev_target, lw = full_loss_inputs(c["seed"], c["B"])
+    af = synth.make_av_features(c["seed"], c["B"])
+    e, tr = make(params, c, mse_weight=1.0, l1_weight=0.1)
+    if "dropout_p" in g:
+        tr.set_dropout(float(g["dropout_p"]), external_masks=True)
+        tr.set_dropout_masks(golden_masks(g))
+    tr.set_loss_terms(perceptual_weight=0.5, temporal_weight=0.2, sparsity_weight=0.01, smoothness_weight=0.1,
+                      landmark_weight=0.3, velocity_weight=0.05, prev_pred=dev(prev_pred), prev_target=dev(prev_target),
+                      landmark_weights=dev(lw), audio_features=dev(af))
+    loss = tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target))
+    assert abs(float(loss.item()) - float(g["loss"])) < 2e-6 * max(1.0, abs(float(g["loss"])))
+    assert_grads_match(tr.grads({k: v.shape for k, v in params.items()}), g, 2e-4)
