@@ -1,111 +1,192 @@
-// Device side of the strided exact-fp32 MFMA GEMM for SMALL problems (training step at 8 windows per GPU: 4 to 80 tiles per
-// product): one 64 x 64 tile per 256 threads, BK = 32, operands through arbitrary strides like gemm_kernel, but with the
-// global loads of the next D k-tiles in flight in registers (gemm_kernel keeps one).  A product of 8 k-steps on a handful
-// of workgroups is bound by the load -> LDS -> MFMA chain of every step, not by arithmetic: with one tile of prefetch a
-// step costs a full L2 round trip, with D = 4 the round trips overlap.  LDS tiles are double buffered (one barrier per
-// k-step).  Included inside namespace km of a .hip translation unit that defines f32x4 and KM_MFMA.
+// Device side of the strided exact-fp32 MFMA GEMM for SMALL problems (training step at 8 windows per GPU: 4 to 160 tiles per
+// product).  One BM x 64 tile (BM = 32 or 64) per 256 threads, BK = 32, operands through strides like gemm_kernel.  What a
+// handful of workgroups needs is a short dependent chain per k-step, so:
+//   * per-thread source pointers are computed ONCE; a k-step adds an offset (gemm_kernel spent more vector cycles on index
+//     arithmetic per step than on its 32 MFMAs -- and on gfx950 fp32 MFMA and VALU share one ALU budget,
+//     tools/micro/coissue.hip);
+//   * an operand that is contiguous along k (A row-major, nn.Linear weights) or along its rows (transposed operands of
+//     the weight-gradient products) moves as 16-byte loads; anything else falls back to scalar loads of the same slots;
+//   * LDS image [k / 4][row][k % 4]: a lane's fragments for FOUR consecutive MFMAs are one ds_read_b128 (lane group g
+//     contracts k = 16 kb + 4 g + s in MFMA s; valid because A and B use the same partition), 16 lanes = 16 rows = all
+//     64 banks; k-contiguous operands are committed with one ds_write_b128 per global float4;
+//   * the loads of the next D k-tiles are in flight in registers, LDS tiles are double buffered: one barrier per k-step.
+// Included inside namespace km of a .hip translation unit that defines f32x4 and KM_MFMA.
 #pragma once
 
 #include "km_gemm.h"
 
 namespace ggd {
-constexpr int BM = 64, BN = 64, BK = 32, LDT = 80;
-constexpr int EPT = BM * BK / 256;
-constexpr int LDS_FLOATS = 2 * 2 * BK * LDT;          // A and B tiles, two buffers each: 40 KB
+constexpr int BN = 64, BK = 32;
+constexpr int lds_floats(int BM) { return 2 * (BM + BN) * BK; }      // A and B tiles, two buffers each
+constexpr int LDS_FLOATS = lds_floats(64);                            // 32 KB
 }
 
-struct GemmTileCtx {
-    const float* A; const float* Bp;
-    int m0, n0, tid;
-    bool a_kfast, b_kfast;
+// One operand tile of ROWS rows x 32 k: slot e of a thread is four elements that are CONTIGUOUS in memory:
+//   mode 0 (k-contiguous operand):   slot = (row r, k group kg): k = 4 kg .. 4 kg + 3
+//   mode 1 (row-contiguous operand): slot = (k, rows 4 r4 .. 4 r4 + 3)
+// Loads are branch-free buffer loads (one b128 when VEC, else four b32): rows outside the matrix point past the
+// descriptor's range and read zeros, elements past K or past the last row are cleared with selects.  No branch encloses a
+// load, so the compiler counts them (s_waitcnt vmcnt(N)) and the D-deep prefetch really overlaps: with `if (in range)`
+// around the loads every commit waited for vmcnt(0), i.e. for the tiles requested last.
+typedef unsigned int gd_u32x4 __attribute__((ext_vector_type(4)));
+template <int ROWS, bool VEC>
+struct OperandTile {
+    static constexpr int E = ROWS * 8 / 256;
+    static constexpr unsigned OOB = 0x80000000u;
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned off[E];         // byte offset of the slot in k-tile 0 (OOB: the row is outside the matrix)
+    int kq[E];               // mode 0: first k of the slot inside a tile; mode 1: its k
+    int nrow[E];             // mode 1: rows of the slot inside the matrix (0 .. 4)
+    int lds[E];              // float offset of the slot's first element in the LDS image
+    unsigned kstep;          // bytes from one k-tile to the next
+    int mode, K, es;         // es: LDS element stride inside a slot
+
+    __device__ __forceinline__ void init(const float* b, int64_t rs, int64_t ks, int row0, int nrows, int K_, int64_t extent_floats,
+                                         int tid) {
+        K = K_;
+        mode = ks == 1 ? 0 : 1;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b), 0, (unsigned)(extent_floats * 4), 0x00020000);
+        kstep = (unsigned)(ggd::BK * ks * 4);
+        es = mode == 1 ? 4 : 1;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int idx = tid + 256 * e;
+            if (mode == 1) {
+                const int r4 = idx & (ROWS / 4 - 1), k = idx / (ROWS / 4), g0 = row0 + 4 * r4;
+                kq[e] = k;
+                nrow[e] = nrows - g0 < 0 ? 0 : (nrows - g0 > 4 ? 4 : nrows - g0);
+                off[e] = g0 < nrows ? (unsigned)(((int64_t)k * ks + g0) * 4) : OOB;
+                lds[e] = ((k >> 2) * ROWS + 4 * r4) * 4 + (k & 3);
+            } else {
+                const int r = idx & (ROWS - 1), kg = idx / ROWS, g = row0 + r;
+                kq[e] = 4 * kg;
+                nrow[e] = 4;
+                off[e] = g < nrows ? (unsigned)(((int64_t)g * rs + 4 * kg) * 4) : OOB;
+                lds[e] = (kg * ROWS + r) * 4;
+            }
+        }
+    }
+    // global -> registers for k-tile `nk` (kb_bytes = byte offset of the contraction batch)
+    __device__ __forceinline__ void load(unsigned kb_bytes, int nk, bool dead, float4 (&v)[E]) const {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            // a row outside the matrix keeps its offset >= 2^31 (operands are < 2^31 bytes); a stage past the end is all OOB
+            const unsigned o = dead ? OOB : off[e] + kb_bytes + (unsigned)nk * kstep;
+            float4 t;
+            if constexpr (VEC) {
+                const gd_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0);
+                t = make_float4(__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3]));
+            } else {
+                t.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, o, 0, 0));
+                t.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, o + 4, 0, 0));
+                t.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, o + 8, 0, 0));
+                t.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, o + 12, 0, 0));
+            }
+            v[e] = t;
+        }
+    }
+    // clear what lies past K / past the last row (selects only), then registers -> LDS image [k / 4][row][k % 4].
+    // Branch-free: four ds_write_b32 at a uniform element stride (1: k-contiguous slot, 4: a slot of four rows).
+    __device__ __forceinline__ void commit(float* tile, int nk, const float4 (&v)[E]) const {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int k = nk * ggd::BK + kq[e];
+            const int nv = mode == 1 ? (k < K ? nrow[e] : 0) : K - k;
+            float* d = tile + lds[e];
+            d[0] = nv > 0 ? v[e].x : 0.f;
+            d[es] = nv > 1 ? v[e].y : 0.f;
+            d[2 * es] = nv > 2 ? v[e].z : 0.f;
+            d[3 * es] = nv > 3 ? v[e].w : 0.f;
+        }
+    }
 };
 
-__device__ __forceinline__ void gemm_stage_d(const GemmArgs& g, const GemmTileCtx& c, const float* A, const float* Bp, int k0,
-                                             float (&ra)[ggd::EPT], float (&rb)[ggd::EPT]) {
-    using namespace ggd;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int idx = c.tid + 256 * e;
-        int m, k;
-        if (c.a_kfast) { k = idx & (BK - 1); m = idx / BK; } else { m = idx & 63; k = idx >> 6; }
-        const int gm = c.m0 + m, gk = k0 + k;
-        ra[e] = (gm < g.M && gk < g.K) ? A[gm * g.a_rs + gk * g.a_cs] : 0.f;
-        int n, kb;
-        if (c.b_kfast) { kb = idx & (BK - 1); n = idx / BK; } else { n = idx & 63; kb = idx >> 6; }
-        const int gn = c.n0 + n, gkb = k0 + kb;
-        rb[e] = (gn < g.N && gkb < g.K) ? Bp[gkb * g.b_rs + gn * g.b_cs] : 0.f;
-    }
+// floats spanned by one output batch of an operand (all contraction batches included)
+__host__ __device__ inline int64_t gemm_operand_extent(int64_t nrows, int64_t rs, int64_t K, int64_t ks, int kb_count, int64_t kbs) {
+    return (nrows - 1) * rs + (K - 1) * ks + 1 + (int64_t)((kb_count > 1 ? kb_count : 1) - 1) * kbs;
+}
+// 16-byte loads are legal for the operand (base of every output batch 16-byte aligned, slot offsets multiples of 4 floats)
+__host__ __device__ inline bool gemm_operand_vec(const float* base, int64_t rs, int64_t ks, int64_t bs1, int64_t bs2, int64_t kbs) {
+    const bool al = (reinterpret_cast<uintptr_t>(base) & 15) == 0 && (bs1 & 3) == 0 && (bs2 & 3) == 0 && (kbs & 3) == 0;
+    return ks == 1 ? (al && (rs & 3) == 0) : (al && (ks & 3) == 0);
 }
 
-// tile (bx, by) of output batch bz; smem = ggd::LDS_FLOATS floats
-template <int D>
+// tile (bx, by) of output batch bz; smem = ggd::lds_floats(BM) floats, 16-byte aligned
+template <int BM, int D, bool VA, bool VB>
 __device__ __forceinline__ void gemm_tile_dev(const GemmArgs& g, int bx, int by, int bz, float* smem) {
     using namespace ggd;
+    constexpr int MT = BM / 32;                              // 16-row MFMA tiles per wave (waves 2 x 2, each (BM / 2) x 32)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lg = lane >> 4, lj = lane & 15;
-    const int wm = wave >> 1, wn = wave & 1;                 // 2 x 2 waves, 32 x 32 each
+    const int wm = wave >> 1, wn = wave & 1;
     const int z1 = bz / g.batch2, z2 = bz - z1 * g.batch2;
-    GemmTileCtx c;
-    c.A = g.A + z1 * g.a_bs1 + z2 * g.a_bs2;
-    c.Bp = g.B + z1 * g.b_bs1 + z2 * g.b_bs2;
+    const int m0 = by * BM, n0 = bx * BN;
+    OperandTile<BM, VA> ta;
+    OperandTile<BN, VB> tb;
+    ta.init(g.A + z1 * g.a_bs1 + z2 * g.a_bs2, g.a_rs, g.a_cs, m0, g.M, g.K,
+            gemm_operand_extent(g.M, g.a_rs, g.K, g.a_cs, g.kb_count, g.a_kbs), tid);
+    tb.init(g.B + z1 * g.b_bs1 + z2 * g.b_bs2, g.b_cs, g.b_rs, n0, g.N, g.K,
+            gemm_operand_extent(g.N, g.b_cs, g.K, g.b_rs, g.kb_count, g.b_kbs), tid);
     float* C = g.C + z1 * g.c_bs1 + z2 * g.c_bs2;
-    c.m0 = by * BM; c.n0 = bx * BN; c.tid = tid;
-    c.a_kfast = g.a_cs == 1;
-    c.b_kfast = g.b_rs == 1;
-    f32x4 acc[2][2];
+    f32x4 acc[MT][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { acc[i][0] = f32x4{0, 0, 0, 0}; acc[i][1] = f32x4{0, 0, 0, 0}; }
+    for (int i = 0; i < MT; ++i) { acc[i][0] = f32x4{0, 0, 0, 0}; acc[i][1] = f32x4{0, 0, 0, 0}; }
     const int kbn = g.kb_count > 0 ? g.kb_count : 1;
     const int kt = (g.K + BK - 1) / BK, total = kbn * kt;
-    float ra[D][EPT], rb[D][EPT];
-    auto stage = [&](int it, float (&a)[EPT], float (&b)[EPT]) {
+    // D stages of loads are ALWAYS in flight -- stages past the end are requested out of range and read zeros -- so the
+    // compiler can count them: the commit of the oldest stage waits with vmcnt(E (D - 1)), not for everything.
+    constexpr int EA = OperandTile<BM, VA>::E, EB = OperandTile<BN, VB>::E;
+    float4 ra[D][EA], rb[D][EB];
+    auto stage = [&](int it, float4 (&a)[EA], float4 (&b)[EB]) {
         const int nb = it / kt, nk = it - nb * kt;
-        gemm_stage_d(g, c, c.A + nb * g.a_kbs, c.Bp + nb * g.b_kbs, nk * BK, a, b);
+        const bool dead = it >= total;                                          // uniform: a stage past the end reads zeros
+        ta.load((unsigned)(nb * g.a_kbs * 4), nk, dead, a);
+        tb.load((unsigned)(nb * g.b_kbs * 4), nk, dead, b);
     };
 #pragma unroll
-    for (int s = 0; s < D; ++s)
-        if (s < total) stage(s, ra[s], rb[s]);
+    for (int s = 0; s < D; ++s) stage(s, ra[s], rb[s]);
     for (int it0 = 0; it0 < total; it0 += D) {
 #pragma unroll
-        for (int s = 0; s < D; ++s) {
+        for (int s = 0; s < D; ++s) {                          // static register slots: no rotation (a move would wait for the load)
             const int it = it0 + s;
-            if (it < total) {                                  // workgroup-uniform
-                float* As = smem + (it & 1) * (2 * BK * LDT);
-                float* Bs = As + BK * LDT;
+            float* As = smem + (s & 1) * ((BM + BN) * BK);     // D is even: step parity == slot parity
+            float* Bs = As + BM * BK;
+            const int nk_c = it % kt;
+            ta.commit(As, nk_c, ra[s]);                        // a stage past the end commits zeros
+            tb.commit(Bs, nk_c, rb[s]);
+            // one barrier per step: the tile written two steps from now reuses this buffer, and every wave passes the
+            // NEXT step's barrier (behind its own MFMAs of this step) before anyone gets there
+            __syncthreads();
+            stage(it + D, ra[s], rb[s]);
+            if (it < total) {                                  // uniform; only LDS reads and MFMAs are conditional
 #pragma unroll
-                for (int e = 0; e < EPT; ++e) {
-                    const int idx = tid + 256 * e;
-                    int m, k;
-                    if (c.a_kfast) { k = idx & (BK - 1); m = idx / BK; } else { m = idx & 63; k = idx >> 6; }
-                    As[k * LDT + m] = ra[s][e];
-                    int n, kb;
-                    if (c.b_kfast) { kb = idx & (BK - 1); n = idx / BK; } else { n = idx & 63; kb = idx >> 6; }
-                    Bs[kb * LDT + n] = rb[s][e];
-                }
-                // one barrier per step: the tile written two steps from now reuses this buffer, and every wave passes the
-                // NEXT step's barrier (behind its own MFMAs of this step) before anyone gets there
-                __syncthreads();
-                if (it + D < total) stage(it + D, ra[s], rb[s]);
+                for (int kb = 0; kb < BK / 16; ++kb) {
+                    f32x4 af[MT], bf[2];
 #pragma unroll
-                for (int q = 0; q < BK / 4; ++q) {
-                    const float* ar = As + (4 * q + lg) * LDT + 32 * wm + lj;
-                    const float* br = Bs + (4 * q + lg) * LDT + 32 * wn + lj;
-                    const float a0 = ar[0], a1 = ar[16], b0 = br[0], b1 = br[16];
-                    acc[0][0] = KM_MFMA(a0, b0, acc[0][0]);
-                    acc[0][1] = KM_MFMA(a0, b1, acc[0][1]);
-                    acc[1][0] = KM_MFMA(a1, b0, acc[1][0]);
-                    acc[1][1] = KM_MFMA(a1, b1, acc[1][1]);
+                    for (int i = 0; i < MT; ++i)
+                        af[i] = *reinterpret_cast<const f32x4*>(As + ((4 * kb + lg) * BM + 16 * MT * wm + 16 * i + lj) * 4);
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn)
+                        bf[jn] = *reinterpret_cast<const f32x4*>(Bs + ((4 * kb + lg) * BN + 32 * wn + 16 * jn + lj) * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+                            acc[i][0] = KM_MFMA(af[i][q], bf[0][q], acc[i][0]);
+                            acc[i][1] = KM_MFMA(af[i][q], bf[1][q], acc[i][1]);
+                        }
                 }
             }
         }
     }
+    static_assert(D % 2 == 0, "the LDS double buffer is indexed by slot parity");
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = c.m0 + 32 * wm + 16 * i + 4 * lg + r, n = c.n0 + 32 * wn + 16 * jn + lj;
+                const int m = m0 + 16 * MT * wm + 16 * i + 4 * lg + r, n = n0 + 32 * wn + 16 * jn + lj;
                 if (m < g.M && n < g.N) {
                     float v = g.alpha * acc[i][jn][r];
                     if (g.bias_mode == 1) v += g.bias[n];

@@ -225,8 +225,14 @@ __global__ void zero_kernel(float* __restrict__ p, int64_t n) {
 // ---- optimizer ---------------------------------------------------------------------------------------------
 
 // sum of squares of the flat gradient, deterministic two-stage reduction
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part,
+                                                            int* __restrict__ steps, int alpha_live) {
     __shared__ float sh[256];
+    // the 1-based AdamW step counters live on the device (graph replay): advanced here, one kernel ahead of their readers
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        steps[0] += 1;
+        if (alpha_live) steps[1] += 1;
+    }
     float a = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) a += g[i] * g[i];
     sh[threadIdx.x] = a;
@@ -256,8 +262,19 @@ __global__ void adamw_tick_kernel(int* __restrict__ steps, int alpha_live) {
 // change / smoothing off): torch leaves its .grad as None and AdamW then skips it entirely (no decay, no moment
 // update, its own step counter).  alpha_idx / alpha_live / (abc1, abc2) reproduce that.
 __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
-                             int64_t n, const float* __restrict__ gnorm, float max_norm, float lr, float b1, float b2,
-                             float eps, float wd, const int* __restrict__ steps, int64_t alpha_idx, int alpha_live) {
+                             int64_t n, const float* __restrict__ part, float* __restrict__ gnorm_out, float max_norm, float lr,
+                             float b1, float b2, float eps, float wd, const int* __restrict__ steps, int64_t alpha_idx,
+                             int alpha_live) {
+    // global gradient norm from the 256 partial sums: every block runs the same fixed-order tree, so all agree bit for bit
+    __shared__ float sh[256];
+    sh[threadIdx.x] = part[threadIdx.x];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    const float gnorm = sqrtf(sh[0]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) gnorm_out[0] = gnorm;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // the 1-based step counters live on the device (advanced by adamw_tick_kernel) so that the launch can be replayed
@@ -270,7 +287,7 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float
     const float bc1 = 1.0f - powf(b1, (float)t), bc2 = 1.0f - powf(b2, (float)t);
     float scale = 1.f;
     if (max_norm > 0.f) {
-        const float c = max_norm / (gnorm[0] + 1e-6f);       // clip_coef, clamped to 1
+        const float c = max_norm / (gnorm + 1e-6f);          // clip_coef, clamped to 1
         scale = c < 1.f ? c : 1.f;
     }
     const float gi = g[i] * scale;
@@ -458,9 +475,8 @@ int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in
         t.mel_w = P("mel_weights"); t.emo_w = P("emotion_weights"); t.temperature = c->cfg.temperature; t.target = target;
         t.bs = bs; t.out = outb; t.dz = dz; t.ema_state = ema_state; t.ema_first = ema_first; t.alpha_p = P("smoothing_alpha");
         t.mse_w = mse_w; t.l1_w = l1_w; t.lc = c->tr_loss_cfg; t.fac = tfac; t.xp = txp; t.loss = loss_dev; t.d_melw = Gd("mel_weights"); t.d_emow = Gd("emotion_weights");
-        t.d_alpha = Gd("smoothing_alpha"); t.B = (int)B; t.DH = (int)DH; t.expr_rows = 1; t.audio_energy = c->tr_loss_cfg.audio_energy_dev;
+        t.d_alpha = Gd("smoothing_alpha"); t.B = (int)B; t.DH = (int)DH; t.expr_rows = 1; t.audio_energy = c->tr_loss_cfg.audio_energy_dev; t.out2 = out_dev;
         hipLaunchKernelGGL(train_tail_kernel, dim3(1), dim3(64 * TAIL_NW), 0, st, t);
-        if (out_dev) HIP_TRY(hipMemcpyAsync(out_dev, outb, (size_t)B * 52 * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
 
     // ================= backward =================
@@ -573,12 +589,11 @@ int train_adamw(Context* c, const float* flat_grad, float lr, float b1, float b2
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = c->tr_nparams;
     const int nb = 256;
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, flat_grad, n, c->tr_part);
-    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, st, c->tr_part, nb, c->tr_gnorm);
+    // two launches: partial sums of squares (+ the step counters), then norm + clip + AdamW in one kernel
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, flat_grad, n, c->tr_part, c->tr_steps, c->tr_alpha_live ? 1 : 0);
     (void)step;
-    hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, st, c->tr_steps, c->tr_alpha_live ? 1 : 0);
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->tr_params, c->tr_m, c->tr_v, flat_grad, n,
-                       c->tr_gnorm, max_norm, lr, b1, b2, eps, wd, c->tr_steps, c->tr_offset.at("smoothing_alpha"),
+                       c->tr_part, c->tr_gnorm, max_norm, lr, b1, b2, eps, wd, c->tr_steps, c->tr_offset.at("smoothing_alpha"),
                        c->tr_alpha_live ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return KM_OK;

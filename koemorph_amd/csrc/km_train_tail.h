@@ -7,7 +7,10 @@ __device__ __forceinline__ int tr_mouth_slot(int i) { return (i >= 14 && i <= 40
 __device__ __forceinline__ int tr_expr_slot(int i) { return i < 14 ? i : i - 27; }
 
 struct TailArgs {
-    const float* zrows;   // (B*28 + B) decoder logits of the mouth rows, then of the shared expression rows (rowdot_kernel)
+    const float* zrows;   // (B*28 + B or B*24) decoder logits of the mouth rows, then of the expression rows
+    float* zrows_out;     // or null.  Not null: the tail computes the logits itself, z[r] = h[r] . w2 + b2 over the mouth rows
+                          // of h1 and the expr_rows * B rows of he, stores them here and uses them (zrows is ignored)
+    float* grow;          // (B*28 + B*24) or null: dL/dz per ROW of the hidden activations (only with expr_rows == 24)
     const float* h1;      // (B*28, DH) post-ReLU hidden of the mouth rows
     const float* he;      // (B, DH)    post-ReLU hidden of the (shared) expression row
     const float* w2; const float* b2;
@@ -16,6 +19,7 @@ struct TailArgs {
     const float* target;  // (B, 52)
     float* bs;            // (B, 52) sigmoid outputs
     float* out;           // (B, 52) final (after clamp and EMA)
+    float* out2;          // (B, 52) or null: the caller's copy of the prediction
     float* dz;            // (B, 52) dL/dz
     float* ema_state;     // (B, 52) or null
     int ema_first;
@@ -48,15 +52,44 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
     __shared__ float wsum_s[52], wm_s[52], we_s[52], dws_p[NW][52], red[NW][64], e_s[NW][52], u_s[NW][136];
     __shared__ float av_g[TAIL_AV_MAX], av_c[2];
     const int i = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x == 0) {   // stream weight softmaxes (dual_stream_attention.py:252-253)
-        float mm = -INFINITY, me = -INFINITY;
-        for (int k = 0; k < 52; ++k) { mm = fmaxf(mm, a.mel_w[k] / a.temperature); me = fmaxf(me, a.emo_w[k] / a.temperature); }
-        float sm = 0.f, se = 0.f;
-        for (int k = 0; k < 52; ++k) {
-            wm_s[k] = expf(a.mel_w[k] / a.temperature - mm); sm += wm_s[k];
-            we_s[k] = expf(a.emo_w[k] / a.temperature - me); se += we_s[k];
+    // wave-wide sums / maxima as xor butterflies: a fixed pairing, so the result does not depend on timing
+    auto wsum64 = [](float v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    };
+    auto wmax64 = [](float v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+        return v;
+    };
+    if (w == 0) {   // stream weight softmaxes (dual_stream_attention.py:252-253), lane k = coefficient k
+        const float vm = i < 52 ? a.mel_w[i] / a.temperature : -INFINITY, ve = i < 52 ? a.emo_w[i] / a.temperature : -INFINITY;
+        const float mm = wmax64(vm), me = wmax64(ve);
+        const float em = i < 52 ? expf(vm - mm) : 0.f, ee = i < 52 ? expf(ve - me) : 0.f;
+        const float sm = wsum64(em), se = wsum64(ee);
+        if (i < 52) { wm_s[i] = em / sm; we_s[i] = ee / se; wsum_s[i] = 0.5f * wm_s[i] + 0.5f * we_s[i]; }
+    }
+    __syncthreads();
+    const float* zr = a.zrows;
+    if (a.zrows_out) {   // decoder output layer: one wave per row, lanes stride the hidden units
+        // 16 lanes per row, four rows per wave at a time: the loads of a pass are independent, so a wave pays the
+        // memory latency once per four rows
+        const int64_t rm = (int64_t)a.B * 28, rows = rm + (int64_t)a.B * a.expr_rows;
+        const int sub = i >> 4, l16 = i & 15;
+        for (int64_t r0 = (int64_t)w * 4; r0 < rows; r0 += (int64_t)NW * 4) {
+            const int64_t r = r0 + sub;
+            float s = 0.f;
+            if (r < rows) {
+                const float* h = r < rm ? a.h1 + r * a.DH : a.he + (r - rm) * a.DH;
+                for (int k = l16; k < a.DH; k += 16) s = fmaf(h[k], a.w2[k], s);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (l16 == 0 && r < rows) a.zrows_out[r] = s + a.b2[0];
         }
-        for (int k = 0; k < 52; ++k) { wm_s[k] /= sm; we_s[k] /= se; wsum_s[k] = 0.5f * wm_s[k] + 0.5f * we_s[k]; }
+        zr = a.zrows_out;
+        __threadfence_block();
     }
     __syncthreads();
     const float alpha = 1.0f / (1.0f + expf(-a.alpha_p[0]));
@@ -66,8 +99,8 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
     if (i < 52) {
         const int slot = tr_mouth_slot(i);
         for (int b = w; b < a.B; b += NW) {
-            const float z = slot >= 0 ? a.zrows[(int64_t)b * 28 + slot]
-                                      : a.zrows[(int64_t)a.B * 28 + (a.expr_rows == 1 ? b : (int64_t)b * 24 + tr_expr_slot(i))];
+            const float z = slot >= 0 ? zr[(int64_t)b * 28 + slot]
+                                      : zr[(int64_t)a.B * 28 + (a.expr_rows == 1 ? b : (int64_t)b * 24 + tr_expr_slot(i))];
             const float bs = 1.0f / (1.0f + expf(-z));
             const float f = wsum_s[i] * bs;
             const float x = fminf(fmaxf(f, 0.f), 1.f);
@@ -84,6 +117,7 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
             }
             a.bs[(int64_t)b * 52 + i] = bs;
             a.out[(int64_t)b * 52 + i] = y;
+            if (a.out2) a.out2[(int64_t)b * 52 + i] = y;
             a.fac[(int64_t)b * 52 + i] = dy_dx * ((f >= 0.f && f <= 1.f) ? 1.f : 0.f);
             a.xp[(int64_t)b * 52 + i] = xp;
         }
@@ -183,36 +217,41 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
             const float df = dy * a.fac[(int64_t)b * 52 + i];
             const float bs = a.bs[(int64_t)b * 52 + i];
             dws += df * bs;
-            a.dz[(int64_t)b * 52 + i] = df * wsum_s[i] * bs * (1.0f - bs);
+            const float dzv = df * wsum_s[i] * bs * (1.0f - bs);
+            a.dz[(int64_t)b * 52 + i] = dzv;
+            if (a.grow) {
+                const int slot = tr_mouth_slot(i);
+                if (slot >= 0) a.grow[(int64_t)b * 28 + slot] = dzv;
+                else a.grow[(int64_t)a.B * 28 + (int64_t)b * 24 + tr_expr_slot(i)] = dzv;
+            }
         }
     }
     if (i < 52) dws_p[w][i] = dws;
     red[w][i] = i < 52 ? loss_acc : 0.f;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float s = 0.f;
-        for (int ww = 0; ww < NW; ++ww)
-            for (int k = 0; k < 52; ++k) s += red[ww][k];
+    if (w == 0) {   // waves in index order per coefficient, then the butterfly over the coefficients
+        float t = 0.f;
+        for (int ww = 0; ww < NW; ++ww) t += red[ww][i];
+        float s = wsum64(t);
         if (av_on) s += lc.perceptual_weight * 0.5f * (1.0f - av_c[0]);
-        a.loss[0] = s;
+        if (i == 0) a.loss[0] = s;
     }
     __syncthreads();
     red[w][i] = i < 52 ? dal : 0.f;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float s = 0.f;
-        for (int ww = 0; ww < NW; ++ww)
-            for (int k = 0; k < 52; ++k) s += red[ww][k];
-        a.d_alpha[0] = s;
+    if (w == 0) {
+        float t = 0.f;
+        for (int ww = 0; ww < NW; ++ww) t += red[ww][i];
+        const float s = wsum64(t);
+        if (i == 0) a.d_alpha[0] = s;
         // softmax backward for both stream-weight vectors: d w_j = (1/tau) w_j (g_j - sum_k g_k w_k), g = 0.5 dwsum
-        float dws_t[52];
-        for (int k = 0; k < 52; ++k) { float t = 0.f; for (int ww = 0; ww < NW; ++ww) t += dws_p[ww][k]; dws_t[k] = t; }
-        float dm = 0.f, de = 0.f;
-        for (int k = 0; k < 52; ++k) { dm += 0.5f * dws_t[k] * wm_s[k]; de += 0.5f * dws_t[k] * we_s[k]; }
-        for (int k = 0; k < 52; ++k) {
-            a.d_melw[k] = wm_s[k] * (0.5f * dws_t[k] - dm) / a.temperature;
-            a.d_emow[k] = we_s[k] * (0.5f * dws_t[k] - de) / a.temperature;
+        float dws_t = 0.f;
+        if (i < 52)
+            for (int ww = 0; ww < NW; ++ww) dws_t += dws_p[ww][i];
+        const float dm = wsum64(i < 52 ? 0.5f * dws_t * wm_s[i] : 0.f), de = wsum64(i < 52 ? 0.5f * dws_t * we_s[i] : 0.f);
+        if (i < 52) {
+            a.d_melw[i] = wm_s[i] * (0.5f * dws_t - dm) / a.temperature;
+            a.d_emow[i] = we_s[i] * (0.5f * dws_t - de) / a.temperature;
         }
     }
 }
-

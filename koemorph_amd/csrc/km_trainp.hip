@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "km_context.h"
@@ -43,13 +44,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- operations of a phase ------------------------------------------------------------------------------------
 enum OpKind : int {
-    OP_GEMM = 0, OP_ZERO, OP_MASKGEN, OP_PACKX, OP_LN_FWD, OP_LN_BWD, OP_LN_PGRAD, OP_SOFTMAX_DROP, OP_SOFTMAX_BWD, OP_ROWDOT,
-    OP_RELU_OUTER, OP_COLSUM, OP_REDUCE, OP_EMO_EXPAND, OP_EMO_REDUCE
+    OP_GEMM = 0, OP_ZERO, OP_FILL, OP_MASKGEN, OP_PACKX, OP_LN_FWD, OP_LN_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_RELU_OUTER, OP_REDUCE,
+    OP_EMO_EXPAND, OP_EMO_REDUCE
 };
 
 struct ElemArgs {
     const float *p0, *p1, *p2, *p3, *p4;
-    float *q0, *q1, *q2;
+    float *q0, *q1, *q2, *q3;
     const unsigned char* mask;
     unsigned char* mask_out;
     int64_t n0, n1;
@@ -61,6 +62,8 @@ struct ElemArgs {
 struct Op {
     int kind;
     int gx, gy;            // OP_GEMM: tiles along N and M (blocks = gx * gy * batch)
+    int bm;                // OP_GEMM: tile rows (32 when the product would leave most of the chip idle with 64)
+    int va, vb;            // OP_GEMM: 16-byte loads are legal for operand A / B
     union {
         GemmArgs g;
         ElemArgs e;
@@ -101,6 +104,11 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, float* smem) {
         const int64_t i = ((int64_t)vb * 256 + tid) * 4;
         if (i + 3 < a.n0) *reinterpret_cast<float4*>(a.q0 + i) = make_float4(0.f, 0.f, 0.f, 0.f);
         else for (int64_t k = i; k < a.n0; ++k) a.q0[k] = 0.f;
+        break;
+    }
+    case OP_FILL: {
+        const int64_t i = (int64_t)vb * 256 + tid;
+        if (i < a.n0) a.q0[i] = a.f0;
         break;
     }
     case OP_MASKGEN: {      // mask_out[n0] bytes: keep (1) with probability 1 - p; counter = (byte index / 4, region, step)
@@ -163,114 +171,19 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, float* smem) {
         for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
         s1 /= d; s2 /= d;
         for (int i = lane; i < d; i += 64) {
-            const float xh = (a.p1[row * d + i] - mu) * rs, dxh = a.p0[row * d + i] * a.p2[i];
+            const float dyv = a.p0[row * d + i];
+            const float xh = (a.p1[row * d + i] - mu) * rs, dxh = dyv * a.p2[i];
             a.q0[row * d + i] = rs * (dxh - s1 - xh * s2);
+            a.q1[row * d + i] = dyv * xh;                     // column sums of this image = d gamma (a GEMM with a ones vector)
         }
         break;
     }
-    case OP_LN_PGRAD: {     // dgamma[c] = sum_rows dy xhat, dbeta[c] = sum_rows dy; vb = split * (d/64) + column block
-        float* sg = smem; float* sb = smem + 256;
-        const int d = a.i0, nbx = (d + 63) / 64;
-        const int y = vb / nbx, bx = vb - y * nbx;
-        const int col = bx * 64 + lane;
-        const int64_t r0 = (int64_t)y * a.n1, r1 = (r0 + a.n1) < a.n0 ? (r0 + a.n1) : a.n0;
-        float ag = 0.f, ab = 0.f;
-        if (col < d)
-            for (int64_t r = r0 + wv; r < r1; r += 4) {
-                const float g = a.p0[r * d + col];
-                ag += g * (a.p1[r * d + col] - a.p2[r]) * a.p3[r];
-                ab += g;
-            }
-        sg[tid] = ag; sb[tid] = ab;
-        __syncthreads();
-        if (wv == 0 && col < d) {
-            a.q0[(int64_t)y * d + col] = sg[lane] + sg[64 + lane] + sg[128 + lane] + sg[192 + lane];
-            a.q1[(int64_t)y * d + col] = sb[lane] + sb[64 + lane] + sb[128 + lane] + sb[192 + lane];
-        }
-        __syncthreads();
-        break;
-    }
-    case OP_SOFTMAX_DROP: { // P = softmax(S) (saved), Pd = P * keep / (1 - p); rows of width w <= 128, one wave per row
-        const int64_t row = (int64_t)vb * 4 + wv;
-        const int w = a.i0;
-        if (row >= a.n0) break;
-        const float* s = a.p0 + row * w;
-        const float v0 = lane < w ? s[lane] : -INFINITY, v1 = lane + 64 < w ? s[lane + 64] : -INFINITY;
-        float m = fmaxf(v0, v1);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        const float e0 = lane < w ? expf(v0 - m) : 0.f, e1 = lane + 64 < w ? expf(v1 - m) : 0.f;
-        float sum = e0 + e1;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        const float p0 = e0 / sum, p1 = e1 / sum;
-        if (lane < w) {
-            a.q0[row * w + lane] = p0;
-            a.q1[row * w + lane] = a.mask ? (a.mask[row * w + lane] ? p0 * a.f0 : 0.f) : p0;
-        }
-        if (lane + 64 < w) {
-            a.q0[row * w + lane + 64] = p1;
-            a.q1[row * w + lane + 64] = a.mask ? (a.mask[row * w + lane + 64] ? p1 * a.f0 : 0.f) : p1;
-        }
-        break;
-    }
-    case OP_SOFTMAX_BWD: {  // dP = dPd keep / (1 - p); dS = P (dP - sum(dP P)); out of place
-        const int64_t row = (int64_t)vb * 4 + wv;
-        const int w = a.i0;
-        if (row >= a.n0) break;
-        auto g_at = [&](int k) { const float g = a.p0[row * w + k]; return a.mask ? (a.mask[row * w + k] ? g * a.f0 : 0.f) : g; };
-        const float p0 = lane < w ? a.p1[row * w + lane] : 0.f, p1 = lane + 64 < w ? a.p1[row * w + lane + 64] : 0.f;
-        const float g0 = lane < w ? g_at(lane) : 0.f, g1 = lane + 64 < w ? g_at(lane + 64) : 0.f;
-        float s = g0 * p0 + g1 * p1;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane < w) a.q0[row * w + lane] = p0 * (g0 - s);
-        if (lane + 64 < w) a.q0[row * w + lane + 64] = p1 * (g1 - s);
-        break;
-    }
-    case OP_ROWDOT: {       // z[row] = h[row] . w + b
-        const int64_t row = (int64_t)vb * 4 + wv;
-        const int n = a.i0;
-        if (row >= a.n0) break;
-        float s = 0.f;
-        for (int i = lane; i < n; i += 64) s = fmaf(a.p0[row * n + i], a.p1[i], s);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) a.q0[row] = s + a.p2[0];
-        break;
-    }
-    case OP_RELU_OUTER: {   // dHpre[r][m] = dz(r) w2[m] scale [H[r][m] > 0]; H is post-ReLU, post-dropout (H > 0 <=> kept and active)
+    case OP_RELU_OUTER: {   // dHpre[r][m] = g[r] w2[m] scale [H[r][m] > 0]; H is post-ReLU, post-dropout (H > 0 <=> kept and active)
         const int64_t i = (int64_t)vb * 256 + tid;
         const int n = a.i0;
         if (i >= a.n0 * n) break;
         const int64_t r = i / n; const int m = (int)(i - r * n);
-        int b;
-        const int bi = drop_dz_index(a.i1, r, b);
-        a.q0[i] = a.p1[i] > 0.f ? a.p0[(int64_t)b * 52 + bi] * a.p2[m] * a.f0 : 0.f;
-        break;
-    }
-    case OP_COLSUM: {       // out[y][c] = sum over this split's rows of (weight(r) *) m[r * rs + c]; weight = dz of the row (i3 = map) or 1
-        float* sh = smem;
-        const int n = a.i0, nbx = (n + 63) / 64;
-        const int y = vb / nbx, bx = vb - y * nbx;
-        const int col = bx * 64 + lane;
-        const int64_t chunk = (a.n0 + a.i2 - 1) / a.i2;
-        const int64_t r0 = (int64_t)y * chunk, r1 = (r0 + chunk) < a.n0 ? (r0 + chunk) : a.n0;
-        float acc = 0.f;
-        if (col < n)
-            for (int64_t r = r0 + wv; r < r1; r += 4) {
-                float wgt = 1.f;
-                if (a.i3) { int b; const int bi = drop_dz_index(a.i3, r, b); wgt = a.p1[(int64_t)b * 52 + bi]; }
-                acc = fmaf(wgt, a.p0[r * a.n1 + col], acc);
-            }
-        sh[tid] = acc;
-        __syncthreads();
-        if (wv == 0 && col < n) {
-            const float s = sh[lane] + sh[64 + lane] + sh[128 + lane] + sh[192 + lane];
-            float* o = a.q0 + (int64_t)y * n + col;
-            *o = a.i1 ? *o + s : s;
-        }
-        __syncthreads();
+        a.q0[i] = a.p1[i] > 0.f ? a.p0[r] * a.p2[m] * a.f0 : 0.f;
         break;
     }
     case OP_REDUCE: {       // out[c] (+)= sum_y part[y][c], fixed order
@@ -304,12 +217,134 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, float* smem) {
         a.q0[i] = s;
         break;
     }
+    case OP_ATTN_FWD: {     // one (window, head): S = scale Q_h K_h^T, P = softmax(S) (saved), A_h = (P keep / (1 - p)) V_h
+        // p0 Q (28, d), p1 KV (R, 2d); q0 P (B, H, 28, NK), q1 A (B * 28, d); i0 d, i1 hd, i2 NK, i3 H; f0 keep scale, u0 = bits of the score scale
+        const int d = a.i0, hd = a.i1, NKk = a.i2, H = a.i3;
+        const int b = vb / H, h = vb - b * H;
+        float* Qs = smem;                         // [28][hd]
+        float* Ks = Qs + 28 * hd;                 // [NK][hd + 1]
+        float* Vs = Ks + NKk * (hd + 1);          // [NK][hd]
+        float* Ss = Vs + NKk * hd;                // [28][NK]
+        const float scale = __uint_as_float(a.u0);
+        for (int i = tid; i < 28 * hd; i += 256) { const int q = i / hd, cc = i - q * hd; Qs[i] = a.p0[q * d + h * hd + cc]; }
+        for (int i = tid; i < NKk * hd; i += 256) {
+            const int k = i / hd, cc = i - k * hd;
+            const float* row = a.p1 + ((int64_t)b * NKk + k) * 2 * d + h * hd + cc;
+            Ks[k * (hd + 1) + cc] = row[0];
+            Vs[i] = row[d];
+        }
+        __syncthreads();
+        for (int i = tid; i < 28 * NKk; i += 256) {
+            const int q = i / NKk, k = i - q * NKk;
+            float sacc = 0.f;
+            for (int cc = 0; cc < hd; ++cc) sacc = fmaf(Qs[q * hd + cc], Ks[k * (hd + 1) + cc], sacc);
+            Ss[i] = scale * sacc;
+        }
+        __syncthreads();
+        for (int q = wv; q < 28; q += 4) {        // softmax of row q by one wave (NK <= 128)
+            const float v0 = lane < NKk ? Ss[q * NKk + lane] : -INFINITY, v1 = lane + 64 < NKk ? Ss[q * NKk + lane + 64] : -INFINITY;
+            float m = fmaxf(v0, v1);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            const float e0 = lane < NKk ? expf(v0 - m) : 0.f, e1 = lane + 64 < NKk ? expf(v1 - m) : 0.f;
+            float sum = e0 + e1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const int64_t prow = (((int64_t)b * H + h) * 28 + q) * NKk;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int k = lane + 64 * t;
+                if (k < NKk) {
+                    const float pv = (t ? e1 : e0) / sum;
+                    a.q0[prow + k] = pv;
+                    Ss[q * NKk + k] = a.mask ? (a.mask[prow + k] ? pv * a.f0 : 0.f) : pv;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 28 * hd; i += 256) {
+            const int q = i / hd, cc = i - q * hd;
+            float acc = 0.f;
+            for (int k = 0; k < NKk; ++k) acc = fmaf(Ss[q * NKk + k], Vs[k * hd + cc], acc);
+            a.q1[((int64_t)b * 28 + q) * d + h * hd + cc] = acc;
+        }
+        __syncthreads();
+        break;
+    }
+    case OP_ATTN_BWD: {     // one (window, head): dPd = dA_h V_h^T, dV_h = Pd^T dA_h, dS = softmax', dK_h = scale dS^T Q_h, dQ_h[b] = scale dS K_h
+        // p0 Q, p1 KV, p2 P, p3 dA (B * 28, d); q0 dKV (R, 2d), q1 dQ partial (B, 28, d)
+        const int d = a.i0, hd = a.i1, NKk = a.i2, H = a.i3;
+        const int b = vb / H, h = vb - b * H;
+        float* Qs = smem;                         // [28][hd]
+        float* Ks = Qs + 28 * hd;                 // [NK][hd + 1]
+        float* Vs = Ks + NKk * (hd + 1);          // [NK][hd + 1]
+        float* Gs = Vs + NKk * (hd + 1);          // [28][hd]   dA_h
+        float* Ps = Gs + 28 * hd;                 // [28][NK]   P
+        float* Ds = Ps + 28 * NKk;                // [28][NK]   dP, then dS
+        const float scale = __uint_as_float(a.u0);
+        const int64_t prow0 = ((int64_t)b * H + h) * 28 * NKk;
+        for (int i = tid; i < 28 * hd; i += 256) {
+            const int q = i / hd, cc = i - q * hd;
+            Qs[i] = a.p0[q * d + h * hd + cc];
+            Gs[i] = a.p3[((int64_t)b * 28 + q) * d + h * hd + cc];
+        }
+        for (int i = tid; i < NKk * hd; i += 256) {
+            const int k = i / hd, cc = i - k * hd;
+            const float* row = a.p1 + ((int64_t)b * NKk + k) * 2 * d + h * hd + cc;
+            Ks[k * (hd + 1) + cc] = row[0];
+            Vs[k * (hd + 1) + cc] = row[d];
+        }
+        for (int i = tid; i < 28 * NKk; i += 256) {     // P, and Pd = P keep / (1 - p) in the image that later holds dP
+            const float pv = a.p2[prow0 + i];
+            Ps[i] = pv;
+            Ds[i] = a.mask ? (a.mask[prow0 + i] ? pv * a.f0 : 0.f) : pv;
+        }
+        __syncthreads();
+        for (int i = tid; i < NKk * hd; i += 256) {     // dV_h = Pd^T dA_h
+            const int k = i / hd, cc = i - k * hd;
+            float acc = 0.f;
+            for (int q = 0; q < 28; ++q) acc = fmaf(Ds[q * NKk + k], Gs[q * hd + cc], acc);
+            a.q0[((int64_t)b * NKk + k) * 2 * d + d + h * hd + cc] = acc;
+        }
+        __syncthreads();
+        for (int i = tid; i < 28 * NKk; i += 256) {     // dP = (dA_h V_h^T) keep / (1 - p)
+            const int q = i / NKk, k = i - q * NKk;
+            float acc = 0.f;
+            for (int cc = 0; cc < hd; ++cc) acc = fmaf(Gs[q * hd + cc], Vs[k * (hd + 1) + cc], acc);
+            Ds[i] = a.mask ? (a.mask[prow0 + i] ? acc * a.f0 : 0.f) : acc;
+        }
+        __syncthreads();
+        for (int q = wv; q < 28; q += 4) {              // dS = P (dP - sum(dP P))
+            const float p0 = lane < NKk ? Ps[q * NKk + lane] : 0.f, p1 = lane + 64 < NKk ? Ps[q * NKk + lane + 64] : 0.f;
+            const float g0 = lane < NKk ? Ds[q * NKk + lane] : 0.f, g1 = lane + 64 < NKk ? Ds[q * NKk + lane + 64] : 0.f;
+            float sacc = g0 * p0 + g1 * p1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+            if (lane < NKk) Ds[q * NKk + lane] = p0 * (g0 - sacc);
+            if (lane + 64 < NKk) Ds[q * NKk + lane + 64] = p1 * (g1 - sacc);
+        }
+        __syncthreads();
+        for (int i = tid; i < NKk * hd; i += 256) {     // dK_h = scale dS^T Q_h
+            const int k = i / hd, cc = i - k * hd;
+            float acc = 0.f;
+            for (int q = 0; q < 28; ++q) acc = fmaf(Ds[q * NKk + k], Qs[q * hd + cc], acc);
+            a.q0[((int64_t)b * NKk + k) * 2 * d + h * hd + cc] = scale * acc;
+        }
+        for (int i = tid; i < 28 * hd; i += 256) {      // dQ_h of this window = scale dS K_h
+            const int q = i / hd, cc = i - q * hd;
+            float acc = 0.f;
+            for (int k = 0; k < NKk; ++k) acc = fmaf(Ds[q * NKk + k], Ks[k * (hd + 1) + cc], acc);
+            a.q1[((int64_t)b * 28 + q) * d + h * hd + cc] = scale * acc;
+        }
+        __syncthreads();
+        break;
+    }
     default: break;
     }
 }
 
 __global__ __launch_bounds__(256) void phase_kernel(Phase p) {
-    __shared__ __attribute__((aligned(16))) float smem[ggd::LDS_FLOATS];
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // the host sizes it for the phase's largest operation
     const int vb = blockIdx.x;
     int i = 0;
     while (i + 1 < p.n_ops && vb >= p.block_end[i]) ++i;            // workgroup-uniform
@@ -318,35 +353,48 @@ __global__ __launch_bounds__(256) void phase_kernel(Phase p) {
     if (op.kind == OP_GEMM) {
         const int per = op.gx * op.gy;
         const int bz = local / per, t = local - bz * per;
-        gemm_tile_dev<4>(op.g, t % op.gx, t / op.gx, bz, smem);
+        const int tx = t % op.gx, ty = t / op.gx;
+        // operand B of the channel encoder (rows of 259 floats) is the one product without 16-byte rows
+        if (op.bm == 32) {
+            if (op.va && op.vb) gemm_tile_dev<32, 4, true, true>(op.g, tx, ty, bz, smem);
+            else if (op.va) gemm_tile_dev<32, 4, true, false>(op.g, tx, ty, bz, smem);
+            else gemm_tile_dev<32, 4, false, false>(op.g, tx, ty, bz, smem);
+        } else {
+            if (op.va && op.vb) gemm_tile_dev<64, 4, true, true>(op.g, tx, ty, bz, smem);
+            else if (op.va) gemm_tile_dev<64, 4, true, false>(op.g, tx, ty, bz, smem);
+            else gemm_tile_dev<64, 4, false, false>(op.g, tx, ty, bz, smem);
+        }
     } else {
         op_elem(op, local, smem);
     }
 }
 
-__global__ __launch_bounds__(256) void trainp_tail_kernel(TailArgs a, float* d_b2, int* drop_ctr) {
-    train_tail_dev<4>(a);
+// 1024 threads: 16 waves compute the 52 B decoder logits (one row per wave at a time) before the loss tail proper
+__global__ __launch_bounds__(1024) void trainp_tail_kernel(TailArgs a, float* d_b2, int* drop_ctr) {
+    train_tail_dev<16>(a);
     // decoder output bias: sum of every logit gradient, in a fixed order (row_grads_kernel of the chain)
-    __shared__ float red[256];
+    __shared__ float red[1024];
     __syncthreads();
     float s = 0.f;
-    for (int i = threadIdx.x; i < a.B * 52; i += 256) s += a.dz[i];
+    for (int i = threadIdx.x; i < a.B * 52; i += 1024) s += a.dz[i];
     red[threadIdx.x] = s;
     __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int k = 0; k < 256; ++k) t += red[k];
-        d_b2[0] = t;
+        d_b2[0] = red[0];
         if (drop_ctr) drop_ctr[0] += 1;           // the next step draws fresh dropout masks
     }
 }
 
 // ---- host: building and launching the program ----------------------------------------------------------------
 struct Program {
-    std::vector<Phase> phases;
     Phase cur{};
     int blocks = 0;
     int rc = KM_OK;
+    size_t lds = 0;
     void add(const Op& op, int nblocks) {
         if (nblocks <= 0) return;
         if (cur.n_ops >= kMaxOps) { rc = fail(KM_ERR_UNSUPPORTED, "training program: more than %d operations in one phase", kMaxOps); return; }
@@ -358,9 +406,24 @@ struct Program {
     void gemm(const GemmArgs& g, int batch) {
         Op op{};
         op.kind = OP_GEMM; op.g = g;
-        op.gx = (g.N + 63) / 64; op.gy = (g.M + 63) / 64;
+        op.gx = (g.N + 63) / 64; op.gy = (g.M + 63) / 64; op.bm = 64;
+        if (g.M <= 32 || op.gx * op.gy * batch < 192) { op.bm = 32; op.gy = (g.M + 31) / 32; }   // finer tiles: more CUs, half the chain
+        need_lds((size_t)ggd::lds_floats(op.bm) * sizeof(float));
+        if ((g.a_cs != 1 && g.a_rs != 1) || (g.b_rs != 1 && g.b_cs != 1)) {
+            rc = fail(KM_ERR_UNSUPPORTED, "training program: an operand is contiguous neither along k nor along its rows");
+            return;
+        }
+        if (gemm_operand_extent(g.M, g.a_rs, g.K, g.a_cs, g.kb_count, g.a_kbs) >= ((int64_t)1 << 29) ||
+            gemm_operand_extent(g.N, g.b_cs, g.K, g.b_rs, g.kb_count, g.b_kbs) >= ((int64_t)1 << 29)) {
+            rc = fail(KM_ERR_UNSUPPORTED, "training program: operand larger than the 2 GiB a buffer descriptor addresses");
+            return;
+        }
+        op.va = gemm_operand_vec(g.A, g.a_rs, g.a_cs, g.a_bs1, g.a_bs2, g.a_kbs) ? 1 : 0;
+        op.vb = gemm_operand_vec(g.B, g.b_cs, g.b_rs, g.b_bs1, g.b_bs2, g.b_kbs) ? 1 : 0;
+        if (!op.va) op.vb = 0;                   // three instantiations: (vec, vec), (vec, scalar), (scalar, scalar)
         add(op, op.gx * op.gy * batch);
     }
+    void need_lds(size_t bytes) { if (bytes > lds) lds = bytes; }
     void elem(int kind, const ElemArgs& e, int64_t nblocks) {
         Op op{};
         op.kind = kind; op.e = e;
@@ -369,11 +432,12 @@ struct Program {
     int end_phase(hipStream_t st) {
         if (rc) return rc;
         if (cur.n_ops > 0) {
-            hipLaunchKernelGGL(phase_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cur);
+            hipLaunchKernelGGL(phase_kernel, dim3((unsigned)blocks), dim3(256), lds, st, cur);
             HIP_TRY(hipGetLastError());
         }
         cur = Phase{};
         blocks = 0;
+        lds = 0;
         return KM_OK;
     }
 };
@@ -480,19 +544,18 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     float* Qb = take(28 * d); float* dQb = take(28 * d);
     float* T1m = take(d * d); float* T1e = take(d * d); float* Wfm = take(DH * d); float* Wfe = take(DH * d);
     float* t1m = take(d); float* t1e = take(d); float* bfm = take(DH); float* bfe = take(DH);
-    float* part_lnm = take(32 * 2 * d); float* part_lne = take(32 * 2 * d);
-    float* part_a = take(32 * 2 * d); float* part_b = take(32 * 2 * d); float* part_c = take(32 * 2 * d);
+    float* ones = take(c->tr_windows * NKk);
     // per-window part
     float* Y0 = take(R * d); float* Y = take(R * d); float* mu = take(R); float* rs = take(R);
     float* KV = take(R * 2 * d);
-    float* Pm = take(B * H * 28 * NKk); float* Pd = take(B * H * 28 * NKk); float* dP = take(B * H * 28 * NKk); float* dS = take(B * H * 28 * NKk);
+    float* Pm = take(B * H * 28 * NKk);
     float* A = take(Rm * d); float* O1 = take(Rm * d); float* O2 = take(Rm * d); float* H1 = take(Rm * DH);
     float* Ae = take(Re * d); float* Oe1 = take(Re * d); float* Oe2 = take(Re * d); float* He = take(Re * DH);
-    float* zrows = take(Rm + Re);
+    float* zrows = take(Rm + Re); float* grow = take(Rm + Re);
     float* dH1 = take(Rm * DH); float* dHe = take(Re * DH);
     float* dA = take(Rm * d); float* dO2 = take(Rm * d); float* dO1 = take(Rm * d);
     float* dAe = take(Re * d); float* dOe2 = take(Re * d); float* dOe1 = take(Re * d);
-    float* dKV = take(R * 2 * d); float* dY = take(R * d); float* dY0 = take(R * d);
+    float* dKV = take(R * 2 * d); float* dY = take(R * d); float* dY0 = take(R * d); float* Tm = take(R * d); float* Te = take(B * d);
     float* E0 = take(B * d); float* E = take(B * d); float* Ve = take(B * d); float* dVe = take(B * d); float* dE = take(B * d); float* dE0 = take(B * d);
     float* emu = take(B); float* ers = take(B);
     float* bs = take(B * 52); float* outb = take(B * 52); float* dz = take(B * 52); float* tfac = take(B * 52); float* txp = take(B * 52);
@@ -521,38 +584,49 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     float* gin_w = Gd("mel_attention.in_proj_weight"); float* gin_b = Gd("mel_attention.in_proj_bias");
     float* gein_w = Gd("emotion_attention.in_proj_weight"); float* gein_b = Gd("emotion_attention.in_proj_bias");
 
+    static PerDeviceOnce once;
+    if (once.first(c->device))
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&phase_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const size_t attn_lds = (size_t)(2 * 28 * hd + 2 * NKk * (hd + 1) + 2 * 28 * NKk) * sizeof(float);
+    if (attn_lds > 160 * 1024) return fail(KM_ERR_UNSUPPORTED, "attention head too large for the fused training kernels");
+
     Program pg;
     auto blocks4 = [](int64_t rows) { return (rows + 3) / 4; };            // one wave per row, 4 rows per block
     auto blocks256 = [](int64_t n) { return (n + 255) / 256; };
-    auto colsum = [&](const float* m, int64_t rows, int64_t rs_, int n, float* out, int accumulate, int map, const float* dzp) {
-        ElemArgs e{};                                                     // single split: rows are few (<= 512 per split by construction below)
-        e.p0 = m; e.p1 = dzp; e.n0 = rows; e.n1 = rs_; e.i0 = n; e.i1 = accumulate; e.i2 = 1; e.i3 = map; e.q0 = out;
-        pg.elem(OP_COLSUM, e, (n + 63) / 64);
-    };
-    // column sum over many rows: split partials now, the fixed-order sum in a later phase (returns the split count)
-    auto colsum_split = [&](const float* m, int64_t rows, int64_t rs_, int n, float* part) -> int {
-        const int S = split_rows(rows);
-        ElemArgs e{};
-        e.p0 = m; e.n0 = rows; e.n1 = rs_; e.i0 = n; e.i1 = 0; e.i2 = S; e.i3 = 0; e.q0 = part;
-        pg.elem(OP_COLSUM, e, (int64_t)S * ((n + 63) / 64));
-        return S;
+    // column sums as products with a vector: out (1 x n) (+)= w^T (1 x rows) M (rows x n); w = ones, or per-row loss gradients
+    auto colsum = [&](const float* m, int64_t rows, int64_t rs_, int64_t n, float* out, int accumulate, const float* wvec) {
+        GemmArgs g = G(wvec, 0, 1, m, rs_, 1, out, n, 1, n, rows);
+        g.beta = accumulate ? 1.f : 0.f;
+        pg.gemm(g, 1);
     };
     auto reduce = [&](const float* part, int S, int64_t n, int64_t stride, float* out, int accumulate) {
         ElemArgs e{};
         e.p0 = part; e.i0 = S; e.n0 = n; e.n1 = stride; e.q0 = out; e.i1 = accumulate;
         pg.elem(OP_REDUCE, e, blocks256(n));
     };
+    unsigned scale_bits;
+    std::memcpy(&scale_bits, &scale, sizeof(scale_bits));
 
-    // ================= P0: clean bucket, masks, packed input, input-independent products =================
+    // ================= P0: clean bucket, ones, masks, packed input, input-independent products =================
     {
         ElemArgs e{};
         e.q0 = flat_grad; e.n0 = c->tr_nparams;
         pg.elem(OP_ZERO, e, (c->tr_nparams + 1023) / 1024);
+        if (xp_dev && c->melmax_dirty) {      // the front end that just ran left its window maxima behind: clean slots for the next one
+            ElemArgs z{};
+            z.q0 = reinterpret_cast<float*>(c->ws_melmax); z.n0 = c->ws_windows;
+            pg.elem(OP_ZERO, z, (c->ws_windows + 1023) / 1024);
+            c->melmax_dirty = false;
+        }
+        ElemArgs f{};
+        f.q0 = ones; f.n0 = R; f.f0 = 1.0f;
+        pg.elem(OP_FILL, f, blocks256(R));
     }
     if (drop && c->tr_dropout_mode == 0) {
         int64_t nm, ne, nd;
         trainp_mask_sizes(c, B, &nm, &ne, &nd);
-        const unsigned thr = (unsigned)std::llround((double)p_drop * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (double)p_drop * 4294967296.0);
+        const double t32 = (double)p_drop * 4294967296.0;
+        const unsigned thr = (unsigned)(t32 > 4294967295.0 ? 4294967295.0 : t32);
         unsigned char* regions[3] = {ms.mel, ms.emo, ms.dec};
         const int64_t sizes[3] = {nm, ne, nd};
         for (int r = 0; r < 3; ++r) {
@@ -607,90 +681,62 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         pg.elem(OP_EMO_EXPAND, e, blocks256(Re * d));
     }
     RUN(pg.end_phase(st));
-    // ================= P4: scores; emotion rows through the folded decoder input + their out_proj =================
+    // ================= P4: attention (scores, softmax, dropout, P V) per (window, head); emotion rows through the fold =================
     {
-        GemmArgs g = G(Qb, d, 1, KV, 1, 2 * d, Pm, NKk, 28, NKk, hd);
-        g.alpha = scale; g.batch2 = (int)H; g.a_bs2 = hd; g.b_bs1 = NKk * 2 * d; g.b_bs2 = hd;
-        g.c_bs1 = H * 28 * NKk; g.c_bs2 = 28 * NKk;
-        pg.gemm(g, (int)(B * H));
+        ElemArgs e{};
+        e.p0 = Qb; e.p1 = KV; e.q0 = Pm; e.q1 = A; e.i0 = (int)d; e.i1 = (int)hd; e.i2 = (int)NKk; e.i3 = (int)H;
+        e.mask = m_mel; e.f0 = keep_scale; e.u0 = scale_bits;
+        pg.need_lds(attn_lds);
+        pg.elem(OP_ATTN_FWD, e, B * H);
     }
     { GemmArgs g = NT(Ae, d, Wfe, d, He, DH, Re, DH, bfe, 1); g.drop = m_dec; g.drop_scale = keep_scale; g.drop_map = 2; pg.gemm(g, 1); }
     pg.gemm(NT(Ae, d, Woe, d, Oe1, d, Re, d, boe, 0), 1);
     RUN(pg.end_phase(st));
-    // ================= P5: softmax + attention dropout; emotion logits; Oe2 =================
-    {
-        ElemArgs e{};
-        e.p0 = Pm; e.q0 = Pm; e.q1 = Pd; e.n0 = B * H * 28; e.i0 = (int)NKk; e.mask = m_mel; e.f0 = keep_scale;
-        pg.elem(OP_SOFTMAX_DROP, e, blocks4(B * H * 28));
-    }
-    {
-        ElemArgs e{};
-        e.p0 = He; e.p1 = w2; e.p2 = b2; e.q0 = zrows + Rm; e.n0 = Re; e.i0 = (int)DH;
-        pg.elem(OP_ROWDOT, e, blocks4(Re));
-    }
-    pg.gemm(NT(Oe1, d, Weo, d, Oe2, d, Re, d, beo, 0), 1);
-    RUN(pg.end_phase(st));
-    // ================= P6: A[b][:, h] = Pd V_h =================
-    {
-        GemmArgs g = G(Pd, NKk, 1, KV + d, 2 * d, 1, A, d, 28, hd, NKk);
-        g.batch2 = (int)H; g.a_bs1 = H * 28 * NKk; g.a_bs2 = 28 * NKk; g.b_bs1 = NKk * 2 * d; g.b_bs2 = hd;
-        g.c_bs1 = 28 * d; g.c_bs2 = hd;
-        pg.gemm(g, (int)(B * H));
-    }
-    RUN(pg.end_phase(st));
-    // ================= P7: decoder hidden through the fold (+ ReLU + dropout); O1 beside it =================
+    // ================= P5: decoder hidden through the fold (+ ReLU + dropout); O1, Oe2 beside it =================
     { GemmArgs g = NT(A, d, Wfm, d, H1, DH, Rm, DH, bfm, 1); g.drop = m_dec; g.drop_scale = keep_scale; g.drop_map = 1; pg.gemm(g, 1); }
     pg.gemm(NT(A, d, Wo, d, O1, d, Rm, d, bo, 0), 1);
+    pg.gemm(NT(Oe1, d, Weo, d, Oe2, d, Re, d, beo, 0), 1);
     RUN(pg.end_phase(st));
-    // ================= P8: mouth logits; O2 =================
-    {
-        ElemArgs e{};
-        e.p0 = H1; e.p1 = w2; e.p2 = b2; e.q0 = zrows; e.n0 = Rm; e.i0 = (int)DH;
-        pg.elem(OP_ROWDOT, e, blocks4(Rm));
-    }
-    pg.gemm(NT(O1, d, Wmo, d, O2, d, Rm, d, bmo, 0), 1);
-    RUN(pg.end_phase(st));
-    // ================= P9: loss tail =================
+    // ================= P6: decoder output layer + loss tail (one workgroup) =================
     {
         TailArgs t{};
-        t.zrows = zrows; t.h1 = H1; t.he = He; t.w2 = w2; t.b2 = b2;
+        t.zrows = zrows; t.zrows_out = zrows; t.grow = grow; t.h1 = H1; t.he = He; t.w2 = w2; t.b2 = b2;
         t.mel_w = P("mel_weights"); t.emo_w = P("emotion_weights"); t.temperature = c->cfg.temperature; t.target = target;
         t.bs = bs; t.out = outb; t.dz = dz; t.ema_state = ema_state; t.ema_first = ema_first; t.alpha_p = P("smoothing_alpha");
         t.mse_w = mse_w; t.l1_w = l1_w; t.lc = c->tr_loss_cfg; t.fac = tfac; t.xp = txp; t.loss = loss_dev;
         t.d_melw = Gd("mel_weights"); t.d_emow = Gd("emotion_weights"); t.d_alpha = Gd("smoothing_alpha");
-        t.B = (int)B; t.DH = (int)DH; t.expr_rows = 24; t.audio_energy = c->tr_loss_cfg.audio_energy_dev;
-        hipLaunchKernelGGL(trainp_tail_kernel, dim3(1), dim3(256), 0, st, t, Gd("blendshape_decoder.3.bias"),
+        t.B = (int)B; t.DH = (int)DH; t.expr_rows = 24; t.audio_energy = c->tr_loss_cfg.audio_energy_dev; t.out2 = out_dev;
+        hipLaunchKernelGGL(trainp_tail_kernel, dim3(1), dim3(1024), 0, st, t, Gd("blendshape_decoder.3.bias"),
                            (drop && c->tr_dropout_mode == 0) ? c->trp_drop_ctr : nullptr);
         HIP_TRY(hipGetLastError());
-        if (out_dev) HIP_TRY(hipMemcpyAsync(out_dev, outb, (size_t)B * 52 * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
-    // ================= P10: decoder output layer backward =================
+    // ================= P7: decoder output layer backward; O2 (needed from P8 on) =================
     {
         ElemArgs e{};
-        e.p0 = dz; e.p1 = H1; e.p2 = w2; e.q0 = dH1; e.n0 = Rm; e.i0 = (int)DH; e.i1 = 1; e.f0 = keep_scale;
+        e.p0 = grow; e.p1 = H1; e.p2 = w2; e.q0 = dH1; e.n0 = Rm; e.i0 = (int)DH; e.f0 = keep_scale;
         pg.elem(OP_RELU_OUTER, e, blocks256(Rm * DH));
-        e.p1 = He; e.q0 = dHe; e.n0 = Re; e.i1 = 2;
+        e.p0 = grow + Rm; e.p1 = He; e.q0 = dHe; e.n0 = Re;
         pg.elem(OP_RELU_OUTER, e, blocks256(Re * DH));
     }
-    colsum(H1, Rm, DH, (int)DH, Gd("blendshape_decoder.3.weight"), 0, 1, dz);                              // dw2 = sum_r dz(r) H1[r]
+    colsum(H1, Rm, DH, DH, Gd("blendshape_decoder.3.weight"), 0, grow);                                     // dw2 = sum_r g[r] H1[r]
+    pg.gemm(NT(O1, d, Wmo, d, O2, d, Rm, d, bmo, 0), 1);
     RUN(pg.end_phase(st));
-    // ================= P11: input gradients through the fold; decoder[0] parameter gradients =================
+    // ================= P8: input gradients through the fold; decoder[0] parameter gradients =================
     pg.gemm(NN(dH1, DH, Wfm, d, dA, d, Rm, d, DH), 1);
     pg.gemm(NN(dHe, DH, Wfe, d, dAe, d, Re, d, DH), 1);
     pg.gemm(NN(dH1, DH, W1, d, dO2, d, Rm, d, DH), 1);
     pg.gemm(NN(dHe, DH, W1, d, dOe2, d, Re, d, DH), 1);
     pg.gemm(TN(dH1, DH, O2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, Rm), 1);
-    colsum(dH1, Rm, DH, (int)DH, Gd("blendshape_decoder.0.bias"), 0, 0, nullptr);
-    colsum(He, Re, DH, (int)DH, Gd("blendshape_decoder.3.weight"), 1, 2, dz);
+    colsum(dH1, Rm, DH, DH, Gd("blendshape_decoder.0.bias"), 0, ones);
+    colsum(He, Re, DH, DH, Gd("blendshape_decoder.3.weight"), 1, grow + Rm);
     RUN(pg.end_phase(st));
-    // ================= P12: attention backward (dPd, dV); emotion value gradient; output projections =================
+    // ================= P9: attention backward per (window, head); emotion value gradient; output projections =================
     {
-        GemmArgs g = G(dA, d, 1, KV + d, 1, 2 * d, dP, NKk, 28, NKk, hd);                                   // dPd = dA_h V_h^T
-        g.batch2 = (int)H; g.a_bs1 = 28 * d; g.a_bs2 = hd; g.b_bs1 = NKk * 2 * d; g.b_bs2 = hd; g.c_bs1 = H * 28 * NKk; g.c_bs2 = 28 * NKk;
-        pg.gemm(g, (int)(B * H));
-        g = G(Pd, 1, NKk, dA, d, 1, dKV + d, 2 * d, NKk, hd, 28);                                           // dV_h = Pd^T dA_h
-        g.batch2 = (int)H; g.a_bs1 = H * 28 * NKk; g.a_bs2 = 28 * NKk; g.b_bs1 = 28 * d; g.b_bs2 = hd; g.c_bs1 = NKk * 2 * d; g.c_bs2 = hd;
-        pg.gemm(g, (int)(B * H));
+        ElemArgs e{};
+        e.p0 = Qb; e.p1 = KV; e.p2 = Pm; e.p3 = dA; e.q0 = dKV; e.q1 = dQ_part; e.i0 = (int)d; e.i1 = (int)hd; e.i2 = (int)NKk; e.i3 = (int)H;
+        e.mask = m_mel; e.f0 = keep_scale; e.u0 = scale_bits;
+        pg.need_lds(attn_lds);
+        pg.elem(OP_ATTN_BWD, e, B * H);
     }
     {
         ElemArgs e{};
@@ -701,86 +747,54 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     pg.gemm(NN(dOe2, d, Weo, d, dOe1, d, Re, d, d), 1);
     pg.gemm(TN(dO2, d, O1, d, Gd("mel_output_proj.weight"), d, d, d, Rm), 1);
     pg.gemm(TN(dOe2, d, Oe1, d, Gd("emotion_output_proj.weight"), d, d, d, Re), 1);
-    colsum(dO2, Rm, d, (int)d, Gd("mel_output_proj.bias"), 0, 0, nullptr);
-    colsum(dOe2, Re, d, (int)d, Gd("emotion_output_proj.bias"), 0, 0, nullptr);
+    colsum(dO2, Rm, d, d, Gd("mel_output_proj.bias"), 0, ones);
+    colsum(dOe2, Re, d, d, Gd("emotion_output_proj.bias"), 0, ones);
     { GemmArgs g = TN(dHe, DH, Oe2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, Re); g.beta = 1.f; pg.gemm(g, 1); }
-    colsum(dHe, Re, DH, (int)DH, Gd("blendshape_decoder.0.bias"), 1, 0, nullptr);
+    colsum(dHe, Re, DH, DH, Gd("blendshape_decoder.0.bias"), 1, ones);
     RUN(pg.end_phase(st));
-    // ================= P13: softmax backward; out_proj gradients; emotion value projection backward =================
-    {
-        ElemArgs e{};
-        e.p0 = dP; e.p1 = Pm; e.q0 = dS; e.n0 = B * H * 28; e.i0 = (int)NKk; e.mask = m_mel; e.f0 = keep_scale;
-        pg.elem(OP_SOFTMAX_BWD, e, blocks4(B * H * 28));
-    }
-    pg.gemm(TN(dO1, d, A, d, Gd("mel_attention.out_proj.weight"), d, d, d, Rm), 1);
-    pg.gemm(TN(dOe1, d, Ae, d, Gd("emotion_attention.out_proj.weight"), d, d, d, Re), 1);
-    colsum(dO1, Rm, d, (int)d, Gd("mel_attention.out_proj.bias"), 0, 0, nullptr);
-    colsum(dOe1, Re, d, (int)d, Gd("emotion_attention.out_proj.bias"), 0, 0, nullptr);
-    pg.gemm(TN(dVe, d, E, d, gein_w + 2 * d * d, d, d, d, B), 1);                                           // only the V third of in_proj
-    colsum(dVe, B, d, (int)d, gein_b + 2 * d, 0, 0, nullptr);
-    pg.gemm(NN(dVe, d, einw + 2 * d * d, d, dE, d, B, d, d), 1);
-    RUN(pg.end_phase(st));
-    // ================= P14: dK, dQ (per-window partials); emotion LayerNorm backward =================
-    {
-        GemmArgs g = G(dS, 1, NKk, Qb, d, 1, dKV, 2 * d, NKk, hd, 28);                                      // dK_h = scale dS^T Q_h
-        g.alpha = scale; g.batch2 = (int)H; g.a_bs1 = H * 28 * NKk; g.a_bs2 = 28 * NKk; g.b_bs2 = hd; g.c_bs1 = NKk * 2 * d; g.c_bs2 = hd;
-        pg.gemm(g, (int)(B * H));
-        g = G(dS, NKk, 1, KV, 2 * d, 1, dQ_part, d, 28, hd, NKk);                                           // dQ_h[b] = scale dS K_h
-        g.alpha = scale; g.batch2 = (int)H; g.a_bs1 = H * 28 * NKk; g.a_bs2 = 28 * NKk; g.b_bs1 = NKk * 2 * d; g.b_bs2 = hd;
-        g.c_bs1 = 28 * d; g.c_bs2 = hd;
-        pg.gemm(g, (int)(B * H));
-    }
-    {
-        ElemArgs e{};
-        e.p0 = dE; e.p1 = E0; e.p2 = emu; e.p3 = ers; e.n0 = B; e.n1 = B; e.i0 = (int)d;
-        e.q0 = Gd("emotion_norm.weight"); e.q1 = Gd("emotion_norm.bias");
-        pg.elem(OP_LN_PGRAD, e, (d + 63) / 64);
-        ElemArgs b{};
-        b.p0 = dE; b.p1 = E0; b.p2 = P("emotion_norm.weight"); b.p3 = emu; b.p4 = ers; b.q0 = dE0; b.n0 = B; b.i0 = (int)d;
-        pg.elem(OP_LN_BWD, b, blocks4(B));
-    }
-    RUN(pg.end_phase(st));
-    // ================= P15: dY; in_proj [K | V] gradients; dQ; emotion encoder gradients =================
+    // ================= P10: dY; in_proj [K | V] gradients; dQ; out_proj gradients; emotion value projection backward =================
     pg.gemm(NN(dKV, 2 * d, inw + d * d, d, dY, d, R, d, 2 * d), 1);
     pg.gemm(TN(dKV, 2 * d, Y, d, gin_w + d * d, d, 2 * d, d, R), 1);
-    const int S_kv = colsum_split(dKV, R, 2 * d, (int)(2 * d), part_a);
+    colsum(dKV, R, 2 * d, 2 * d, gin_b + d, 0, ones);
     reduce(dQ_part, (int)B, 28 * d, 28 * d, dQb, 0);
-    pg.gemm(TN(dE0, d, emo, ED, Gd("emotion_encoder.weight"), ED, d, ED, B), 1);
-    colsum(dE0, B, d, (int)d, Gd("emotion_encoder.bias"), 0, 0, nullptr);
+    pg.gemm(TN(dO1, d, A, d, Gd("mel_attention.out_proj.weight"), d, d, d, Rm), 1);
+    pg.gemm(TN(dOe1, d, Ae, d, Gd("emotion_attention.out_proj.weight"), d, d, d, Re), 1);
+    colsum(dO1, Rm, d, d, Gd("mel_attention.out_proj.bias"), 0, ones);
+    colsum(dOe1, Re, d, d, Gd("emotion_attention.out_proj.bias"), 0, ones);
+    pg.gemm(TN(dVe, d, E, d, gein_w + 2 * d * d, d, d, d, B), 1);                                           // only the V third of in_proj
+    colsum(dVe, B, d, d, gein_b + 2 * d, 0, ones);
+    pg.gemm(NN(dVe, d, einw + 2 * d * d, d, dE, d, B, d, d), 1);
     RUN(pg.end_phase(st));
-    // ================= P16: LayerNorm backward + its parameter gradients; query-side gradients =================
-    const int S_ln = split_rows(R);
+    // ================= P11: LayerNorm backward (both streams); query-side gradients =================
     {
-        ElemArgs e{};
-        e.p0 = dY; e.p1 = Y0; e.p2 = mu; e.p3 = rs; e.n0 = R; e.n1 = (R + S_ln - 1) / S_ln; e.i0 = (int)d;
-        e.q0 = S_ln == 1 ? Gd("mel_norm.weight") : part_lnm; e.q1 = S_ln == 1 ? Gd("mel_norm.bias") : part_lnm + 32 * d;
-        pg.elem(OP_LN_PGRAD, e, (int64_t)S_ln * ((d + 63) / 64));
         ElemArgs b{};
-        b.p0 = dY; b.p1 = Y0; b.p2 = P("mel_norm.weight"); b.p3 = mu; b.p4 = rs; b.q0 = dY0; b.n0 = R; b.i0 = (int)d;
+        b.p0 = dY; b.p1 = Y0; b.p2 = P("mel_norm.weight"); b.p3 = mu; b.p4 = rs; b.q0 = dY0; b.q1 = Tm; b.n0 = R; b.i0 = (int)d;
         pg.elem(OP_LN_BWD, b, blocks4(R));
+        ElemArgs e{};
+        e.p0 = dE; e.p1 = E0; e.p2 = P("emotion_norm.weight"); e.p3 = emu; e.p4 = ers; e.q0 = dE0; e.q1 = Te; e.n0 = B; e.i0 = (int)d;
+        pg.elem(OP_LN_BWD, e, blocks4(B));
     }
-    reduce(part_a, S_kv, 2 * d, 2 * d, gin_b + d, 0);
     pg.gemm(TN(dQb, d, P("mouth_queries"), d, gin_w, d, d, d, 28), 1);
-    colsum(dQb, 28, d, (int)d, gin_b, 0, 0, nullptr);
+    colsum(dQb, 28, d, d, gin_b, 0, ones);
     pg.gemm(NN(dQb, d, inw, d, Gd("mouth_queries"), d, 28, d, d), 1);
     RUN(pg.end_phase(st));
-    // ================= P17: channel encoder gradients (per-window partials) =================
+    // ================= P12: channel encoder gradients (per-window partials); LayerNorm parameters; emotion encoder =================
     {
         GemmArgs g = G(dY0, 1, d, X, 1, NKk, dWce_part, KT, d, KT, NKk);                                    // dWce[b] = dY0_b^T X_b
         g.a_bs1 = NKk * d; g.b_bs1 = KP * NKk; g.c_bs1 = d * KT;
         pg.gemm(g, (int)B);
     }
-    const int S_ce = colsum_split(dY0, R, d, (int)d, part_b);
-    if (S_ln > 1) {
-        reduce(part_lnm, S_ln, d, d, Gd("mel_norm.weight"), 0);
-        reduce(part_lnm + 32 * d, S_ln, d, d, Gd("mel_norm.bias"), 0);
-    }
+    colsum(dY0, R, d, d, Gd("mel_channel_encoder.bias"), 0, ones);
+    colsum(Tm, R, d, d, Gd("mel_norm.weight"), 0, ones);
+    colsum(dY, R, d, d, Gd("mel_norm.bias"), 0, ones);
+    colsum(Te, B, d, d, Gd("emotion_norm.weight"), 0, ones);
+    colsum(dE, B, d, d, Gd("emotion_norm.bias"), 0, ones);
+    pg.gemm(TN(dE0, d, emo, ED, Gd("emotion_encoder.weight"), ED, d, ED, B), 1);
+    colsum(dE0, B, d, d, Gd("emotion_encoder.bias"), 0, ones);
     RUN(pg.end_phase(st));
-    // ================= P18: sum the partials =================
+    // ================= P13: sum the per-window partials of the channel encoder weight =================
     reduce(dWce_part, (int)B, d * KT, d * KT, Gd("mel_channel_encoder.weight"), 0);
-    reduce(part_b, S_ce, d, d, Gd("mel_channel_encoder.bias"), 0);
     RUN(pg.end_phase(st));
-    (void)part_lne; (void)part_c; (void)dQb; (void)gein_w;
     return KM_OK;
 }
 
