@@ -279,6 +279,15 @@ int km_audio_energy(const float* features_dev, int64_t B, int64_t T, int64_t D, 
  *                               oracle.core.core_forward(drop_masks=...)
  *   km_train_set_dropout_masks  the reverse (host -> device) */
 int km_train_set_dropout(km_handle h, float p, uint64_t seed, int32_t external_masks);
+
+/* Overlapping the data-parallel gradient all-reduce with the end of the backward pass (new construction: the reference is
+ * single-process).  The flat bucket is laid out so that the tensors the backward pass finishes last come last:
+ *   km_train_grad_split   *early_floats = E: floats [0, E) of flat_grad (83 % at d_model 256) are final after phase 10 of
+ *                         14 of km_train_step*, the rest when the call's work completes
+ *   km_train_wait_early   make `stream` wait (hipStreamWaitEvent) for that point of the most recent km_train_step*: a
+ *                         side stream can then all-reduce flat_grad[0:E] while the launch stream still computes the tail */
+int km_train_grad_split(km_handle h, int64_t* early_floats);
+int km_train_wait_early(km_handle h, void* stream);
 int km_train_get_dropout_masks(km_handle h, int64_t B, uint8_t* mel_host, uint8_t* emo_host, uint8_t* dec_host, void* stream);
 int km_train_set_dropout_masks(km_handle h, int64_t B, const uint8_t* mel_host, const uint8_t* emo_host, const uint8_t* dec_host,
                                void* stream);

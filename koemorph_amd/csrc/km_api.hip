@@ -240,10 +240,22 @@ int km_train_init(km_handle h, int64_t max_windows, void* stream) {
     if (max_windows <= 0) return fail(KM_ERR_INVALID_ARG, "km_train_init: bad max_windows");
     if (int rc = free_train(c)) return rc;
     c->tr_offset.clear();
+    // Flat layout: state-dict order within two groups; every offset a multiple of 4 floats (16 B).  The second group holds
+    // the tensors whose gradients the backward pass finishes LAST (channel encoder, LayerNorm parameters, emotion encoder,
+    // mouth queries: 17 % of the bucket), so the all-reduce of the first 83 % can start while they are still being
+    // computed (km_train_grad_split / km_train_wait_early).
+    auto late = [](const std::string& k) {
+        return k == "mouth_queries" || k.rfind("mel_channel_encoder.", 0) == 0 || k.rfind("mel_norm.", 0) == 0 ||
+               k.rfind("emotion_norm.", 0) == 0 || k.rfind("emotion_encoder.", 0) == 0;
+    };
     int64_t off = 0;
-    for (const auto& k : c->param_order) {            // state-dict order; every offset a multiple of 4 floats (16 B)
-        c->tr_offset[k] = off;
-        off += ((int64_t)c->params.at(k).data.size() + 3) / 4 * 4;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) c->tr_early = off;
+        for (const auto& k : c->param_order) {
+            if (late(k) != (pass == 1)) continue;
+            c->tr_offset[k] = off;
+            off += ((int64_t)c->params.at(k).data.size() + 3) / 4 * 4;
+        }
     }
     c->tr_nparams = off;
     const size_t nb = (size_t)off * sizeof(float);
@@ -340,6 +352,20 @@ int km_train_step_audio(km_handle h, const float* audio_dev, int64_t B, int64_t 
     if (int rc = launch_mel(c, c->mel_plans[0], audio_dev, B, L, 0, c->ws_mel, c->ws_short, stream)) return rc;
     return train_forward_backward(c, c->ws_mel, B, n_frames, c->ws_short, emotion_dev, target_dev, mse_weight, l1_weight,
                                   flat_grad_dev, loss_dev, out_dev, ema_state_dev, ema_first, stream);
+}
+
+int km_train_grad_split(km_handle h, int64_t* early_floats) {
+    if (int rc = need_train(h, 1)) return rc;
+    if (!early_floats) return fail(KM_ERR_INVALID_ARG, "km_train_grad_split: NULL argument");
+    *early_floats = h->opt.train_chain ? h->tr_nparams : h->tr_early;      // the chain finishes everything at its last join
+    return KM_OK;
+}
+
+int km_train_wait_early(km_handle h, void* stream) {
+    if (int rc = need_train(h, 1)) return rc;
+    if (!h->tr_early_recorded) return fail(KM_ERR_NOT_READY, "km_train_wait_early: no phased training step has run yet");
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)h->tr_ev[0], 0));
+    return KM_OK;
 }
 
 int km_train_set_dropout(km_handle h, float p, uint64_t seed, int32_t external_masks) {

@@ -121,6 +121,8 @@ struct Context {
     int64_t stream_out_frames = 0;
     // training state (km_train_*): flat fp32 master parameters + AdamW moments on the device, in state-dict order
     int64_t tr_nparams = 0, tr_windows = 0;
+    int64_t tr_early = 0;            // floats [0, tr_early) of the gradient bucket are final when tr_ev[0] fires (phased step)
+    bool tr_early_recorded = false;
     std::map<std::string, int64_t> tr_offset;
     float* tr_params = nullptr; float* tr_m = nullptr; float* tr_v = nullptr;
     float* tr_act = nullptr; float* tr_q = nullptr; float* tr_dq = nullptr; float* tr_part = nullptr; float* tr_gnorm = nullptr;

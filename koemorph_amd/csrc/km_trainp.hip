@@ -70,7 +70,8 @@ struct Op {
     };
 };
 
-constexpr int kMaxOps = 12;
+constexpr int kMaxOps = 14;
+static_assert(sizeof(GemmArgs) <= 208, "Phase has to stay under the 4 KB kernel-argument limit");
 struct Phase {
     int n_ops;
     int block_end[kMaxOps];
@@ -757,6 +758,13 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     pg.gemm(TN(dKV, 2 * d, Y, d, gin_w + d * d, d, 2 * d, d, R), 1);
     colsum(dKV, R, 2 * d, 2 * d, gin_b + d, 0, ones);
     reduce(dQ_part, (int)B, 28 * d, 28 * d, dQb, 0);
+    {   // query rows of in_proj straight from the per-window partials (contraction batch over the windows), so that the whole
+        // in_proj gradient is final here: dWq = sum_b dQ[b]^T mq, dbq = column sums over all B * 28 rows
+        GemmArgs g = TN(dQ_part, d, P("mouth_queries"), d, gin_w, d, d, d, 28);
+        g.kb_count = (int)B; g.a_kbs = 28 * d; g.b_kbs = 0;
+        pg.gemm(g, 1);
+        colsum(dQ_part, Rm, d, d, gin_b, 0, ones);
+    }
     pg.gemm(TN(dO1, d, A, d, Gd("mel_attention.out_proj.weight"), d, d, d, Rm), 1);
     pg.gemm(TN(dOe1, d, Ae, d, Gd("emotion_attention.out_proj.weight"), d, d, d, Re), 1);
     colsum(dO1, Rm, d, d, Gd("mel_attention.out_proj.bias"), 0, ones);
@@ -765,6 +773,9 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     colsum(dVe, B, d, d, gein_b + 2 * d, 0, ones);
     pg.gemm(NN(dVe, d, einw + 2 * d * d, d, dE, d, B, d, d), 1);
     RUN(pg.end_phase(st));
+    // everything but the "late" group of the bucket (km_train_init) is final: a side stream may start its all-reduce
+    HIP_TRY(hipEventRecord((hipEvent_t)c->tr_ev[0], st));
+    c->tr_early_recorded = true;
     // ================= P11: LayerNorm backward (both streams); query-side gradients =================
     {
         ElemArgs b{};
@@ -774,8 +785,6 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         e.p0 = dE; e.p1 = E0; e.p2 = P("emotion_norm.weight"); e.p3 = emu; e.p4 = ers; e.q0 = dE0; e.q1 = Te; e.n0 = B; e.i0 = (int)d;
         pg.elem(OP_LN_BWD, e, blocks4(B));
     }
-    pg.gemm(TN(dQb, d, P("mouth_queries"), d, gin_w, d, d, d, 28), 1);
-    colsum(dQb, 28, d, d, gin_b, 0, ones);
     pg.gemm(NN(dQb, d, inw, d, Gd("mouth_queries"), d, 28, d, d), 1);
     RUN(pg.end_phase(st));
     // ================= P12: channel encoder gradients (per-window partials); LayerNorm parameters; emotion encoder =================

@@ -15,6 +15,7 @@ nearest real criterion is ``KoeMorphLoss`` (src/model/losses.py:29) whose frame-
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -61,6 +62,8 @@ class Trainer:
         self.out = torch.zeros(max_windows, 52, device=self.device)
         self.ema_state = torch.zeros(max_windows, 52, device=self.device)
         self._ema_batch: Optional[int] = None
+        self._side = None                 # side stream of the overlapped gradient all-reduce
+        self._last_was_step = False       # the bucket was just produced by km_train_step* on this stream (its early event is fresh)
         self.step_count = 0
         self.epoch = 0
 
@@ -187,6 +190,7 @@ class Trainer:
                                       _ptr(emotion.contiguous()), _ptr(target.contiguous()), self.mse_weight,
                                       self.l1_weight, _ptr(self.flat_grad), _ptr(self.loss), _ptr(self.out), st, first,
                                       _stream_ptr(self.device)))
+        self._last_was_step = True
         return self.loss
 
     def forward_backward(self, audio, emotion, target):
@@ -197,12 +201,43 @@ class Trainer:
                                             _ptr(target.contiguous()), self.mse_weight, self.l1_weight,
                                             _ptr(self.flat_grad), _ptr(self.loss), _ptr(self.out), st, first,
                                             _stream_ptr(self.device)))
+        self._last_was_step = True
         return self.loss
+
+    def _allreduce_two_piece(self, weight: Optional[float], overlap: bool) -> None:
+        """The step's one gradient exchange, issued as two pieces: floats [0, E) of the bucket (83 %: everything but the
+        tensors the backward pass finishes last, km_train_grad_split) are reduced on a side stream that waits only for
+        phase 10 of the 14 (km_train_wait_early), i.e. while the launch stream still computes the LayerNorm / channel
+        encoder gradients; the rest follows on the launch stream when the step is done.  Every rank issues the same two
+        collectives whether or not it ran a step (a rank without windows contributes zeros): only the placement differs."""
+        import ctypes
+        early = ctypes.c_int64(0)
+        check(self._lib.km_train_grad_split(self._h, ctypes.byref(early)))
+        E = int(early.value)
+        if E <= 0 or E >= self.n_params:
+            parallel.allreduce_gradients(self.flat_grad, weight=weight)
+            return
+        if not overlap or os.environ.get("KM_ALLREDUCE_OVERLAP", "1") == "0":
+            parallel.allreduce_gradients(self.flat_grad[:E], weight=weight)
+            parallel.allreduce_gradients(self.flat_grad[E:], weight=weight)
+            return
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        check(self._lib.km_train_wait_early(self._h, self._side.cuda_stream))
+        with torch.cuda.stream(self._side):
+            parallel.allreduce_gradients(self.flat_grad[:E], weight=weight)
+        parallel.allreduce_gradients(self.flat_grad[E:], weight=weight)
+        main.wait_stream(self._side)
 
     def optimizer_step(self, weight: Optional[float] = None):
         """All-reduce + clip + AdamW.  ``weight`` = this rank's windows / windows of the global batch when the ranks'
         shares differ (see parallel.allreduce_gradients); None = equal shares."""
-        parallel.allreduce_gradients(self.flat_grad, weight=weight)         # the ONE collective of the training step
+        if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            self._allreduce_two_piece(weight, overlap=self._last_was_step)  # the ONE exchange of the training step
+        elif weight is not None:
+            self.flat_grad.mul_(float(weight))
+        self._last_was_step = False
         self.step_count += 1
         check(self._lib.km_train_adamw(self._h, _ptr(self.flat_grad), self.lr, self.betas[0], self.betas[1], self.eps,
                                        self.weight_decay, self.grad_clip if self.grad_clip else 0.0, self.step_count,

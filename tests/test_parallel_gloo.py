@@ -102,3 +102,35 @@ def test_bench_starts_its_own_ranks(n):
     d = json.loads(lines[0])
     assert d["n_gpus"] == n and d["rccl_ranks"] == n and d["steps"] == 4
     assert d["ms_per_step"] >= 10.0 * n * 0.9                 # the clock is the SLOWEST rank's (rank r sleeps 10 (r+1) ms per step)
+
+
+def _direct_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_from_env("gloo")
+    g = torch.Generator().manual_seed(100 + rank)
+    n = 837744 + 3                                             # not a multiple of the world size or of 4
+    mine = torch.randn(n, generator=g)
+    ref = sum(torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(world))
+    out = parallel.allreduce_sum_direct(mine.clone())
+    os.environ["KM_ALLREDUCE"] = "direct"
+    via = parallel.allreduce_gradients(mine.clone(), weight=1.0)
+    q.put((rank, bool(torch.allclose(out, ref, atol=1e-5)), bool(torch.equal(out, via)), out[:64].clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_direct_allreduce_world3():
+    """all-to-all + local sum in rank order + all-gather (the xGMI-shaped form of the gradient all-reduce): equals the
+    plain sum, and every rank ends with bit-identical values."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_direct_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] and r[2] for r in res)
+    assert torch.equal(res[0][3], res[1][3]) and torch.equal(res[0][3], res[2][3])
