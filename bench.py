@@ -349,15 +349,21 @@ def usable_cpus() -> int:
     return int(os.environ.get("KM_CPU_THREADS", min(n, 16)))
 
 
+def _cpu_front_one(y):
+    """One window of the numpy front end (worker of the CPU-baseline process pool; numpy only, never touches the GPU)."""
+    from oracle import mel as omel
+    return omel.mel_batch_window(y, sample_rate=16000, n_fft=1024, hop=533)
+
+
 def cpu_baseline_c2(args, params, audio_np, emo_np, eng, audio, emo):
     """The oracle on this host's cores: front end / core / end to end at 1 thread and at all
     threads, plus B = 1 sequential (how the reference runs, scripts/rt.py:343-381).  Bounded: every leg gets an equal
     share of --cpu-seconds.  The numpy front end is one window per call (the reference's own loop,
-    simplified_dual_stream_model.py:184-229); at N threads the windows are dealt to a thread pool (numpy's FFT and
-    matmul release the GIL)."""
+    simplified_dual_stream_model.py:184-229); at N workers the windows are dealt to a pool of N PROCESSES (threads
+    serialise on the interpreter lock between numpy's many small calls and came out slower than one thread)."""
+    import multiprocessing as mp
     import numpy as np
     import torch
-    from concurrent.futures import ThreadPoolExecutor
     from oracle import core as ocore, mel as omel, models
 
     n_all = usable_cpus()
@@ -369,11 +375,12 @@ def cpu_baseline_c2(args, params, audio_np, emo_np, eng, audio, emo):
     long0, short0 = orc.extract_mel_features(a_s[:2])                       # warm-up (filterbank cache, BLAS threads)
     ocore.core_forward_np(params, long0, short0, e_s[:2])
 
-    def front(n_threads, a):
-        if n_threads == 1:
+    pool = mp.get_context("spawn").Pool(n_all) if n_all > 1 else None      # spawn: the children never inherit the HIP runtime
+
+    def front(n_workers, a):
+        if n_workers == 1 or pool is None:
             return omel.mel_batch(a, sample_rate=16000, n_fft=1024, hop=533)
-        with ThreadPoolExecutor(n_threads) as ex:
-            res = list(ex.map(lambda y: omel.mel_batch_window(y, sample_rate=16000, n_fft=1024, hop=533), a))
+        res = pool.map(_cpu_front_one, list(a), chunksize=max(1, len(a) // (4 * n_workers)))
         return (np.stack([r[0] for r in res]).astype(np.float32), np.stack([r[1] for r in res]).astype(np.float32))
 
     def rate(fn, frames_per_call):
@@ -413,12 +420,15 @@ def cpu_baseline_c2(args, params, audio_np, emo_np, eng, audio, emo):
     total_frames += r_seq[1]
     total_t += r_seq[2]
     torch.set_num_threads(n_all)
+    if pool is not None:
+        pool.close()
+        pool.join()
     chk = eng.forward_audio(audio[:nb], emo[:nb]).cpu().numpy()             # same weights, same inputs, through the HIP path
     best = out[f"threads_{n_all}"]["end_to_end_frames_per_s"]
     return {"value": best, "unit": "frames/s", "cores": n_all, "kind": "port",
             "sample": f"{nb} windows of 136448 samples per pass, 7 legs of <= {budget:.1f} s each, {total_frames} frame-passes in "
-                      f"{total_t:.1f} s of CPU work; value = end to end at {n_all} threads (numpy float64 STFT + float32 mel/dB "
-                      f"over a {n_all}-thread pool, torch-CPU fp32 core on {n_all} threads)",
+                      f"{total_t:.1f} s of CPU work; value = end to end at {n_all} cores (numpy float64 STFT + float32 mel/dB "
+                      f"over a {n_all}-process pool, torch-CPU fp32 core on {n_all} threads)",
             "breakdown": out,
             "b1_sequential_frames_per_s": round(r_seq[0], 2), "b1_sequential_rtf_30fps": round(30.0 / r_seq[0], 5),
             "max_abs_diff_vs_gpu": float(np.abs(chk - ref).max())}
