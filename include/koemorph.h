@@ -388,6 +388,30 @@ int km_stream_reset(km_handle h, void* stream);
 int km_enable_stage_timing(km_handle h, int32_t enable);
 int km_stage_times(km_handle h, float* ms3);
 
+/* ---- eGeMAPSv02 functionals: the long-context emotion stream's feature extractor --------------------------------
+ * Replaces the openSMILE call of OpenSMILEeGeMAPSExtractor._extract_features_from_audio
+ * (src/features/opensmile_extractor.py:427-439): peak normalisation to [-1, 1] (:431-433), then the 88 eGeMAPSv02
+ * functionals of the window (`opensmile.Smile(FeatureSet.eGeMAPSv02, FeatureLevel.Functionals).process_signal`, :227-235,
+ * :439), for B windows of L samples at 16 kHz in one call.  openSMILE is a third-party package the reference neither
+ * vendors nor pins: the arithmetic is the restatement of the published parameter set in oracle/egemaps.py (parity
+ * unpinned; output order = openSMILE's feature order).
+ *   km_egemaps_plan_create / _destroy   constant tables (windows, filterbank, log-frequency axis, ...) on the device
+ *   km_egemaps_num_frames               10 ms frames of a window of L samples (60 ms frames, left aligned); at most 2048
+ *   km_egemaps_workspace_floats         floats of caller-owned scratch km_egemaps_functionals needs for (B, L)
+ *   km_egemaps_functionals              audio_dev (B, L) -> out_dev (B, 88); launches on `stream`, no allocation, no sync
+ *   km_egemaps_records                  per-frame low-level descriptors of the last call on that workspace, (B, frames, 36)
+ *                                       floats to the host (tests) */
+int km_egemaps_plan_create(void** plan_out);
+int km_egemaps_plan_destroy(void* plan);
+int64_t km_egemaps_num_frames(int64_t L);
+int64_t km_egemaps_workspace_floats(int64_t B, int64_t L);
+int km_egemaps_functionals(void* plan, const float* audio_dev, int64_t B, int64_t L, int32_t normalize, float* work_dev,
+                           int64_t work_floats, float* out_dev, void* stream);
+int km_egemaps_records(const float* work_dev, int64_t B, int64_t L, float* rec_host, void* stream);
+/* out (B, N) = x (B, K) w^T + b with w stored (N, K) like nn.Linear: the 264 -> 256 compression of the three concatenated
+ * eGeMAPS windows (OpenSMILEeGeMAPSExtractor.get_concatenated_features, opensmile_extractor.py:575-590).  b may be NULL. */
+int km_linear(const float* x_dev, const float* w_dev, const float* b_dev, int64_t B, int64_t K, int64_t N, float* out_dev, void* stream);
+
 /* ---- run-time switches ---------------------------------------------------------------------------
  * Replaces what would be module attributes / environment switches on the reference side (the reference has none on
  * this path: every switch selects between two implementations of the SAME arithmetic, for A/B timing and for the

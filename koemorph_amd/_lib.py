@@ -124,6 +124,13 @@ SIGNATURES = {
     "km_stream_tick": (C.c_int, [_h, _p, _p, _p, _p]),
     "km_stream_reset": (C.c_int, [_h, _p]),
     "km_set_option": (C.c_int, [_h, C.c_char_p, _i64]),
+    "km_egemaps_plan_create": (C.c_int, [C.POINTER(_p)]),
+    "km_egemaps_plan_destroy": (C.c_int, [_p]),
+    "km_egemaps_num_frames": (_i64, [_i64]),
+    "km_egemaps_workspace_floats": (_i64, [_i64, _i64]),
+    "km_egemaps_functionals": (C.c_int, [_p, _p, _i64, _i64, _i32, _p, _i64, _p, _p]),
+    "km_egemaps_records": (C.c_int, [_p, _i64, _i64, _p, _p]),
+    "km_linear": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "km_enable_stage_timing": (C.c_int, [_h, _i32]),
     "km_stage_times": (C.c_int, [_h, C.POINTER(C.c_float)]),
     "km_debug_buffer": (C.c_int, [_h, C.c_char_p, _p, C.POINTER(_i64)]),

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "km_context.h"
+#include "km_gemm.h"
 
 using namespace km;
 
@@ -352,6 +353,15 @@ int km_train_step_audio(km_handle h, const float* audio_dev, int64_t B, int64_t 
     if (int rc = launch_mel(c, c->mel_plans[0], audio_dev, B, L, 0, c->ws_mel, c->ws_short, stream)) return rc;
     return train_forward_backward(c, c->ws_mel, B, n_frames, c->ws_short, emotion_dev, target_dev, mse_weight, l1_weight,
                                   flat_grad_dev, loss_dev, out_dev, ema_state_dev, ema_first, stream);
+}
+
+int km_linear(const float* x_dev, const float* w_dev, const float* b_dev, int64_t B, int64_t K, int64_t N, float* out_dev, void* stream) {
+    if (!x_dev || !w_dev || !out_dev || B <= 0 || K <= 0 || N <= 0) return fail(KM_ERR_INVALID_ARG, "km_linear: bad argument");
+    GemmArgs g{};
+    g.alpha = 1.f; g.batch2 = 1; g.kb_count = 1;
+    g.A = x_dev; g.a_rs = K; g.a_cs = 1; g.B = w_dev; g.b_rs = 1; g.b_cs = K; g.C = out_dev; g.c_rs = N;
+    g.M = (int)B; g.N = (int)N; g.K = (int)K; g.bias = b_dev; g.bias_mode = b_dev ? 1 : 0;
+    return launch_gemm(g, 1, stream);
 }
 
 int km_train_grad_split(km_handle h, int64_t* early_floats) {

@@ -301,3 +301,31 @@ def make_av_features(seed: int, B: int, T: int = 40, D: int = 80) -> np.ndarray:
     """audio_features (B, T, D) for the audio-visual term of the reference's PerceptualBlendshapeLoss
     (src/model/losses.py:340-378): mel-like rows whose overall level differs from window to window."""
     return (uniform(seed * 3 + 7, (B, T, D), 0.0, 1.0) * uniform(seed * 3 + 8, (B, 1, 1), 0.2, 2.0)).astype(np.float32)
+
+
+def make_vowel(seed: int, f0: float, seconds: float, formants=((700.0, 90.0), (1200.0, 110.0), (2600.0, 160.0)),
+               jitter: float = 0.0, noise: float = 0.002, sample_rate: int = 16000, vibrato: float = 0.0) -> np.ndarray:
+    """A synthetic vowel with KNOWN parameters for the eGeMAPS tests: an impulse train of fundamental f0 (period jittered by
+    `jitter` relative standard deviation, optional slow vibrato of relative depth `vibrato`) through two-pole resonators at the
+    given (frequency, bandwidth) pairs, plus white noise; peak normalised.  Pure numpy, reproducible from the seed."""
+    n = int(seconds * sample_rate)
+    x = np.zeros(n, np.float64)
+    g = normal(seed, (4 * int(seconds * f0) + 16,)).astype(np.float64)
+    t, i = 0.0, 0
+    while t < n - 1:
+        x[int(t)] = 1.0
+        f = f0 * (1.0 + vibrato * np.sin(2.0 * np.pi * 5.0 * t / sample_rate))
+        t += sample_rate / f * (1.0 + jitter * g[i % len(g)])
+        i += 1
+    for fc, bw in formants:
+        r, th = np.exp(-np.pi * bw / sample_rate), 2.0 * np.pi * fc / sample_rate
+        a1, a2 = -2.0 * r * np.cos(th), r * r
+        y = np.zeros(n)
+        y1 = y2 = 0.0
+        for k in range(n):
+            v = x[k] - a1 * y1 - a2 * y2
+            y[k] = v
+            y2, y1 = y1, v
+        x = y
+    x = x + noise * np.abs(x).max() * normal(seed + 1, (n,)).astype(np.float64)
+    return (x / np.abs(x).max()).astype(np.float32)

@@ -86,3 +86,42 @@ class MelAudioBufferOracle:
             return None
         idx = (self.write_ptr + np.arange(self.buffer_size)) % self.buffer_size
         return self.audio_buffer[idx].copy()
+
+
+class AudioBufferOracle:
+    """Restatement of AudioBuffer (/root/reference/src/features/opensmile_extractor.py:29-154) with explicit modular
+    indexing: a ring of max_samples; ``is_full`` once the write position has wrapped (:83-91); ``get_window``: zeros (and an
+    underrun count) from an empty buffer, ALL samples so far while fewer than the window have arrived (:111-116), the OLDEST
+    `window` samples while the ring has not wrapped yet (:128-130 -- not the newest: kept as written there), the newest
+    `window` samples once it has (:119-127)."""
+
+    def __init__(self, max_duration: float, sample_rate: int = 16000):
+        self.n = int(max_duration * sample_rate)
+        self.sample_rate = sample_rate
+        self.ring = np.zeros(self.n, np.float32)
+        self.w = 0
+        self.full = False
+        self.underruns = 0
+        self.total = 0
+
+    def append(self, x: np.ndarray) -> None:
+        x = np.asarray(x, np.float32)
+        if self.w + len(x) > self.n:
+            self.full = True
+        for i, v in enumerate(x):
+            self.ring[(self.w + i) % self.n] = v
+        self.w += len(x)
+        if self.w >= self.n:
+            self.full = True
+            self.w %= self.n
+        self.total += len(x)
+
+    def get_window(self, duration=None) -> np.ndarray:
+        want = self.n if duration is None else min(int(duration * self.sample_rate), self.n)
+        if not self.full:
+            if self.w == 0:
+                if want > 0:
+                    self.underruns += 1
+                    return np.zeros(want, np.float32)
+            return self.ring[:min(self.w, want)].copy()
+        return np.array([self.ring[(self.w - want + i) % self.n] for i in range(want)], np.float32)
