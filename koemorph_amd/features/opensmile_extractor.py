@@ -321,6 +321,46 @@ class OpenSMILEeGeMAPSExtractor:
                                              torch.cuda.current_stream(dev).cuda_stream))
         return out[0].cpu().numpy().astype(np.float32)
 
+    def emotion_features_batch(self, audio):
+        """(B, L) windows -> (B, 256) emotion vectors, the END STATE of the reference's production path
+        (EmotionExtractor._extract_opensmile, src/features/emotion_extractor.py:435-470, with use_concatenation): per
+        sample it resets the audio buffer, feeds the window in update-interval frames with force_update (an openSMILE run
+        on the growing window at EVERY frame), then concatenates the three window slots and compresses 264 -> 256.  Only
+        the last of those runs reaches the output; and the 300 / 600 ms slots are filled once per extractor lifetime, by
+        the first extraction it ever makes (see _update_window_features).  So: one batched extraction of the B full
+        windows, one more of the first sample's first two frames if the slots are still empty, one batched Linear."""
+        import torch
+        if not self.use_concatenation:
+            raise RuntimeError("emotion_features_batch needs use_concatenation=True (the reference's production configuration)")
+        if isinstance(audio, np.ndarray):
+            audio = torch.from_numpy(np.ascontiguousarray(audio, np.float32))
+        audio = audio.to(self.engine.device, torch.float32)
+        B, L = audio.shape
+        frame = int(self.sample_rate * self.update_interval)
+        ctx = int(self.context_window * self.sample_rate)
+        if self.window_features[0.3] is None:
+            # the first frame count at which the buffer holds >= 0.5 s (reference _extract_features :366-368)
+            k = 1
+            while min(k * frame, L) < int(self.sample_rate * 0.5) and k * frame < L:
+                k += 1
+            first = self.extract_batch(audio[:1, :min(k * frame, L)][:, -ctx:])[0].cpu().numpy()
+            self._update_window_features(self._clock(), first)
+        current = self.extract_batch(audio[:, -ctx:])                                    # (B, 88)
+        self.window_features[0.0] = current[-1].cpu().numpy()
+        self.current_features = self.window_features[0.0]
+        dev = self.engine.device
+        past = torch.from_numpy(np.concatenate([self.window_features[0.3], self.window_features[0.6]])).to(dev)
+        cat = torch.cat([current, past.unsqueeze(0).expand(B, -1)], dim=1).contiguous()  # (B, 264)
+        if self.compression_layer is None:
+            self.compression_layer = torch.nn.Linear(264, 256)
+        w = self.compression_layer.weight.detach().to(dev, torch.float32).contiguous()
+        b = self.compression_layer.bias.detach().to(dev, torch.float32).contiguous()
+        out = torch.empty(B, 256, device=dev)
+        with torch.cuda.device(dev):
+            check(self.engine._lib.km_linear(cat.data_ptr(), w.data_ptr(), b.data_ptr(), B, 264, 256, out.data_ptr(),
+                                             torch.cuda.current_stream(dev).cuda_stream))
+        return out
+
     def get_feature_names(self) -> List[str]:
         from ..egemaps_names import FEATURE_NAMES
         return list(FEATURE_NAMES)
