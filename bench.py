@@ -60,6 +60,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=None, help="windows (c2/c4: 256, c3: 8) or streams (c5: 128) per GPU per step")
     ap.add_argument("--heads", type=int, default=8, help="c4: attention heads (8 or 16)")
     ap.add_argument("--dropout", type=float, default=0.1, help="c3: train-mode dropout probability (the reference trains at 0.1)")
+    ap.add_argument("--graph", action="store_true", help="c3: replay forward + backward from a hipGraph (Trainer.capture)")
     ap.add_argument("--cpu-seconds", type=float, default=18.0, help="CPU-baseline time budget (0 = skip)")
     ap.add_argument("--cpu-windows", type=int, default=None, help="deprecated: 0 skips the CPU baseline")
     ap.add_argument("--no-split", action="store_true", help="skip the experimental split-bf16 timing")
@@ -454,7 +455,13 @@ def run_c3(args, rk: Ranks):
     audio = torch.from_numpy(synth.make_audio(10 + rk.rank, B, L, "uniform")).to(rk.dev)
     emo = torch.from_numpy(synth.normal(20 + rk.rank, (B, 256))).to(rk.dev)
     target = torch.from_numpy(synth.uniform(30 + rk.rank, (B, 52), 0, 1)).to(rk.dev)
-    dt = timed(rk, lambda: tr.step(audio, emo, target), args.steps, args.warmup)
+    if args.graph:
+        for _ in range(3):
+            tr.step(audio, emo, target)
+        tr.capture(B, L)
+        dt = timed(rk, lambda: tr.step_graph(audio, emo, target), args.steps, args.warmup)
+    else:
+        dt = timed(rk, lambda: tr.step(audio, emo, target), args.steps, args.warmup)
     ms = dt / args.steps * 1e3
     value = B * rk.world * args.steps / dt
     tf = TRAIN_FLOPS_PER_WINDOW * B / (ms * 1e-3) / 1e12
@@ -464,7 +471,7 @@ def run_c3(args, rk: Ranks):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "rccl_ranks": rk.rccl_ranks,
         "config": {"workload": f"C3: train step, {B} windows/GPU x 136448 samples, window 256, d_model 256, dropout "
-                               f"{kw.get('dropout', 0.0)}, MSE loss, clip 1.0, AdamW; ONE all-reduce of the flat {tr.n_params}-float "
+                               f"{kw.get('dropout', 0.0)}, {'hipGraph replay, ' if args.graph else ''}MSE loss, clip 1.0, AdamW; ONE all-reduce of the flat {tr.n_params}-float "
                                "gradient bucket per step", "windows_per_gpu": B,
                    "parallelism": f"data parallel x{rk.world}, gradient all-reduce over {'RCCL' if rk.backend == 'nccl' else rk.backend}"},
         "roofline": {"kernel": "whole step (launch-bound at this batch)", "bound": "mfma", "achieved": round(tf, 3),

@@ -73,20 +73,30 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
     __syncthreads();
     const float* zr = a.zrows;
     if (a.zrows_out) {   // decoder output layer: one wave per row, lanes stride the hidden units
-        // 16 lanes per row, four rows per wave at a time: the loads of a pass are independent, so a wave pays the
-        // memory latency once per four rows
+        // 16 lanes per row, four rows per wave at a time, eight such passes in flight: the stores come after the group's
+        // loads (a store to zrows_out between them would order every later load behind it), so a wave pays the memory
+        // latency once per 32 rows
         const int64_t rm = (int64_t)a.B * 28, rows = rm + (int64_t)a.B * a.expr_rows;
         const int sub = i >> 4, l16 = i & 15;
-        for (int64_t r0 = (int64_t)w * 4; r0 < rows; r0 += (int64_t)NW * 4) {
-            const int64_t r = r0 + sub;
-            float s = 0.f;
-            if (r < rows) {
-                const float* h = r < rm ? a.h1 + r * a.DH : a.he + (r - rm) * a.DH;
-                for (int k = l16; k < a.DH; k += 16) s = fmaf(h[k], a.w2[k], s);
+        for (int64_t g0 = (int64_t)w * 4; g0 < rows; g0 += (int64_t)NW * 4 * 8) {
+            float zl[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t r = g0 + (int64_t)u * NW * 4 + sub;
+                float s = 0.f;
+                if (r < rows) {
+                    const float* h = r < rm ? a.h1 + r * a.DH : a.he + (r - rm) * a.DH;
+                    for (int k = l16; k < a.DH; k += 16) s = fmaf(h[k], a.w2[k], s);
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                zl[u] = s;
             }
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (l16 == 0 && r < rows) a.zrows_out[r] = s + a.b2[0];
+            for (int u = 0; u < 8; ++u) {
+                const int64_t r = g0 + (int64_t)u * NW * 4 + sub;
+                if (l16 == 0 && r < rows) a.zrows_out[r] = zl[u] + a.b2[0];
+            }
         }
         zr = a.zrows_out;
         __threadfence_block();

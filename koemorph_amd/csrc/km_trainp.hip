@@ -97,6 +97,151 @@ __device__ __forceinline__ int drop_dz_index(int map, int64_t r, int& b_out) {
     const int64_t b = r / 24; const int q = (int)(r - b * 24); b_out = (int)b; return q < 14 ? q : q + 27;
 }
 
+// global -> LDS staging of n elements, element i read from src(i) and written to dst(i): the loads of eight elements per
+// thread are issued before the first LDS store.  The LDS image is reached through a generic pointer here, so the compiler
+// must assume a store may alias the next load and would otherwise serialise load -> store -> load (a full memory round trip
+// per element: 20 - 30 of them made the attention blocks the long poles of their phases).
+template <typename Src, typename Dst>
+__device__ __forceinline__ void stage_to_lds(int n, Src src, Dst dst) {
+    for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + 256 * u; v[u] = i < n ? src(i) : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + 256 * u; if (i < n) dst(i, v[u]); }
+    }
+}
+
+template <int HD>
+__device__ __forceinline__ void attn_fwd_dev(const ElemArgs& a, int vb, float* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+     // one (window, head): S = scale Q_h K_h^T, P = softmax(S) (saved), A_h = (P keep / (1 - p)) V_h
+        // p0 Q (28, d), p1 KV (R, 2d); q0 P (B, H, 28, NK), q1 A (B * 28, d); i0 d, i1 hd, i2 NK, i3 H; f0 keep scale, u0 = bits of the score scale
+        const int d = a.i0, NKk = a.i2, H = a.i3;
+        constexpr int hd = HD;
+        const int b = vb / H, h = vb - b * H;
+        float* Qs = smem;                         // [28][hd]
+        float* Ks = Qs + 28 * hd;                 // [NK][hd + 1]
+        float* Vs = Ks + NKk * (hd + 1);          // [NK][hd]
+        float* Ss = Vs + NKk * hd;                // [28][NK]
+        const float scale = __uint_as_float(a.u0);
+        const float* kvb = a.p1 + (int64_t)b * NKk * 2 * d + h * hd;
+        stage_to_lds(28 * hd, [&](int i) { const int q = i / hd; return a.p0[q * d + h * hd + (i - q * hd)]; }, [&](int i, float v) { Qs[i] = v; });
+        stage_to_lds(NKk * hd, [&](int i) { const int k = i / hd; return kvb[(int64_t)k * 2 * d + (i - k * hd)]; },
+                     [&](int i, float v) { const int k = i / hd; Ks[k * (hd + 1) + (i - k * hd)] = v; });
+        stage_to_lds(NKk * hd, [&](int i) { const int k = i / hd; return kvb[(int64_t)k * 2 * d + d + (i - k * hd)]; }, [&](int i, float v) { Vs[i] = v; });
+        __syncthreads();
+        for (int i = tid; i < 28 * NKk; i += 256) {
+            const int q = i / NKk, k = i - q * NKk;
+            float sacc = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < hd; ++cc) sacc = fmaf(Qs[q * hd + cc], Ks[k * (hd + 1) + cc], sacc);
+            Ss[i] = scale * sacc;
+        }
+        __syncthreads();
+        for (int q = wv; q < 28; q += 4) {        // softmax of row q by one wave (NK <= 128)
+            const float v0 = lane < NKk ? Ss[q * NKk + lane] : -INFINITY, v1 = lane + 64 < NKk ? Ss[q * NKk + lane + 64] : -INFINITY;
+            float m = fmaxf(v0, v1);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            const float e0 = lane < NKk ? expf(v0 - m) : 0.f, e1 = lane + 64 < NKk ? expf(v1 - m) : 0.f;
+            float sum = e0 + e1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const int64_t prow = (((int64_t)b * H + h) * 28 + q) * NKk;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int k = lane + 64 * t;
+                if (k < NKk) {
+                    const float pv = (t ? e1 : e0) / sum;
+                    a.q0[prow + k] = pv;
+                    Ss[q * NKk + k] = a.mask ? (a.mask[prow + k] ? pv * a.f0 : 0.f) : pv;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 28 * hd; i += 256) {
+            const int q = i / hd, cc = i - q * hd;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < NKk; ++k) acc = fmaf(Ss[q * NKk + k], Vs[k * hd + cc], acc);
+            a.q1[((int64_t)b * 28 + q) * d + h * hd + cc] = acc;
+        }
+        __syncthreads();
+}
+
+template <int HD>
+__device__ __forceinline__ void attn_bwd_dev(const ElemArgs& a, int vb, float* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+     // one (window, head): dPd = dA_h V_h^T, dV_h = Pd^T dA_h, dS = softmax', dK_h = scale dS^T Q_h, dQ_h[b] = scale dS K_h
+        // p0 Q, p1 KV, p2 P, p3 dA (B * 28, d); q0 dKV (R, 2d), q1 dQ partial (B, 28, d)
+        const int d = a.i0, NKk = a.i2, H = a.i3;
+        constexpr int hd = HD;
+        const int b = vb / H, h = vb - b * H;
+        float* Qs = smem;                         // [28][hd]
+        float* Ks = Qs + 28 * hd;                 // [NK][hd + 1]
+        float* Vs = Ks + NKk * (hd + 1);          // [NK][hd + 1]
+        float* Gs = Vs + NKk * (hd + 1);          // [28][hd]   dA_h
+        float* Ps = Gs + 28 * hd;                 // [28][NK]   P
+        float* Ds = Ps + 28 * NKk;                // [28][NK]   dP, then dS
+        const float scale = __uint_as_float(a.u0);
+        const int64_t prow0 = ((int64_t)b * H + h) * 28 * NKk;
+        const float* kvb = a.p1 + (int64_t)b * NKk * 2 * d + h * hd;
+        const float* gab = a.p3 + (int64_t)b * 28 * d + h * hd;
+        stage_to_lds(28 * hd, [&](int i) { const int q = i / hd; return a.p0[q * d + h * hd + (i - q * hd)]; }, [&](int i, float v) { Qs[i] = v; });
+        stage_to_lds(28 * hd, [&](int i) { const int q = i / hd; return gab[(int64_t)q * d + (i - q * hd)]; }, [&](int i, float v) { Gs[i] = v; });
+        stage_to_lds(NKk * hd, [&](int i) { const int k = i / hd; return kvb[(int64_t)k * 2 * d + (i - k * hd)]; },
+                     [&](int i, float v) { const int k = i / hd; Ks[k * (hd + 1) + (i - k * hd)] = v; });
+        stage_to_lds(NKk * hd, [&](int i) { const int k = i / hd; return kvb[(int64_t)k * 2 * d + d + (i - k * hd)]; },
+                     [&](int i, float v) { const int k = i / hd; Vs[k * (hd + 1) + (i - k * hd)] = v; });
+        // P, and Pd = P keep / (1 - p) in the image that later holds dP
+        stage_to_lds(28 * NKk, [&](int i) { return a.p2[prow0 + i]; }, [&](int i, float v) { Ps[i] = v; });
+        stage_to_lds(28 * NKk, [&](int i) { const float pv = a.p2[prow0 + i]; return a.mask ? (a.mask[prow0 + i] ? pv * a.f0 : 0.f) : pv; },
+                     [&](int i, float v) { Ds[i] = v; });
+        __syncthreads();
+        for (int i = tid; i < NKk * hd; i += 256) {     // dV_h = Pd^T dA_h
+            const int k = i / hd, cc = i - k * hd;
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 28; ++q) acc = fmaf(Ds[q * NKk + k], Gs[q * hd + cc], acc);
+            a.q0[((int64_t)b * NKk + k) * 2 * d + d + h * hd + cc] = acc;
+        }
+        __syncthreads();
+        for (int i = tid; i < 28 * NKk; i += 256) {     // dP = (dA_h V_h^T) keep / (1 - p)
+            const int q = i / NKk, k = i - q * NKk;
+            float acc = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < hd; ++cc) acc = fmaf(Gs[q * hd + cc], Vs[k * (hd + 1) + cc], acc);
+            Ds[i] = a.mask ? (a.mask[prow0 + i] ? acc * a.f0 : 0.f) : acc;
+        }
+        __syncthreads();
+        for (int q = wv; q < 28; q += 4) {              // dS = P (dP - sum(dP P))
+            const float p0 = lane < NKk ? Ps[q * NKk + lane] : 0.f, p1 = lane + 64 < NKk ? Ps[q * NKk + lane + 64] : 0.f;
+            const float g0 = lane < NKk ? Ds[q * NKk + lane] : 0.f, g1 = lane + 64 < NKk ? Ds[q * NKk + lane + 64] : 0.f;
+            float sacc = g0 * p0 + g1 * p1;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+            if (lane < NKk) Ds[q * NKk + lane] = p0 * (g0 - sacc);
+            if (lane + 64 < NKk) Ds[q * NKk + lane + 64] = p1 * (g1 - sacc);
+        }
+        __syncthreads();
+        for (int i = tid; i < NKk * hd; i += 256) {     // dK_h = scale dS^T Q_h
+            const int k = i / hd, cc = i - k * hd;
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < 28; ++q) acc = fmaf(Ds[q * NKk + k], Qs[q * hd + cc], acc);
+            a.q0[((int64_t)b * NKk + k) * 2 * d + h * hd + cc] = scale * acc;
+        }
+        for (int i = tid; i < 28 * hd; i += 256) {      // dQ_h of this window = scale dS K_h
+            const int q = i / hd, cc = i - q * hd;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < NKk; ++k) acc = fmaf(Ds[q * NKk + k], Ks[k * (hd + 1) + cc], acc);
+            a.q1[((int64_t)b * 28 + q) * d + h * hd + cc] = scale * acc;
+        }
+        __syncthreads();
+}
+
 __device__ __forceinline__ void op_elem(const Op& op, int vb, float* smem) {
     const ElemArgs& a = op.e;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -218,128 +363,12 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, float* smem) {
         a.q0[i] = s;
         break;
     }
-    case OP_ATTN_FWD: {     // one (window, head): S = scale Q_h K_h^T, P = softmax(S) (saved), A_h = (P keep / (1 - p)) V_h
-        // p0 Q (28, d), p1 KV (R, 2d); q0 P (B, H, 28, NK), q1 A (B * 28, d); i0 d, i1 hd, i2 NK, i3 H; f0 keep scale, u0 = bits of the score scale
-        const int d = a.i0, hd = a.i1, NKk = a.i2, H = a.i3;
-        const int b = vb / H, h = vb - b * H;
-        float* Qs = smem;                         // [28][hd]
-        float* Ks = Qs + 28 * hd;                 // [NK][hd + 1]
-        float* Vs = Ks + NKk * (hd + 1);          // [NK][hd]
-        float* Ss = Vs + NKk * hd;                // [28][NK]
-        const float scale = __uint_as_float(a.u0);
-        for (int i = tid; i < 28 * hd; i += 256) { const int q = i / hd, cc = i - q * hd; Qs[i] = a.p0[q * d + h * hd + cc]; }
-        for (int i = tid; i < NKk * hd; i += 256) {
-            const int k = i / hd, cc = i - k * hd;
-            const float* row = a.p1 + ((int64_t)b * NKk + k) * 2 * d + h * hd + cc;
-            Ks[k * (hd + 1) + cc] = row[0];
-            Vs[i] = row[d];
-        }
-        __syncthreads();
-        for (int i = tid; i < 28 * NKk; i += 256) {
-            const int q = i / NKk, k = i - q * NKk;
-            float sacc = 0.f;
-            for (int cc = 0; cc < hd; ++cc) sacc = fmaf(Qs[q * hd + cc], Ks[k * (hd + 1) + cc], sacc);
-            Ss[i] = scale * sacc;
-        }
-        __syncthreads();
-        for (int q = wv; q < 28; q += 4) {        // softmax of row q by one wave (NK <= 128)
-            const float v0 = lane < NKk ? Ss[q * NKk + lane] : -INFINITY, v1 = lane + 64 < NKk ? Ss[q * NKk + lane + 64] : -INFINITY;
-            float m = fmaxf(v0, v1);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            const float e0 = lane < NKk ? expf(v0 - m) : 0.f, e1 = lane + 64 < NKk ? expf(v1 - m) : 0.f;
-            float sum = e0 + e1;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-            const int64_t prow = (((int64_t)b * H + h) * 28 + q) * NKk;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int k = lane + 64 * t;
-                if (k < NKk) {
-                    const float pv = (t ? e1 : e0) / sum;
-                    a.q0[prow + k] = pv;
-                    Ss[q * NKk + k] = a.mask ? (a.mask[prow + k] ? pv * a.f0 : 0.f) : pv;
-                }
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < 28 * hd; i += 256) {
-            const int q = i / hd, cc = i - q * hd;
-            float acc = 0.f;
-            for (int k = 0; k < NKk; ++k) acc = fmaf(Ss[q * NKk + k], Vs[k * hd + cc], acc);
-            a.q1[((int64_t)b * 28 + q) * d + h * hd + cc] = acc;
-        }
-        __syncthreads();
+    case OP_ATTN_FWD:
+        if (a.i1 == 32) attn_fwd_dev<32>(a, vb, smem); else if (a.i1 == 64) attn_fwd_dev<64>(a, vb, smem); else attn_fwd_dev<16>(a, vb, smem);
         break;
-    }
-    case OP_ATTN_BWD: {     // one (window, head): dPd = dA_h V_h^T, dV_h = Pd^T dA_h, dS = softmax', dK_h = scale dS^T Q_h, dQ_h[b] = scale dS K_h
-        // p0 Q, p1 KV, p2 P, p3 dA (B * 28, d); q0 dKV (R, 2d), q1 dQ partial (B, 28, d)
-        const int d = a.i0, hd = a.i1, NKk = a.i2, H = a.i3;
-        const int b = vb / H, h = vb - b * H;
-        float* Qs = smem;                         // [28][hd]
-        float* Ks = Qs + 28 * hd;                 // [NK][hd + 1]
-        float* Vs = Ks + NKk * (hd + 1);          // [NK][hd + 1]
-        float* Gs = Vs + NKk * (hd + 1);          // [28][hd]   dA_h
-        float* Ps = Gs + 28 * hd;                 // [28][NK]   P
-        float* Ds = Ps + 28 * NKk;                // [28][NK]   dP, then dS
-        const float scale = __uint_as_float(a.u0);
-        const int64_t prow0 = ((int64_t)b * H + h) * 28 * NKk;
-        for (int i = tid; i < 28 * hd; i += 256) {
-            const int q = i / hd, cc = i - q * hd;
-            Qs[i] = a.p0[q * d + h * hd + cc];
-            Gs[i] = a.p3[((int64_t)b * 28 + q) * d + h * hd + cc];
-        }
-        for (int i = tid; i < NKk * hd; i += 256) {
-            const int k = i / hd, cc = i - k * hd;
-            const float* row = a.p1 + ((int64_t)b * NKk + k) * 2 * d + h * hd + cc;
-            Ks[k * (hd + 1) + cc] = row[0];
-            Vs[k * (hd + 1) + cc] = row[d];
-        }
-        for (int i = tid; i < 28 * NKk; i += 256) {     // P, and Pd = P keep / (1 - p) in the image that later holds dP
-            const float pv = a.p2[prow0 + i];
-            Ps[i] = pv;
-            Ds[i] = a.mask ? (a.mask[prow0 + i] ? pv * a.f0 : 0.f) : pv;
-        }
-        __syncthreads();
-        for (int i = tid; i < NKk * hd; i += 256) {     // dV_h = Pd^T dA_h
-            const int k = i / hd, cc = i - k * hd;
-            float acc = 0.f;
-            for (int q = 0; q < 28; ++q) acc = fmaf(Ds[q * NKk + k], Gs[q * hd + cc], acc);
-            a.q0[((int64_t)b * NKk + k) * 2 * d + d + h * hd + cc] = acc;
-        }
-        __syncthreads();
-        for (int i = tid; i < 28 * NKk; i += 256) {     // dP = (dA_h V_h^T) keep / (1 - p)
-            const int q = i / NKk, k = i - q * NKk;
-            float acc = 0.f;
-            for (int cc = 0; cc < hd; ++cc) acc = fmaf(Gs[q * hd + cc], Vs[k * (hd + 1) + cc], acc);
-            Ds[i] = a.mask ? (a.mask[prow0 + i] ? acc * a.f0 : 0.f) : acc;
-        }
-        __syncthreads();
-        for (int q = wv; q < 28; q += 4) {              // dS = P (dP - sum(dP P))
-            const float p0 = lane < NKk ? Ps[q * NKk + lane] : 0.f, p1 = lane + 64 < NKk ? Ps[q * NKk + lane + 64] : 0.f;
-            const float g0 = lane < NKk ? Ds[q * NKk + lane] : 0.f, g1 = lane + 64 < NKk ? Ds[q * NKk + lane + 64] : 0.f;
-            float sacc = g0 * p0 + g1 * p1;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
-            if (lane < NKk) Ds[q * NKk + lane] = p0 * (g0 - sacc);
-            if (lane + 64 < NKk) Ds[q * NKk + lane + 64] = p1 * (g1 - sacc);
-        }
-        __syncthreads();
-        for (int i = tid; i < NKk * hd; i += 256) {     // dK_h = scale dS^T Q_h
-            const int k = i / hd, cc = i - k * hd;
-            float acc = 0.f;
-            for (int q = 0; q < 28; ++q) acc = fmaf(Ds[q * NKk + k], Qs[q * hd + cc], acc);
-            a.q0[((int64_t)b * NKk + k) * 2 * d + h * hd + cc] = scale * acc;
-        }
-        for (int i = tid; i < 28 * hd; i += 256) {      // dQ_h of this window = scale dS K_h
-            const int q = i / hd, cc = i - q * hd;
-            float acc = 0.f;
-            for (int k = 0; k < NKk; ++k) acc = fmaf(Ds[q * NKk + k], Ks[k * (hd + 1) + cc], acc);
-            a.q1[((int64_t)b * 28 + q) * d + h * hd + cc] = scale * acc;
-        }
-        __syncthreads();
+    case OP_ATTN_BWD:
+        if (a.i1 == 32) attn_bwd_dev<32>(a, vb, smem); else if (a.i1 == 64) attn_bwd_dev<64>(a, vb, smem); else attn_bwd_dev<16>(a, vb, smem);
         break;
-    }
     default: break;
     }
 }
@@ -589,7 +618,8 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     if (once.first(c->device))
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&phase_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const size_t attn_lds = (size_t)(2 * 28 * hd + 2 * NKk * (hd + 1) + 2 * 28 * NKk) * sizeof(float);
-    if (attn_lds > 160 * 1024) return fail(KM_ERR_UNSUPPORTED, "attention head too large for the fused training kernels");
+    if (attn_lds > 160 * 1024 || (hd != 16 && hd != 32 && hd != 64))
+        return fail(KM_ERR_UNSUPPORTED, "the fused training attention blocks are built for heads of 16, 32 or 64 columns (got %lld)", (long long)hd);
 
     Program pg;
     auto blocks4 = [](int64_t rows) { return (rows + 3) / 4; };            // one wave per row, 4 rows per block
