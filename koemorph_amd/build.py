@@ -5,6 +5,7 @@ torch.  hipcc cross-compiles without a GPU, so this also runs in the CPU-only bu
 """
 from __future__ import annotations
 
+import glob
 import os
 import shutil
 import subprocess
@@ -16,8 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libkoemorph_hip.so")
 SOURCES = ["km_host.cpp", "km_wire.cpp", "km_core.hip", "km_mel.hip", "km_generic.hip", "km_koemorph.hip", "km_train.hip", "km_trainp.hip", "km_egemaps.hip", "km_data.hip", "km_api.hip"]
-HEADERS = [os.path.join(CSRC, "km_context.h"), os.path.join(CSRC, "km_device.h"), os.path.join(CSRC, "km_gemm.h"), os.path.join(CSRC, "km_gemm_dev.h"), os.path.join(CSRC, "km_train_tail.h"),
-           os.path.join(ROOT, "include", "koemorph.h")]
+HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(ROOT, "include", "koemorph.h")]
 
 
 def _hipcc() -> str:

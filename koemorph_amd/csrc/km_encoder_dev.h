@@ -1,0 +1,255 @@
+// Fused encoder product + LayerNorm of the shape-generic attention core (device code only, so that the kernel can be
+// instantiated by km_generic.hip and by the stand-alone timing harness tools/micro/enc_bench.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "km_device.h"
+
+namespace km {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// KM_ENC_SKIP (timing harness only, tools/micro/enc_bench.hip; 0 in the library): bit 0 no MFMAs, bit 1 no Y store,
+// bit 2 no LayerNorm, bit 3 no tile loads / commits after the prologue (bit 4: no weight loads, bit 5: no A tiles)
+#ifndef KM_ENC_SKIP
+#define KM_ENC_SKIP 0
+#endif
+#ifndef KM_MFMA
+#define KM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
+
+// ---------------------------------------------------------------------------------------------------------
+// encoder_ln_kernel<NW>: the same product as encoder_tn_kernel with ONE workgroup of NW = d / 32 waves per window, so
+// that a row's d columns are all in the workgroup and LayerNorm (two-pass, DPP row sums + a [row][wave] exchange, as in
+// the fused d=256 kernel) runs in the epilogue: no Y0 round trip, no separate ln_rows launch.
+// ---------------------------------------------------------------------------------------------------------
+// FUSE_DB: the input is the front end's POWER-mel (B, n_frames, 80) + window maxima; the dB / log conversion and the
+// row packing (T long rows, 3 short-term rows, zero rows) happen while a tile is staged, so no packed log-mel image is
+// written and read back (mel_log_packed_kernel disappears from km_forward_audio).
+struct EncSrc {
+    const float* melpow; const unsigned* melmax; int n_frames, T; LogParams lp;
+};
+
+// NW waves of CT column tiles each: D = 16 CT NW columns (d = 512 -> 8 waves x 64 columns, two waves per SIMD with 20
+// accumulators each; d = 256 -> 8 x 32; d = 64 -> 2 x 32).  What the timing harness showed about the first version
+// (16 waves x 32 columns, both operands through LDS, 114 us at C4): the MFMA loop alone runs at 0.83 of the nominal rate,
+// the tile traffic (global -> registers -> LDS, after the MFMAs of the same iteration, then the barrier) cost 19 us on top
+// because every wave of the workgroup reaches that tail at the same time -- nobody is left to issue MFMAs under it.  So:
+//  * B (the weight) never touches LDS: wce_pg is the MFMA operand image [k block][wave][column tile][lane][4]
+//    (km_host.cpp), one coalesced 1 KiB load per wave and tile, fetched one k block ahead straight into registers;
+//  * A (80 channels x 16 frames per k block, converted to dB on the way) is the only LDS traffic: 5 KB per k block,
+//    committed at the TOP of an iteration from registers loaded an iteration earlier, so its writes and the reads of the
+//    next block's fragments run under the iteration's 80 MFMAs;
+//  * a lane's CT column tiles are CT adjacent columns (n = 16 CT wave + CT lj + ct), so the epilogue stores 16-byte
+//    vectors, 256 contiguous bytes per row and wave, instead of 64-byte segments.
+template <int NW, int CT, bool FUSE_DB>
+__global__ __launch_bounds__(64 * NW) void encoder_ln_kernel(const float* __restrict__ xp, const float* __restrict__ wpg,
+                                                             const float* __restrict__ bias, const float* __restrict__ gam,
+                                                             const float* __restrict__ bet, float* __restrict__ Y, int KP,
+                                                             EncSrc src) {
+    constexpr int NKc = 80, NTHR = 64 * NW, D = 16 * CT * NW;
+    static_assert(NKc % NW == 0, "rows must divide evenly among the waves");
+    static_assert(CT == 2 || CT == 4, "a lane's columns are stored as one 8- or 16-byte vector");
+    constexpr int ABUF = 4 * NKc * 4;                 // floats of one A tile image [k / 4][row][k % 4]
+    __shared__ __attribute__((aligned(16))) float As[2 * ABUF];
+    __shared__ __attribute__((aligned(16))) float Ps[2][NKc * NW];      // LayerNorm partial sums [pass][row][wave]
+    __shared__ __attribute__((aligned(16))) float Ts[2][NKc];           // LayerNorm row totals [pass][row]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lg = lane >> 4, lj = lane & 15;
+    const int b = blockIdx.x;
+    const int kt = KP / 16;
+    // Tiles are fetched with buffer loads: a thread (or a row, or a k block past the end) with nothing to fetch points
+    // past the descriptor's range and gets zeros without a memory access, so no load sits under a branch.
+    const float* X = FUSE_DB ? src.melpow + (int64_t)b * src.n_frames * NKc : xp + (int64_t)b * KP * NKc;
+    const unsigned x_bytes = (unsigned)((FUSE_DB ? src.n_frames : KP) * NKc * 4);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wpg), 0, (unsigned)(D * KP * 4), 0x00020000);
+    constexpr unsigned OOB = 0x7fffffffu;
+    // with >= 320 threads one staged row per thread (16 rows x 20 float4): the log conversion is spread over five waves
+    constexpr bool WIDE = NTHR >= 320;
+    constexpr int NA = WIDE ? 1 : 4;                                   // staged rows per loading thread
+    const bool a_thr = tid < (WIDE ? 320 : 80);
+    const int akg = tid / 20, am4 = tid - akg * 20;
+    float ref_db = 0.f, floor_db = 0.f;
+    if (FUSE_DB) log_window_consts(src.lp, __uint_as_float(src.melmax[b]), ref_db, floor_db);
+    u32x4 ra[NA];
+    unsigned ravalid = 0;        // FUSE_DB: which of the staged rows hold a real frame (zero rows stay zero)
+    auto load_a = [&](int t) {
+        const int k0 = 16 * t;
+        if constexpr (FUSE_DB) ravalid = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = k0 + (WIDE ? akg : 4 * akg + i);           // packed row of this load
+            int f = r;
+            if constexpr (FUSE_DB) {                                  // packed row -> frame (mel_log_packed_kernel's mapping)
+                f = -1;
+                if (r < src.T) f = r < src.n_frames ? r : -1;
+                else if (r < src.T + 3) {
+                    const int q = r - src.T;
+                    if (src.n_frames >= 3) f = src.n_frames - 3 + q; else if (q < src.n_frames) f = q;
+                }
+                ravalid |= (f >= 0 ? 1u : 0u) << i;
+            }
+            const unsigned off = (a_thr && f >= 0 && t < kt) ? (unsigned)(f * NKc + 4 * am4) * 4u : OOB;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+        }
+    };
+    auto commit_a = [&](int buf) {
+        float* Ab = As + buf * ABUF;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) asm volatile("" ::"v"(ra[i]));   // an unconditional use: keeps the loads out of the branch below
+        if (a_thr) {
+            float4 a4[NA];
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                a4[i] = make_float4(__uint_as_float(ra[i].x), __uint_as_float(ra[i].y), __uint_as_float(ra[i].z), __uint_as_float(ra[i].w));
+            if constexpr (FUSE_DB) {
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (src.lp.log_mode == KM_LOG_LN_EPS) {
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) a4[i] = (ravalid >> i) & 1 ? log_four_t<KM_LOG_LN_EPS>(src.lp, a4[i], ref_db, floor_db) : z4;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) a4[i] = (ravalid >> i) & 1 ? log_four_t<KM_LOG_DB_MAX>(src.lp, a4[i], ref_db, floor_db) : z4;
+                }
+            }
+            if constexpr (WIDE) {
+                float* dst = &Ab[((akg >> 2) * NKc + 4 * am4) * 4 + (akg & 3)];
+                dst[0] = a4[0].x; dst[4] = a4[0].y; dst[8] = a4[0].z; dst[12] = a4[0].w;
+            } else {
+                float* dst = &Ab[(akg * NKc + 4 * am4) * 4];
+                *reinterpret_cast<float4*>(dst + 0) = make_float4(a4[0].x, a4[NA > 1 ? 1 : 0].x, a4[NA > 2 ? 2 : 0].x, a4[NA > 3 ? 3 : 0].x);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(a4[0].y, a4[NA > 1 ? 1 : 0].y, a4[NA > 2 ? 2 : 0].y, a4[NA > 3 ? 3 : 0].y);
+                *reinterpret_cast<float4*>(dst + 8) = make_float4(a4[0].z, a4[NA > 1 ? 1 : 0].z, a4[NA > 2 ? 2 : 0].z, a4[NA > 3 ? 3 : 0].z);
+                *reinterpret_cast<float4*>(dst + 12) = make_float4(a4[0].w, a4[NA > 1 ? 1 : 0].w, a4[NA > 2 ? 2 : 0].w, a4[NA > 3 ? 3 : 0].w);
+            }
+        }
+    };
+    f32x4 acc[5][CT];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[i][ct] = f32x4{0, 0, 0, 0};
+    f32x4 af[2][5], bf[2][CT];
+    auto frags_a = [&](int buf, int slot) {
+        const float* Ab = As + buf * ABUF;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) af[slot][i] = *reinterpret_cast<const f32x4*>(&Ab[(lg * NKc + 16 * i + lj) * 4]);
+    };
+    const unsigned bo = (unsigned)((wave * CT * 64 + lane) * 16);
+    auto load_b = [&](int t, int slot) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+            bf[slot][ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                wr, t < kt ? bo + (unsigned)(t * NW * CT + ct) * 1024u : OOB, 0, 0));
+    };
+    load_a(0);
+    load_b(0, 0);
+    commit_a(0);
+    load_a(1);
+    commit_a(1);
+    load_a(2);
+    __syncthreads();
+    frags_a(0, 0);
+    __syncthreads();       // tile 0's fragments are out of buffer 0 before iteration 0 overwrites it
+    // iteration `it` (u = it & 1): tile it + 2 (in registers since iteration it - 1) -> buffer u, whose tile `it` went
+    // into fragments before the last barrier; request tile it + 3; read tile it + 1's fragments (committed at the top of
+    // iteration it - 1) and its weight image; then the 20 CT MFMAs of tile `it` from registers.
+    for (int it0 = 0; it0 < kt; it0 += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int it = it0 + u;
+            if (!(KM_ENC_SKIP & (8 | 32))) { commit_a(u); load_a(it + 3); }
+            frags_a(u ^ 1, u ^ 1);
+            if (!(KM_ENC_SKIP & (8 | 16))) load_b(it + 1, u ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it < kt && !(KM_ENC_SKIP & 1)) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < 5; ++i)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) acc[i][ct] = KM_MFMA(af[u][i][s], bf[u][ct][s], acc[i][ct]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
+    }
+    // bias, then LayerNorm over the D columns of each of the 80 rows (this lane: rows 16 i + 4 lg + r, columns n0 + ct)
+    const int n0 = 16 * CT * wave + CT * lj;
+    {
+        float bb[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) bb[ct] = bias[n0 + ct];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][ct][r] += bb[ct];
+    }
+    float mean[5][4] = {}, rstd[5][4] = {};
+#pragma unroll
+    for (int pass = 0; pass < ((KM_ENC_SKIP & 4) ? 0 : 2); ++pass) {
+        float* P = Ps[pass];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = 0.f;
+                if (pass == 0) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ct += 2) v += acc[i][ct][r] + acc[i][ct + 1][r];
+                } else {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ct += 2) {
+                        const float d0 = acc[i][ct][r] - mean[i][r], d1 = acc[i][ct + 1][r] - mean[i][r];
+                        v += d0 * d0 + d1 * d1;
+                    }
+                }
+                v = row16_sum(v);
+                if (lj == 0) P[(16 * i + 4 * lg + r) * NW + wave] = v;
+            }
+        __syncthreads();
+        // row totals: wave w adds up the NW partials (in wave order) of rows w * RPW .. + RPW - 1, one row per lane
+        constexpr int RPW = NKc / NW;
+        if (lane < RPW) {
+            const int row = wave * RPW + lane;
+            float s = 0.f;
+            for (int w = 0; w < NW; ++w) s += P[row * NW + w];
+            Ts[pass][row] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(&Ts[pass][16 * i + 4 * lg]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (pass == 0) mean[i][r] = t[r] * (1.0f / D);
+                else rstd[i][r] = 1.0f / sqrtf(t[r] * (1.0f / D) + 1e-5f);
+            }
+        }
+    }
+    float* Yb = Y + (int64_t)b * NKc * D;
+    if ((KM_ENC_SKIP & 2) && Yb[0] != 12345.f) return;     // keeps the accumulators live without the store traffic
+    float g[CT], be[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) { g[ct] = gam[n0 + ct]; be[ct] = bet[n0 + ct]; }
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float o[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) o[ct] = (acc[i][ct][r] - mean[i][r]) * rstd[i][r] * g[ct] + be[ct];
+            float* dst = Yb + (int64_t)(16 * i + 4 * lg + r) * D + n0;
+            if constexpr (CT == 4) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            else *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
+        }
+}
+
+}  // namespace km

@@ -26,12 +26,11 @@
 
 #include "km_context.h"
 #include "km_device.h"
+#include "km_encoder_dev.h"
 #include "km_gemm.h"
 
 namespace km {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define KM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -431,7 +430,6 @@ __global__ __launch_bounds__(64) void decoder_tail_kernel(const float* __restric
 // one contiguous run), B = Y rows staged through LDS in 64-k chunks.  Replaces the scores GEMM + softmax_rows_kernel
 // and the round trip of the raw scores.
 // ---------------------------------------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 as_f32x4(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
 
 __device__ __forceinline__ float row16_max(float v) {
@@ -943,194 +941,23 @@ __global__ __launch_bounds__(256) void encoder_tn_kernel(const float* __restrict
         }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// encoder_ln_kernel<NW>: the same product as encoder_tn_kernel with ONE workgroup of NW = d / 32 waves per window, so
-// that a row's d columns are all in the workgroup and LayerNorm (two-pass, DPP row sums + a [row][wave] exchange, as in
-// the fused d=256 kernel) runs in the epilogue: no Y0 round trip, no separate ln_rows launch.
-// ---------------------------------------------------------------------------------------------------------
-// FUSE_DB: the input is the front end's POWER-mel (B, n_frames, 80) + window maxima; the dB / log conversion and the
-// row packing (T long rows, 3 short-term rows, zero rows) happen while a tile is staged, so no packed log-mel image is
-// written and read back (mel_log_packed_kernel disappears from km_forward_audio).
-struct EncSrc {
-    const float* melpow; const unsigned* melmax; int n_frames, T; LogParams lp;
-};
+template <int NW, int CT, bool FUSE_DB>
+static int launch_encoder_ln(Context* c, int64_t B, hipStream_t st, const float* xp, int KP, const EncSrc& src) {
+    hipLaunchKernelGGL((encoder_ln_kernel<NW, CT, FUSE_DB>), dim3((unsigned)B), dim3(64 * NW), 0, st, xp, dv(c, "wce_pg"), dv(c, "bce"),
+                       dv(c, "ln_g"), dv(c, "ln_b"), c->ws_generic, KP, src);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
 
-template <int NW, bool FUSE_DB>
-__global__ __launch_bounds__(64 * NW) void encoder_ln_kernel(const float* __restrict__ xp, const float* __restrict__ wpad,
-                                                             const float* __restrict__ bias, const float* __restrict__ gam,
-                                                             const float* __restrict__ bet, float* __restrict__ Y, int KP,
-                                                             EncSrc src) {
-    constexpr int NKc = 80, BN = 32 * NW, NTHR = 64 * NW, D = BN;
-    constexpr int EB = 4 * BN / NTHR;                                  // float4 of the weight tile per thread (= 2)
-    __shared__ __attribute__((aligned(16))) float As[2][4 * NKc * 4];
-    __shared__ __attribute__((aligned(16))) float Bs[2][4 * BN * 4];
-    __shared__ __attribute__((aligned(16))) float Ps[2][NKc * NW];      // LayerNorm partial sums [pass][row][wave]
-    __shared__ __attribute__((aligned(16))) float Ts[2][NKc];           // LayerNorm row totals [pass][row]
-    static_assert(NKc % NW == 0, "rows must divide evenly among the waves");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lg = lane >> 4, lj = lane & 15;
-    const int b = blockIdx.x;
-    // Tiles are fetched with buffer loads: a thread (or a row) with nothing to fetch points past the descriptor's range
-    // and gets zeros without a memory access, so neither load sits under a branch -- the compiler then keeps both ahead
-    // of the MFMAs (plain loads under `if (a_thr)` were waited on at the join, and the weight loads were sunk into
-    // commit(), i.e. no prefetch at all).
-    const float* X = FUSE_DB ? src.melpow + (int64_t)b * src.n_frames * NKc : xp + (int64_t)b * KP * NKc;
-    const unsigned x_bytes = (unsigned)((FUSE_DB ? src.n_frames : KP) * NKc * 4);
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wpad), 0, (unsigned)(D * KP * 4), 0x00020000);
-    constexpr unsigned OOB = 0x7fffffffu;
-    // FUSE_DB with >= 320 threads: one staged row per thread (16 rows x 20 float4), so the log conversion is spread over
-    // five waves instead of sitting on 80 threads' critical path
-    constexpr bool WIDE = FUSE_DB && NTHR >= 320;
-    constexpr int NA = WIDE ? 1 : 4;                                   // staged rows per loading thread
-    const bool a_thr = tid < (WIDE ? 320 : 80);
-    const int akg = tid / 20, am4 = tid - akg * 20;
-    float ref_db = 0.f, floor_db = 0.f;
-    if (FUSE_DB) log_window_consts(src.lp, __uint_as_float(src.melmax[b]), ref_db, floor_db);
-    unsigned bofs[EB];
-#pragma unroll
-    for (int e = 0; e < EB; ++e) {
-        const int idx = tid + NTHR * e, kg = idx / BN, n = idx - kg * BN;
-        bofs[e] = (unsigned)(n * KP + 4 * kg) * 4u;
+// d_model -> (waves, column tiles per wave) of the fused encoder + LayerNorm kernel
+template <bool FUSE_DB>
+static int launch_encoder_ln_for(Context* c, int64_t B, hipStream_t st, const float* xp, int KP, const EncSrc& src) {
+    switch (c->d) {
+        case 512: return launch_encoder_ln<8, 4, FUSE_DB>(c, B, st, xp, KP, src);
+        case 256: return launch_encoder_ln<8, 2, FUSE_DB>(c, B, st, xp, KP, src);
+        case 64:  return launch_encoder_ln<2, 2, FUSE_DB>(c, B, st, xp, KP, src);
     }
-    u32x4 ra[NA], rb[EB];
-    unsigned ravalid = 0;        // FUSE_DB: which of the staged rows hold a real frame (zero rows stay zero)
-    auto stage = [&](int k0) {
-        if constexpr (FUSE_DB) ravalid = 0;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int r = k0 + (WIDE ? akg : 4 * akg + i);           // packed row of this load
-            int f = r;
-            if constexpr (FUSE_DB) {                                  // packed row -> frame (mel_log_packed_kernel's mapping)
-                f = -1;
-                if (r < src.T) f = r < src.n_frames ? r : -1;
-                else if (r < src.T + 3) {
-                    const int q = r - src.T;
-                    if (src.n_frames >= 3) f = src.n_frames - 3 + q; else if (q < src.n_frames) f = q;
-                }
-                ravalid |= (f >= 0 ? 1u : 0u) << i;
-            }
-            const unsigned off = (a_thr && f >= 0) ? (unsigned)(f * NKc + 4 * am4) * 4u : OOB;
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
-        }
-#pragma unroll
-        for (int e = 0; e < EB; ++e) rb[e] = __builtin_amdgcn_raw_buffer_load_b128(wr, bofs[e] + (unsigned)k0 * 4u, 0, 0);
-    };
-    auto commit = [&](int buf) {
-#pragma unroll
-        for (int e = 0; e < EB; ++e) *reinterpret_cast<u32x4*>(&Bs[buf][(tid + NTHR * e) * 4]) = rb[e];
-#pragma unroll
-        for (int i = 0; i < NA; ++i) asm volatile("" ::"v"(ra[i]));   // an unconditional use: keeps the loads out of the branch below
-        if (a_thr) {
-            float4 a4[NA];
-#pragma unroll
-            for (int i = 0; i < NA; ++i)
-                a4[i] = make_float4(__uint_as_float(ra[i].x), __uint_as_float(ra[i].y), __uint_as_float(ra[i].z), __uint_as_float(ra[i].w));
-            if constexpr (FUSE_DB) {
-                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (src.lp.log_mode == KM_LOG_LN_EPS) {
-#pragma unroll
-                    for (int i = 0; i < NA; ++i) a4[i] = (ravalid >> i) & 1 ? log_four_t<KM_LOG_LN_EPS>(src.lp, a4[i], ref_db, floor_db) : z4;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NA; ++i) a4[i] = (ravalid >> i) & 1 ? log_four_t<KM_LOG_DB_MAX>(src.lp, a4[i], ref_db, floor_db) : z4;
-                }
-            }
-            if constexpr (WIDE) {
-                float* dst = &As[buf][((akg >> 2) * NKc + 4 * am4) * 4 + (akg & 3)];
-                dst[0] = a4[0].x; dst[4] = a4[0].y; dst[8] = a4[0].z; dst[12] = a4[0].w;
-            } else {
-                float* dst = &As[buf][(akg * NKc + 4 * am4) * 4];
-                *reinterpret_cast<float4*>(dst + 0) = make_float4(a4[0].x, a4[NA > 1 ? 1 : 0].x, a4[NA > 2 ? 2 : 0].x, a4[NA > 3 ? 3 : 0].x);
-                *reinterpret_cast<float4*>(dst + 4) = make_float4(a4[0].y, a4[NA > 1 ? 1 : 0].y, a4[NA > 2 ? 2 : 0].y, a4[NA > 3 ? 3 : 0].y);
-                *reinterpret_cast<float4*>(dst + 8) = make_float4(a4[0].z, a4[NA > 1 ? 1 : 0].z, a4[NA > 2 ? 2 : 0].z, a4[NA > 3 ? 3 : 0].z);
-                *reinterpret_cast<float4*>(dst + 12) = make_float4(a4[0].w, a4[NA > 1 ? 1 : 0].w, a4[NA > 2 ? 2 : 0].w, a4[NA > 3 ? 3 : 0].w);
-            }
-        }
-    };
-    f32x4 acc[5][2];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) { acc[i][0] = f32x4{0, 0, 0, 0}; acc[i][1] = f32x4{0, 0, 0, 0}; }
-    const int kt = KP / 16;
-    stage(0);
-    commit(0);
-    __syncthreads();
-    for (int it = 0; it < kt; ++it) {
-        const int buf = it & 1;
-        stage((it + 1 < kt ? it + 1 : it) * 16);
-        asm volatile("" ::: "memory");   // pins the prefetch loads above the MFMAs (the compiler otherwise sinks them into commit())
-        f32x4 af[5], bf[2];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[buf][(lg * NKc + 16 * i + lj) * 4]);
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) bf[jn] = *reinterpret_cast<const f32x4*>(&Bs[buf][(lg * BN + 32 * wave + 16 * jn + lj) * 4]);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                acc[i][0] = KM_MFMA(af[i][s], bf[0][s], acc[i][0]);
-                acc[i][1] = KM_MFMA(af[i][s], bf[1][s], acc[i][1]);
-            }
-        __builtin_amdgcn_sched_barrier(0);   // the tile's LDS writes stay behind its MFMAs
-        commit(buf ^ 1);
-        __syncthreads();
-    }
-    // bias, then LayerNorm over the D columns of each of the 80 rows (this lane: rows 16 i + 4 lg + r, columns n0, n0 + 16)
-    const int n0 = 32 * wave + lj;
-    {
-        const float bb0 = bias[n0], bb1 = bias[n0 + 16];
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { acc[i][0][r] += bb0; acc[i][1][r] += bb1; }
-    }
-    float mean[5][4], rstd[5][4];
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        float* P = Ps[pass];
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v;
-                if (pass == 0) v = acc[i][0][r] + acc[i][1][r];
-                else {
-                    const float d0 = acc[i][0][r] - mean[i][r], d1 = acc[i][1][r] - mean[i][r];
-                    v = d0 * d0 + d1 * d1;
-                }
-                v = row16_sum(v);
-                if (lj == 0) P[(16 * i + 4 * lg + r) * NW + wave] = v;
-            }
-        __syncthreads();
-        // row totals: wave w adds up the NW partials (in wave order) of rows w * RPW .. + RPW - 1, one row per lane
-        constexpr int RPW = NKc / NW;
-        if (lane < RPW) {
-            const int row = wave * RPW + lane;
-            float s = 0.f;
-            for (int w = 0; w < NW; ++w) s += P[row * NW + w];
-            Ts[pass][row] = s;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(&Ts[pass][16 * i + 4 * lg]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (pass == 0) mean[i][r] = t[r] * (1.0f / D);
-                else rstd[i][r] = 1.0f / sqrtf(t[r] * (1.0f / D) + 1e-5f);
-            }
-        }
-    }
-    const float g0 = gam[n0], g1 = gam[n0 + 16], be0 = bet[n0], be1 = bet[n0 + 16];
-    float* Yb = Y + (int64_t)b * NKc * D;
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float* yr = Yb + (int64_t)(16 * i + 4 * lg + r) * D + n0;
-            yr[0] = (acc[i][0][r] - mean[i][r]) * rstd[i][r] * g0 + be0;
-            yr[16] = (acc[i][1][r] - mean[i][r]) * rstd[i][r] * g1 + be1;
-        }
+    return fail(KM_ERR_UNSUPPORTED, "no fused encoder for d_model=%d", c->d);
 }
 
 static int core_generic_after_encoder(Context* c, int64_t B, const float* zemo, float* out, float* raw, float* attn, void* stream,
@@ -1145,16 +972,9 @@ int launch_core_generic_packed(Context* c, const float* xp, int64_t B, const flo
     const bool fuse_ln = !c->opt.no_ln_fusion;
     hipStream_t st = (hipStream_t)stream;
     bool ln_done = fuse_ln;
-    if (fuse_ln && d == 512)
-        hipLaunchKernelGGL((encoder_ln_kernel<16, false>), dim3((unsigned)B), dim3(1024), 0, st, xp, dv(c, "wce_pad"), dv(c, "bce"), dv(c, "ln_g"),
-                           dv(c, "ln_b"), Y, KP, EncSrc{});
-    else if (fuse_ln && d == 256)
-        hipLaunchKernelGGL((encoder_ln_kernel<8, false>), dim3((unsigned)B), dim3(512), 0, st, xp, dv(c, "wce_pad"), dv(c, "bce"), dv(c, "ln_g"),
-                           dv(c, "ln_b"), Y, KP, EncSrc{});
-    else if (fuse_ln && d == 64)
-        hipLaunchKernelGGL((encoder_ln_kernel<2, false>), dim3((unsigned)B), dim3(128), 0, st, xp, dv(c, "wce_pad"), dv(c, "bce"), dv(c, "ln_g"),
-                           dv(c, "ln_b"), Y, KP, EncSrc{});
-    else {
+    if (fuse_ln && (d == 512 || d == 256 || d == 64)) {
+        if (int rc = launch_encoder_ln_for<false>(c, B, st, xp, KP, EncSrc{})) return rc;
+    } else {
         ln_done = false;
         hipLaunchKernelGGL(encoder_tn_kernel, dim3((unsigned)((d + 127) / 128), (unsigned)B), dim3(256), 0, st, xp,
                            dv(c, "wce_pad"), dv(c, "bce"), Y, d, KP);
@@ -1174,20 +994,10 @@ LogParams plan_log_params(MelPlan* p);
 int launch_core_generic_power(Context* c, MelPlan* plan, int64_t B, int64_t n_frames, const float* zemo, float* out,
                               float* raw, float* attn, void* stream) {
     if (!generic_core_takes_power(c)) return fail(KM_ERR_UNSUPPORTED, "no fused encoder for d_model=%d", c->d);
-    const int d = c->d, KP = (c->KT + 15) / 16 * 16;
-    float* Y = c->ws_generic;
+    const int KP = (c->KT + 15) / 16 * 16;
     hipStream_t st = (hipStream_t)stream;
     EncSrc src{c->ws_melpow, c->ws_melmax, (int)n_frames, c->T, plan_log_params(plan)};
-    if (d == 512)
-        hipLaunchKernelGGL((encoder_ln_kernel<16, true>), dim3((unsigned)B), dim3(1024), 0, st, (const float*)nullptr, dv(c, "wce_pad"),
-                           dv(c, "bce"), dv(c, "ln_g"), dv(c, "ln_b"), Y, KP, src);
-    else if (d == 256)
-        hipLaunchKernelGGL((encoder_ln_kernel<8, true>), dim3((unsigned)B), dim3(512), 0, st, (const float*)nullptr, dv(c, "wce_pad"),
-                           dv(c, "bce"), dv(c, "ln_g"), dv(c, "ln_b"), Y, KP, src);
-    else
-        hipLaunchKernelGGL((encoder_ln_kernel<2, true>), dim3((unsigned)B), dim3(128), 0, st, (const float*)nullptr, dv(c, "wce_pad"),
-                           dv(c, "bce"), dv(c, "ln_g"), dv(c, "ln_b"), Y, KP, src);
-    HIP_TRY(hipGetLastError());
+    if (int rc = launch_encoder_ln_for<true>(c, B, st, nullptr, KP, src)) return rc;
     c->melmax_dirty = true;      // the maxima stay behind (only the fused d=256 core re-zeroes them)
     return core_generic_after_encoder(c, B, zemo, out, raw, attn, stream, true);
 }

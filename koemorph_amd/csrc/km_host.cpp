@@ -275,6 +275,21 @@ int finalize_host(Context* c) {
         const std::vector<float>& w = P(c, "mel_channel_encoder.weight");          // (d, KT)
         std::vector<float> wp((size_t)d * KP, 0.0f);
         for (int n = 0; n < d; ++n) std::copy(w.begin() + (size_t)n * KT, w.begin() + (size_t)(n + 1) * KT, wp.begin() + (size_t)n * KP);
+        if (d == 512 || d == 256 || d == 64) {
+            // the same weight as MFMA B-operand image for encoder_ln_kernel<NW, CT> (km_encoder_dev.h): wave w, column tile
+            // ct, lane (g, j) holds column n = 16 CT w + CT j + ct; [k block][w][ct][lane][s] = W[n][16 kb + 4 g + s]
+            const int NWv = d == 64 ? 2 : 8, CT = d / (16 * NWv), KBv = KP / 16;
+            std::vector<float> pg((size_t)d * KP);
+            for (int kb = 0; kb < KBv; ++kb)
+                for (int w2 = 0; w2 < NWv; ++w2)
+                    for (int ct = 0; ct < CT; ++ct)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 4; ++e) {
+                                const int g = l >> 4, j = l & 15, n = 16 * CT * w2 + CT * j + ct;
+                                pg[((((size_t)kb * NWv + w2) * CT + ct) * 64 + l) * 4 + e] = wp[(size_t)n * KP + 16 * kb + 4 * g + e];
+                            }
+            put(c, "wce_pg", std::move(pg));
+        }
         put(c, "wce_pad", std::move(wp));
     }
     put(c, "bf", to_f(bf));                                        // (DH)
