@@ -26,6 +26,7 @@
 
 #include "km_context.h"
 #include "km_device.h"
+#include "km_attn_dev.h"
 #include "km_encoder_dev.h"
 #include "km_gemm.h"
 
@@ -399,7 +400,6 @@ __global__ void head_mean_kernel(const float* __restrict__ p, float* __restrict_
     out[i] = s / H;
 }
 
-__device__ __forceinline__ int gen_mouth_slot(int i) { return (i >= 14 && i <= 40) ? i - 14 : (i == 51 ? 27 : -1); }
 
 // z = Hd w2 + b2 per mouth row, sigmoid, stream weights, clamp (+ the emotion logit for the expression rows)
 __global__ __launch_bounds__(64) void decoder_tail_kernel(const float* __restrict__ hd, int DH, const float* __restrict__ w2,
@@ -420,411 +420,6 @@ __global__ __launch_bounds__(64) void decoder_tail_kernel(const float* __restric
     const float bs = 1.0f / (1.0f + expf(-z));
     if (raw) raw[(int64_t)b * 52 + i] = bs;
     out[(int64_t)b * 52 + i] = fminf(fmaxf(wsum[i] * bs, 0.f), 1.f);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// scores_softmax_kernel<D>: P_b (H*28 x 80) = softmax_rows(Qk Y_b^T) for one window per workgroup (8 waves).  Wave w owns
-// row tiles 2 w' ... of the stacked heads (a row's 80 keys are 5 column tiles in ONE wave: the row maximum and sum are
-// an in-lane pass over the 5 tiles plus a DPP reduction over the 16 key lanes -- no exchange), A = the packed folded
-// query-key image (qk_pg, one coalesced KiB per wave and k block, k block outermost so a workgroup's fetch per step is
-// one contiguous run), B = Y rows staged through LDS in 64-k chunks.  Replaces the scores GEMM + softmax_rows_kernel
-// and the round trip of the raw scores.
-// ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x4 as_f32x4(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
-
-__device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));
-    return v;
-}
-
-template <int D>
-__global__ __launch_bounds__(512) void scores_softmax_kernel(const float* __restrict__ Y, const float* __restrict__ qk_pg,
-                                                             float* __restrict__ S, int rows /* H * 28 */) {
-    constexpr int NKc = 80, KB = D / 16, CH = 4, NCH = KB / CH, QS = NKc + 1;
-    static_assert(KB % CH == 0 && CH % 2 == 0, "k blocks come in chunks of four");
-    // Y_b reaches the MFMAs through LDS in chunks of 64 k ([k / 4][row, padded to 81][k % 4]: conflict-free b128 on both
-    // sides), double buffered: read from L2 once per workgroup instead of once per wave (7 x 160 KB per window before).
-    __shared__ __attribute__((aligned(16))) float Ys[2][16 * QS * 4];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lg = lane >> 4, lj = lane & 15;
-    const int MT = (rows + 15) >> 4;
-    const float* Yb = Y + (int64_t)b * NKc * D;
-    float* Sb = S + (int64_t)b * rows * NKc;
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Yb), 0, (unsigned)(NKc * D * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qk_pg), 0, (unsigned)(MT * KB * 1024), 0x00020000);
-    constexpr unsigned OOB = 0x7fffffffu;
-    u32x4 yst[3];
-    auto ystage = [&](int ch) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int idx = tid + 512 * j, row = idx >> 4, q = idx & 15;
-            yst[j] = __builtin_amdgcn_raw_buffer_load_b128(yr, idx < NKc * 16 ? (unsigned)((row * D + 64 * ch + 4 * q) * 4) : OOB, 0, 0);
-        }
-    };
-    auto ycommit = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int idx = tid + 512 * j, row = idx >> 4, q = idx & 15;
-            asm volatile("" ::"v"(yst[j]));     // unconditional use: the load stays out of the branch
-            if (idx < NKc * 16) *reinterpret_cast<u32x4*>(&Ys[buf][(q * QS + row) * 4]) = yst[j];
-        }
-    };
-    const int npass = (MT + 15) >> 4;
-    for (int pass = 0; pass < npass; ++pass) {                             // two row tiles per wave and pass
-        const int mt0 = 16 * pass + 2 * wave;
-        const bool active = mt0 < MT, two = mt0 + 1 < MT;                  // wave-uniform
-        f32x4 acc[2][5];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int nt = 0; nt < 5; ++nt) acc[i][nt] = f32x4{0, 0, 0, 0};
-        // qk_pg is [k block][row tile][lane][4]: what the workgroup's waves fetch for one k block is ONE contiguous
-        // 1 KiB x MT run (with the row tile outermost the 14 runs sat 32 KiB apart -- one L2 channel for all of them)
-        const unsigned a0o = (unsigned)((mt0 * 64 + lane) * 16), a1o = a0o + (two ? 1024u : 0u);
-        auto lda = [&](unsigned o, int kb) { return as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(ar, active ? o + (unsigned)(kb * MT) * 1024u : OOB, 0, 0)); };
-        auto ldy = [&](int buf, int kk, int nt) { return *reinterpret_cast<const f32x4*>(&Ys[buf][((4 * kk + lg) * QS + 16 * nt + lj) * 4]); };
-        ystage(0);
-        f32x4 av[2][2], yb[2][5];
-        av[0][0] = lda(a0o, 0); av[0][1] = lda(a1o, 0);
-        ycommit(0);
-        __syncthreads();
-#pragma unroll
-        for (int nt = 0; nt < 5; ++nt) yb[0][nt] = ldy(0, 0, nt);
-        for (int ch = 0; ch < NCH; ++ch) {
-            const int buf = ch & 1;
-            const bool more = ch + 1 < NCH;
-            if (more) ystage(ch + 1);
-#pragma unroll
-            for (int kk = 0; kk < CH; ++kk) {
-                const int cur = kk & 1, nxt = cur ^ 1, kb = CH * ch + kk;
-                const int kn = kb + 1 < KB ? kb + 1 : kb;
-                av[nxt][0] = lda(a0o, kn); av[nxt][1] = lda(a1o, kn);
-                if (kk + 1 < CH) {
-#pragma unroll
-                    for (int nt = 0; nt < 5; ++nt) yb[nxt][nt] = ldy(buf, kk + 1, nt);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (active) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-#pragma unroll
-                        for (int nt = 0; nt < 5; ++nt) {
-                            acc[0][nt] = KM_MFMA(av[cur][0][s], yb[cur][nt][s], acc[0][nt]);
-                            acc[1][nt] = KM_MFMA(av[cur][1][s], yb[cur][nt][s], acc[1][nt]);
-                        }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (more) ycommit(buf ^ 1);
-            __syncthreads();
-            if (more) {
-#pragma unroll
-                for (int nt = 0; nt < 5; ++nt) yb[0][nt] = ldy(buf ^ 1, 0, nt);
-            }
-        }
-        if (!active) continue;
-        // softmax over the 80 keys of every row: C/D layout puts row 4 lg + r of a tile in lanes lj = 0..15 x 5 tiles
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (i == 1 && !two) break;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float m = acc[i][0][r];
-#pragma unroll
-                for (int nt = 1; nt < 5; ++nt) m = fmaxf(m, acc[i][nt][r]);
-                m = row16_max(m);
-                float e[5], sum = 0.f;
-#pragma unroll
-                for (int nt = 0; nt < 5; ++nt) { e[nt] = __builtin_amdgcn_exp2f((acc[i][nt][r] - m) * 1.44269504088896341f); sum += e[nt]; }
-                sum = row16_sum(sum);
-                const float inv = 1.0f / sum;
-                const int row = 16 * (mt0 + i) + 4 * lg + r;
-                if (row < rows) {
-#pragma unroll
-                    for (int nt = 0; nt < 5; ++nt) Sb[(int64_t)row * NKc + 16 * nt + lj] = e[nt] * inv;
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// attn_out_kernel<D>: everything after the softmax for one window in one workgroup (8 waves): O = P V per head straight
-// from the softmaxed scores and the value projection in L2 (A fragments as one b128 per 16 keys, B as four coalesced
-// dword rows), O -> LDS [32 q][D + 8], hidden^T = Wf^T O^T with the packed fold (wf_pg), ReLU . w2, cross-wave sum in
-// wave order, sigmoid, stream weights, clamp.  Replaces the batched P V product (windows x heads tiny GEMMs), the fold
-// GEMM and decoder_tail_kernel: 9.6 MFLOP per window that the three launches spent 107 us of latency on at C4.
-// D = 512 (decoder hidden 256 = 8 waves x 32 units); heads of 64 or 32 columns.
-// ---------------------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(512) void attn_out_kernel(const float* __restrict__ S, const float* __restrict__ V,
-                                                       const float* __restrict__ wf_pg, const float* __restrict__ bf,
-                                                       const float* __restrict__ w2, const float* __restrict__ b2,
-                                                       const float* __restrict__ zemo, const float* __restrict__ wsum,
-                                                       float* __restrict__ out, float* __restrict__ raw, int H) {
-    constexpr int NKc = 80, OS = D + 8, KB = D / 16, NWv = 8;
-    static_assert(D / 2 == 32 * NWv && D == 64 * NWv, "one wave per 64 output columns and per 32 hidden units");
-    extern __shared__ __attribute__((aligned(16))) float gsm[];
-    float* Os = gsm;                   // [32][OS]
-    float* R2 = Os + 32 * OS;          // [NWv][32]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lg = lane >> 4, lj = lane & 15;
-    const int hd = D / H, tph = hd / 16;                   // column tiles per head: 4 (hd 64) or 2 (hd 32)
-    const float* Pb = S + (int64_t)b * H * 28 * NKc;
-    const float* Vb = V + (int64_t)b * NKc * D;
-    // ---- O[:, 64 w .. 64 w + 63] = P_h V_h for the head(s) that own these columns ----
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[mt][ct] = f32x4{0, 0, 0, 0};
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {                 // two passes of two column tiles; a head spans one or both
-        const int h = (64 * wave + 32 * half) / hd;
-        f32x4 a[2][5];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int q = 16 * mt + lj;
-#pragma unroll
-            for (int kb = 0; kb < 5; ++kb)
-                a[mt][kb] = q < 28 ? *reinterpret_cast<const f32x4*>(Pb + ((int64_t)h * 28 + q) * NKc + 16 * kb + 4 * lg)
-                                   : f32x4{0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-            const int ct = 2 * half + c2;
-            const float* vcol = Vb + 64 * wave + 16 * ct + lj;
-#pragma unroll
-            for (int kb = 0; kb < 5; ++kb) {
-                float bv[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) bv[s] = vcol[(int64_t)(16 * kb + 4 * lg + s) * D];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    acc[0][ct] = KM_MFMA(a[0][kb][s], bv[s], acc[0][ct]);
-                    acc[1][ct] = KM_MFMA(a[1][kb][s], bv[s], acc[1][ct]);
-                }
-            }
-        }
-    }
-    (void)tph;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Os[(16 * mt + 4 * lg + r) * OS + 64 * wave + 16 * ct + lj] = acc[mt][ct][r];
-    __syncthreads();
-    // ---- hidden^T (256 x 32 q) = Wf^T O^T; wave w owns hidden units 32 w .. 32 w + 31 ----
-    f32x4 Z[2][2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) { Z[rt][0] = f32x4{0, 0, 0, 0}; Z[rt][1] = f32x4{0, 0, 0, 0}; }
-    {
-        const f32x4* fp = reinterpret_cast<const f32x4*>(wf_pg) + (size_t)wave * 2 * KB * 64 + lane;
-#pragma unroll 4
-        for (int kb = 0; kb < KB; ++kb) {
-            const f32x4 w0 = fp[(size_t)kb * 64], w1 = fp[(size_t)(KB + kb) * 64];
-            const f32x4 o0 = *reinterpret_cast<const f32x4*>(Os + lj * OS + 16 * kb + 4 * lg);
-            const f32x4 o1 = *reinterpret_cast<const f32x4*>(Os + (16 + lj) * OS + 16 * kb + 4 * lg);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                Z[0][0] = KM_MFMA(w0[s], o0[s], Z[0][0]);
-                Z[0][1] = KM_MFMA(w0[s], o1[s], Z[0][1]);
-                Z[1][0] = KM_MFMA(w1[s], o0[s], Z[1][0]);
-                Z[1][1] = KM_MFMA(w1[s], o1[s], Z[1][1]);
-            }
-        }
-    }
-    {
-        float zp[2] = {0.f, 0.f};
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int hid = 32 * wave + 16 * rt + 4 * lg + r;
-                const float bfv = bf[hid], w2v = w2[hid];
-                zp[0] += fmaxf(Z[rt][0][r] + bfv, 0.f) * w2v;
-                zp[1] += fmaxf(Z[rt][1][r] + bfv, 0.f) * w2v;
-            }
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            zp[qt] += __shfl_xor(zp[qt], 16);
-            zp[qt] += __shfl_xor(zp[qt], 32);
-        }
-        if (lg == 0) { R2[wave * 32 + lj] = zp[0]; R2[wave * 32 + 16 + lj] = zp[1]; }
-    }
-    __syncthreads();
-    if (tid < 52) {
-        const int slot = gen_mouth_slot(tid);
-        float z;
-        if (slot >= 0) {
-            z = b2[0];
-#pragma unroll
-            for (int w = 0; w < NWv; ++w) z += R2[w * 32 + slot];
-        } else {
-            z = zemo[b];
-        }
-        const float bs = 1.0f / (1.0f + expf(-z));
-        if (raw) raw[(int64_t)b * 52 + tid] = bs;
-        out[(int64_t)b * 52 + tid] = fminf(fmaxf(wsum[tid] * bs, 0.f), 1.f);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// attn_out_v_kernel<D>: attn_out_kernel with the value projection inside, for heads of 64 columns (H = D / 64):
-// O_h = (P_h Y) Wv_h^T instead of P_h (Y Wv_h^T) -- 33 instead of 44 MFLOP per window at D = 512 and no (80, D) value
-// matrix written to and read back from memory.  Per head: T_h (32 q x D) = P_h Y with this wave's 64 columns of Y held
-// in registers for ALL heads (80 values per lane, loaded once), T_h -> LDS, then each wave owns one 16 x 16 tile of
-// O_h = T_h Wv_h^T (K = D, packed wv_pg image); two barriers per head.  Then the fold and the tail as in attn_out_kernel.
-// ---------------------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(512) void attn_out_v_kernel(const float* __restrict__ S, const float* __restrict__ Y,
-                                                         const float* __restrict__ wv_pg, const float* __restrict__ wf_pg,
-                                                         const float* __restrict__ bf, const float* __restrict__ w2,
-                                                         const float* __restrict__ b2, const float* __restrict__ zemo,
-                                                         const float* __restrict__ wsum, float* __restrict__ out,
-                                                         float* __restrict__ raw) {
-    constexpr int NKc = 80, OS = D + 8, KB = D / 16, NWv = 8, H = D / 64;
-    static_assert(D == 64 * NWv, "one wave per 64 columns");
-    extern __shared__ __attribute__((aligned(16))) float gsm[];
-    float* Ts = gsm;                   // [32][OS]  T_h = P_h Y
-    float* Os = Ts + 32 * OS;          // [32][OS]  concatenated heads
-    float* R2 = Os + 32 * OS;          // [NWv][32]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lg = lane >> 4, lj = lane & 15;
-    const float* Pb = S + (int64_t)b * H * 28 * NKc;
-    const float* Yb = Y + (int64_t)b * NKc * D;
-    // this wave's 64 columns of Y as B fragments: yv[kb][s][ct] = Y[16 kb + 4 lg + s][64 w + 16 ct + lj]
-    float yv[5][4][4];
-#pragma unroll
-    for (int kb = 0; kb < 5; ++kb)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) yv[kb][s][ct] = Yb[(int64_t)(16 * kb + 4 * lg + s) * D + 64 * wave + 16 * ct + lj];
-    const int rt = wave >> 2, oct = wave & 3;              // the O_h tile this wave owns in step b
-    for (int h = 0; h < H; ++h) {
-        // ---- a: T_h[:, 64 w .. +63] = P_h Y ----
-        f32x4 acc[2][4];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[mt][ct] = f32x4{0, 0, 0, 0};
-        f32x4 a[2][5];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int q = 16 * mt + lj;
-#pragma unroll
-            for (int kb = 0; kb < 5; ++kb)
-                a[mt][kb] = q < 28 ? *reinterpret_cast<const f32x4*>(Pb + ((int64_t)h * 28 + q) * NKc + 16 * kb + 4 * lg)
-                                   : f32x4{0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int kb = 0; kb < 5; ++kb)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    acc[0][ct] = KM_MFMA(a[0][kb][s], yv[kb][s][ct], acc[0][ct]);
-                    acc[1][ct] = KM_MFMA(a[1][kb][s], yv[kb][s][ct], acc[1][ct]);
-                }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Ts[(16 * mt + 4 * lg + r) * OS + 64 * wave + 16 * ct + lj] = acc[mt][ct][r];
-        __syncthreads();
-        // ---- b: O_h (32 x 64) = T_h Wv_h^T, one 16 x 16 tile per wave ----
-        // four independent accumulation chains (k blocks 4 j + c) keep the MFMA pipe busy from one tile; operands of the
-        // next group of four k blocks are requested before the current group's 16 MFMAs
-        f32x4 oc[4];
-#pragma unroll
-        for (int cidx = 0; cidx < 4; ++cidx) oc[cidx] = f32x4{0, 0, 0, 0};
-        const f32x4* wp = reinterpret_cast<const f32x4*>(wv_pg) + ((size_t)h * 4 + oct) * KB * 64 + lane;
-        const float* trow = Ts + (16 * rt + lj) * OS + 4 * lg;
-        f32x4 wv[4], tv[4];
-#pragma unroll
-        for (int cidx = 0; cidx < 4; ++cidx) { wv[cidx] = wp[(size_t)cidx * 64]; tv[cidx] = *reinterpret_cast<const f32x4*>(trow + 16 * cidx); }
-        for (int kb = 0; kb < KB; kb += 4) {
-            f32x4 wn[4], tn[4];
-            const int kn = kb + 4 < KB ? kb + 4 : kb;
-#pragma unroll
-            for (int cidx = 0; cidx < 4; ++cidx) {
-                wn[cidx] = wp[(size_t)(kn + cidx) * 64];
-                tn[cidx] = *reinterpret_cast<const f32x4*>(trow + 16 * (kn + cidx));
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int cidx = 0; cidx < 4; ++cidx) oc[cidx] = KM_MFMA(tv[cidx][s], wv[cidx][s], oc[cidx]);
-#pragma unroll
-            for (int cidx = 0; cidx < 4; ++cidx) { wv[cidx] = wn[cidx]; tv[cidx] = tn[cidx]; }
-        }
-        const f32x4 o = (oc[0] + oc[1]) + (oc[2] + oc[3]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Os[(16 * rt + 4 * lg + r) * OS + 64 * h + 16 * oct + lj] = o[r];
-        __syncthreads();               // T_h is free for the next head; after the last head O is complete
-    }
-    // ---- hidden^T (256 x 32 q) = Wf^T O^T; wave w owns hidden units 32 w .. 32 w + 31 ----
-    f32x4 Z[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { Z[i][0] = f32x4{0, 0, 0, 0}; Z[i][1] = f32x4{0, 0, 0, 0}; }
-    {
-        const f32x4* fp = reinterpret_cast<const f32x4*>(wf_pg) + (size_t)wave * 2 * KB * 64 + lane;
-#pragma unroll 4
-        for (int kb = 0; kb < KB; ++kb) {
-            const f32x4 w0 = fp[(size_t)kb * 64], w1 = fp[(size_t)(KB + kb) * 64];
-            const f32x4 o0 = *reinterpret_cast<const f32x4*>(Os + lj * OS + 16 * kb + 4 * lg);
-            const f32x4 o1 = *reinterpret_cast<const f32x4*>(Os + (16 + lj) * OS + 16 * kb + 4 * lg);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                Z[0][0] = KM_MFMA(w0[s], o0[s], Z[0][0]);
-                Z[0][1] = KM_MFMA(w0[s], o1[s], Z[0][1]);
-                Z[1][0] = KM_MFMA(w1[s], o0[s], Z[1][0]);
-                Z[1][1] = KM_MFMA(w1[s], o1[s], Z[1][1]);
-            }
-        }
-    }
-    {
-        float zp[2] = {0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int hid = 32 * wave + 16 * i + 4 * lg + r;
-                const float bfv = bf[hid], w2v = w2[hid];
-                zp[0] += fmaxf(Z[i][0][r] + bfv, 0.f) * w2v;
-                zp[1] += fmaxf(Z[i][1][r] + bfv, 0.f) * w2v;
-            }
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            zp[qt] += __shfl_xor(zp[qt], 16);
-            zp[qt] += __shfl_xor(zp[qt], 32);
-        }
-        if (lg == 0) { R2[wave * 32 + lj] = zp[0]; R2[wave * 32 + 16 + lj] = zp[1]; }
-    }
-    __syncthreads();
-    if (tid < 52) {
-        const int slot = gen_mouth_slot(tid);
-        float z;
-        if (slot >= 0) {
-            z = b2[0];
-#pragma unroll
-            for (int w = 0; w < NWv; ++w) z += R2[w * 32 + slot];
-        } else {
-            z = zemo[b];
-        }
-        const float bs = 1.0f / (1.0f + expf(-z));
-        if (raw) raw[(int64_t)b * 52 + tid] = bs;
-        out[(int64_t)b * 52 + tid] = fminf(fmaxf(wsum[tid] * bs, 0.f), 1.f);
-    }
 }
 
 __global__ void gather_clip_logits_kernel(const float* __restrict__ zclip, float* __restrict__ zwin, int64_t nw, int64_t w0, int wpc) {
@@ -1085,16 +680,21 @@ static int core_generic_after_encoder(Context* c, int64_t B, const float* zemo, 
         hipLaunchKernelGGL(head_mean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, S, attn,
                            B, H, 28 * NKk);
     }
-    if (d == 512 && DH == 256 && NKk == 80 && H == 8 && c->packed.count("wf_pg") && c->packed.count("wv_pg") &&
+    if (d == 512 && DH == 256 && NKk == 80 && (H == 8 || H == 16) && c->packed.count("wf_pg") && c->packed.count("wv_bg") &&
         !c->opt.no_out_fusion && !c->opt.no_v_fusion) {
-        // heads of 64 columns: the value projection happens inside the output kernel, O_h = (P_h Y) Wv_h^T
-        constexpr int lds = (2 * 32 * (512 + 8) + 8 * 32) * (int)sizeof(float);
+        // the value projection, P V and the decoder in one kernel per window, V in registers (8 or 16 heads)
+        constexpr int lds = (2 * 16 * 81 * 4 + 32 * (512 + 8) + 8 * 32) * (int)sizeof(float);
         static PerDeviceOnce once;
-        if (once.first(c->device))
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_out_v_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-
-        hipLaunchKernelGGL(attn_out_v_kernel<512>, dim3((unsigned)B), dim3(512), lds, (hipStream_t)stream, S, Y, dv(c, "wv_pg"),
-                           dv(c, "wf_pg"), dv(c, "bf"), dv(c, "w2"), dv(c, "b2"), zemo, dv(c, "wsum"), out, raw);
+        if (once.first(c->device)) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_out_vr_kernel<512, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_out_vr_kernel<512, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        }
+        if (H == 8)
+            hipLaunchKernelGGL((attn_out_vr_kernel<512, 1>), dim3((unsigned)B), dim3(512), lds, (hipStream_t)stream, S, Y, dv(c, "wv_bg"),
+                               dv(c, "wf_pg"), dv(c, "bf"), dv(c, "w2"), dv(c, "b2"), zemo, dv(c, "wsum"), out, raw);
+        else
+            hipLaunchKernelGGL((attn_out_vr_kernel<512, 2>), dim3((unsigned)B), dim3(512), lds, (hipStream_t)stream, S, Y, dv(c, "wv_bg"),
+                               dv(c, "wf_pg"), dv(c, "bf"), dv(c, "w2"), dv(c, "b2"), zemo, dv(c, "wsum"), out, raw);
         HIP_TRY(hipGetLastError());
         return KM_OK;
     }

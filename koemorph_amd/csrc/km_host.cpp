@@ -253,21 +253,21 @@ int finalize_host(Context* c) {
                     }
         put(c, "qk_pg", std::move(qk_pg));
     }
-    if (d % 16 == 0 && hd % 16 == 0) {
-        // value projection as MFMA B-operand image for attn_out_kernel<.., true>: O_h = (P_h Y) Wv_h^T;
-        // [h][ct][kb][lane][s] = Wv[h * hd + 16 ct + j][16 kb + 4 g + s]
-        const int CT = hd / 16, KBv = d / 16;
-        std::vector<float> wv_pg((size_t)H * CT * KBv * 64 * 4);
-        for (int h = 0; h < H; ++h)
-            for (int ct = 0; ct < CT; ++ct)
-                for (int kb = 0; kb < KBv; ++kb)
+    if (d == 512) {
+        // value projection as MFMA B-operand image for attn_out_vr_kernel: V = Y Wv^T with wave w owning columns 64 w + 16 ct + j;
+        // [kb][w][ct][lane][s] = Wv[64 w + 16 ct + j][16 kb + 4 g + s]
+        const int NWv = d / 64, KBv = d / 16;
+        std::vector<float> wv_bg((size_t)d * d);
+        for (int kb = 0; kb < KBv; ++kb)
+            for (int w2 = 0; w2 < NWv; ++w2)
+                for (int ct = 0; ct < 4; ++ct)
                     for (int l = 0; l < 64; ++l)
                         for (int e = 0; e < 4; ++e) {
                             const int g = l >> 4, j = l & 15;
-                            wv_pg[((((size_t)h * CT + ct) * KBv + kb) * 64 + l) * 4 + e] =
-                                (float)Wv[(size_t)(h * hd + 16 * ct + j) * d + 16 * kb + 4 * g + e];
+                            wv_bg[((((size_t)kb * NWv + w2) * 4 + ct) * 64 + l) * 4 + e] =
+                                (float)Wv[(size_t)(64 * w2 + 16 * ct + j) * d + 16 * kb + 4 * g + e];
                         }
-        put(c, "wv_pg", std::move(wv_pg));
+        put(c, "wv_bg", std::move(wv_bg));
     }
     {   // channel encoder weight with K padded to a multiple of 16 (zeros): rows stay 16-byte aligned and the long
         // and short-term columns form ONE contraction for encoder_tn_kernel (km_generic.hip)
