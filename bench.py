@@ -38,10 +38,16 @@ EXECUTED_MFMA_FLOPS_PER_FRAME = 8 * 2148 * 2048   # what core_fused_kernel issue
 #                                           8 waves x 2148 v_mfma_f32_16x16x4_f32 x 2048 FLOP = 35.19 M (PMC: 9.011 G per 256 windows)
 BYTES_PER_FRAME_AUDIO = 136448 * 4        # fp32 audio in
 POWER_MEL_BYTES_PER_FRAME = 257 * 80 * 4  # front end -> core hand-off (written once, read once)
-# d=512 / T=512 / H=8 (C4): reference formulation 190 M; the folded chain executes encoder 80x528x512 (43.3 M) + stacked scores
-# 256x80x512 (21.0 M) + P_h Y 8x32x80x512 (21.0 M) + T_h Wv_h^T 8x32x512x64 (16.8 M) + fold 32x512x256 (8.4 M) = 110.4 M
+# d=512 / T=512 (C4): reference formulation 190 M per window.  The folded chain issues, per window, encoder 8 waves x 33 k blocks x
+# 80 MFMAs (43.25 M), stacked scores ceil(28 H / 16) row tiles x 5 x 128 MFMAs (H=8: 18.35 M, H=16: 36.70 M) and the output kernel
+# 8 waves x 3232 MFMAs (V = Y Wv^T 2560, P V 160, decoder fold 512: 52.95 M) -- v_mfma_f32_16x16x4_f32, 2048 FLOP each
 ALGORITHMIC_FLOPS_PER_FRAME_C4 = 190e6
-EXECUTED_FLOPS_PER_FRAME_C4 = 110.4e6
+
+
+def executed_flops_per_frame_c4(heads: int) -> float:
+    return 2048.0 * (8 * 33 * 80 + -(-28 * heads // 16) * 5 * 128 + 8 * 3232)
+
+
 # training (C3): forward (unfolded, 48.8 M) + backward (2x) per window
 TRAIN_FLOPS_PER_WINDOW = 3 * 48.8e6
 PEAK_F32_MFMA_TFLOPS = 157.3              # /opt/skills/guides/MI355X_MICROARCH.md chip table
@@ -531,7 +537,7 @@ def run_c4(args, rk: Ranks):
     dt = timed(rk, lambda: eng.forward_audio(audio, emo, out=out), args.steps, args.warmup)
     ms = dt / args.steps * 1e3
     value = B * rk.world * args.steps / dt
-    exe = EXECUTED_FLOPS_PER_FRAME_C4 * B / (ms * 1e-3) / 1e12
+    exe = executed_flops_per_frame_c4(H) * B / (ms * 1e-3) / 1e12
     alg = ALGORITHMIC_FLOPS_PER_FRAME_C4 * B / (ms * 1e-3) / 1e12
     return {
         "metric": "blendshape frames/sec (52-coef, 512-win, d_model=512, 60 fps)", "value": round(value, 1), "unit": "frames/s",
@@ -544,7 +550,9 @@ def run_c4(args, rk: Ranks):
         "roofline": {"kernel": "whole step (front end + encoder_ln + scores_softmax + attn_out)", "bound": "mfma",
                      "achieved": round(exe, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(exe / PEAK_F32_MFMA_TFLOPS, 4), "algorithmic_frac": round(alg / PEAK_F32_MFMA_TFLOPS, 4),
-                     "traffic": None, "note": "executed FLOPs of the folded chain at H=8 (bench.py header); H=16 executes more"},
+                     "traffic": None, "executed_flops_per_window": executed_flops_per_frame_c4(H),
+                     "note": "MFMA FLOPs the three core kernels issue (bench.py header) over the WHOLE step incl. the VALU front end; "
+                             "per kernel: profiles/r02_c4_kernel_stats.txt, r02_c4_harness.txt"},
         "cpu_baseline": None,
     }
 
