@@ -145,6 +145,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     if _lib is not None:
         return _lib
     path = _build.LIB_PATH
+    if os.environ.get("KM_LIBRARY"):          # A/B builds of the same ABI (tools/micro/mel_variants.sh): loaded as they are
+        path, build_if_missing = os.environ["KM_LIBRARY"], False
     if build_if_missing and _build.is_stale():
         try:
             _build.build_library()

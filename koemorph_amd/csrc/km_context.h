@@ -28,6 +28,10 @@ struct Packed {
     float* dev = nullptr;
 };
 
+constexpr int kMelRpWaves = 8;      // waves per workgroup of mel_power_rp_kernel
+constexpr int kMelRpGroups = 4;     // filter groups a wave can hold (8 x 4 x 4 = up to 128 filters)
+constexpr int kMelRpRow = 580;      // power-row stride in dwords (4 mod 64: see the mel stage), >= fbg_extent
+
 // Sparse triangular mel filterbank + window for one front-end configuration.
 struct MelPlan {
     km_mel_config cfg{};
@@ -38,8 +42,12 @@ struct MelPlan {
     std::vector<int32_t> fb_count;  // n_mels: number of bins
     std::vector<int32_t> fb_offset; // n_mels: offset into fb_weight
     std::vector<float> fb_weight;   // concatenated non-zero weights
-    std::vector<int32_t> fb4_desc;  // n_mels: the same filters in 16-bin trips (km_host.cpp build_mel_plan)
-    std::vector<float> fb4_weight;  // 16 * sum(trips)
+    // the same filters for mel_power_rp_kernel (km_host.cpp build_mel_plan): groups of four consecutive filters dealt to
+    // the workgroup's waves (balanced by length); a lane owns one (frame, filter) pair and walks the filter four bins a step
+    std::vector<int32_t> fbg_gid;   // [wave][slot]: group (filters 4 gid .. 4 gid + 3) or -1
+    std::vector<int32_t> fbg_desc;  // [wave][slot][filter in group]: first bin / 4 | steps << 8 | tap offset (float4) << 16
+    std::vector<float> fbg_weight;  // four taps x 1/4 per (filter, step), zero padded to the group's step count
+    int fbg_extent = 0;             // 1 + the highest bin a step reads (the power rows are padded with zeros up to it)
     // device mirrors
     float* d_window = nullptr;
     float* d_twiddle = nullptr;
@@ -47,8 +55,9 @@ struct MelPlan {
     int32_t* d_fb_count = nullptr;
     int32_t* d_fb_offset = nullptr;
     float* d_fb_weight = nullptr;
-    int32_t* d_fb4_desc = nullptr;
-    float* d_fb4_weight = nullptr;
+    int32_t* d_fbg_gid = nullptr;
+    int32_t* d_fbg_desc = nullptr;
+    float* d_fbg_weight = nullptr;
     bool uploaded = false;
 };
 

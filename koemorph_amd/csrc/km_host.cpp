@@ -463,19 +463,53 @@ MelPlan* build_mel_plan(const km_mel_config& cfg) {
         }
     }
     if (p->fb_weight.empty()) p->fb_weight.push_back(0.0f);
-    // second image of the same filters for mel_power_rp_kernel: filter i starts at its first bin rounded down to a
-    // multiple of 4 and is zero-padded to whole trips of 16 bins (4 lanes x one 16-byte LDS read each);
-    // descriptor = first bin | trips << 10 | (offset / 16) << 16
-    p->fb4_desc.assign(nm, 0);
-    for (int i = 0; i < nm; ++i) {
-        const int st4 = p->fb_start[i] & ~3, lead = p->fb_start[i] - st4;
-        const int trips = p->fb_count[i] > 0 ? (lead + p->fb_count[i] + 15) / 16 : 0;
-        const size_t off = p->fb4_weight.size();
-        p->fb4_desc[i] = (int32_t)((uint32_t)st4 | ((uint32_t)trips << 10) | ((uint32_t)(off / 16) << 16));
-        p->fb4_weight.resize(off + (size_t)16 * trips, 0.0f);
-        for (int k = 0; k < p->fb_count[i]; ++k) p->fb4_weight[off + lead + k] = p->fb_weight[p->fb_offset[i] + k];
+    // second image of the same filters for mel_power_rp_kernel: groups of four consecutive filters; a lane owns one
+    // (frame, filter) pair and walks its filter four bins (one 16-byte LDS read of powers, one 16-byte load of taps) per
+    // step from the filter's first bin rounded down to a multiple of 4; every filter of a group is zero-padded to the
+    // group's step count.  The taps carry the 1/4 of |X|^2 = |2X|^2 / 4 (exact).  Groups go to the waves longest first,
+    // each to the wave with the least steps so far (<= kMelRpGroups per wave).
+    {
+        const int ng = (nm + 3) / 4;
+        std::vector<int> gsteps(ng, 0), order(ng);
+        auto fsteps = [&](int i) { return (i < nm && p->fb_count[i] > 0) ? ((p->fb_start[i] & 3) + p->fb_count[i] + 3) / 4 : 0; };
+        for (int g = 0; g < ng; ++g) {
+            for (int s = 0; s < 4; ++s) gsteps[g] = std::max(gsteps[g], fsteps(4 * g + s));
+            order[g] = g;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return gsteps[x] > gsteps[y]; });
+        std::vector<std::vector<int>> mine(kMelRpWaves);
+        std::vector<int> load(kMelRpWaves, 0);
+        const bool fits = ng <= kMelRpWaves * kMelRpGroups;
+        for (int oi = 0; fits && oi < ng; ++oi) {
+            int best = -1;
+            for (int w = 0; w < kMelRpWaves; ++w)
+                if ((int)mine[w].size() < kMelRpGroups && (best < 0 || load[w] < load[best])) best = w;
+            mine[best].push_back(order[oi]);
+            load[best] += gsteps[order[oi]];
+        }
+        if (fits) {
+            p->fbg_gid.assign((size_t)kMelRpWaves * kMelRpGroups, -1);
+            p->fbg_desc.assign((size_t)kMelRpWaves * kMelRpGroups * 4, 0);
+            for (int w = 0; w < kMelRpWaves; ++w)
+                for (size_t gi = 0; gi < mine[w].size(); ++gi) {
+                    const int g = mine[w][gi], steps = gsteps[g];
+                    p->fbg_gid[(size_t)w * kMelRpGroups + gi] = g;
+                    for (int s = 0; s < 4; ++s) {
+                        const int i = 4 * g + s;
+                        const bool live = i < nm && p->fb_count[i] > 0;
+                        const int st4 = live ? (p->fb_start[i] & ~3) : 0, lead = live ? p->fb_start[i] - st4 : 0;
+                        const size_t off = p->fbg_weight.size();
+                        p->fbg_weight.resize(off + (size_t)4 * steps, 0.0f);
+                        for (int k = 0; live && k < p->fb_count[i]; ++k) p->fbg_weight[off + lead + k] = 0.25f * p->fb_weight[p->fb_offset[i] + k];
+                        p->fbg_desc[((size_t)w * kMelRpGroups + gi) * 4 + s] =
+                            (int32_t)((uint32_t)(st4 / 4) | ((uint32_t)steps << 8) | ((uint32_t)(off / 4) << 16));
+                        p->fbg_extent = std::max(p->fbg_extent, st4 + 4 * steps);
+                    }
+                }
+            if (p->fbg_extent > kMelRpRow || p->fbg_weight.size() / 4 > 65535) { p->fbg_gid.clear(); p->fbg_desc.clear(); }
+        }
+        if (p->fbg_weight.empty()) p->fbg_weight.assign(4, 0.0f);
     }
-    if (p->fb4_weight.empty()) p->fb4_weight.assign(16, 0.0f);
     return p;
 }
 

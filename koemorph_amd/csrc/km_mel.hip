@@ -114,9 +114,10 @@ struct MelArgs {
     const int* fb_offset;
     const float* fb_weight;
     int fb_nnz;           // number of stored filter weights
-    const int* fb4_desc;  // 16-bin-trip image of the filters (mel_power_rp_kernel)
-    const float* fb4_weight;
-    int fb4_nnz;
+    const int* fbg_gid;   // grouped image of the filters (mel_power_rp_kernel; MelPlan::fbg_*)
+    const int* fbg_desc;
+    const float* fbg_weight;
+    int fbg_nw;           // floats in fbg_weight
     float* melpow;        // (B, n_frames, n_mels)
     unsigned* melmax;     // (B) float bits, zero-initialised
     EmoArgs emo;          // optional: the window's emotion logit, computed by the last workgroup of each window
@@ -362,9 +363,16 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
 // ~120 registers instead of ~240, so 512-thread workgroups run at 4 waves per SIMD (2 workgroups of 80 KB LDS per
 // CU).  The two-frames-per-wave kernel above is latency bound (T ~ 41 us + 136 us / waves-per-SIMD at the C2 shape).
 // ---------------------------------------------------------------------------------------------------------
+// KM_MEL_SKIP (A/B builds only, tools/micro/mel_variants.sh; 0 in the library): bit 0 no mel filter stage, bit 1 no LDS
+// exchanges between the FFT passes (data stays in registers: wrong spectra, same arithmetic), bit 2 no FFT arithmetic,
+// bit 3 no audio loads
+#ifndef KM_MEL_SKIP
+#define KM_MEL_SKIP 0
+#endif
 namespace melrp {
-constexpr int WAVES = 8, NT = 512, FPB = 16, NC = 512, FFT_BUF = 576;
-constexpr int NFS = 528;   // power-row stride in dwords: 16 (mod 64), see the mel stage
+constexpr int WAVES = kMelRpWaves, NT = 64 * WAVES, FPB = 16, NC = 512, FFT_BUF = 576, NGW = kMelRpGroups;
+constexpr int NFS = kMelRpRow;   // power-row stride in dwords: 4 (mod 64), see the mel stage
+static_assert(WAVES == 8 && NFS % 64 == 4 && NFS >= 528, "mel stage layout");
 
 // Complex arithmetic on register pairs, one packed instruction (v_pk_add/mul/fma_f32) per complex operation.
 // Multiplications by -i, conjugations and the cross terms of a complex product are half-selects (op_sel / op_sel_hi)
@@ -533,7 +541,7 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
     float2* fbuf = reinterpret_cast<float2*>(smem);                     // [WAVES][FFT_BUF]
     float* pw = smem + WAVES * FFT_BUF * 2;                              // [FPB][NFS]
     float* redmax = pw + FPB * NFS;                                      // [WAVES]
-    float* fbw = redmax + WAVES;                                         // [fb4_nnz] filter taps x 1/4, 16-bin trips
+    float* fbw = redmax + WAVES;                                         // [fbg_nw] filter taps x 1/4, four per step
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -555,8 +563,8 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
         else emotion_window_generic(a.emo, EmoShape{a.emo.d, a.emo.DH}, gw, pw);
     }
 
-    for (int i = tid; i < a.fb4_nnz; i += NT) fbw[i] = 0.25f * a.fb4_weight[i];
-    if (tid < FPB * 15) pw[(tid / 15) * NFS + 513 + tid % 15] = 0.f;     // row padding read by the 16-bin mel trips
+    for (int i = tid; i < a.fbg_nw; i += NT) fbw[i] = a.fbg_weight[i];
+    for (int i = tid; i < FPB * (NFS - 513); i += NT) pw[(i / (NFS - 513)) * NFS + 513 + i % (NFS - 513)] = 0.f;   // row padding the mel steps may read
 
     // lane-constant operands (56 registers)
     const int n2 = lane & 7, k0 = lane >> 3;
@@ -570,18 +578,22 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) twp[i] = ld2(a.twiddle + lane + 64 * i);   // W_1024^k, k = lane + 64 i
 
-    // filters of this wave (wave, wave + 8, ...): descriptor j (first bin | trips << 10 | weight offset / 16 << 16)
-    // lives in lane j and is broadcast with v_readlane
-    const int n_my = (a.n_mels - wave + WAVES - 1) / WAVES;
-    int my_desc = 0;
-    if (lane < n_my) my_desc = a.fb4_desc[wave + WAVES * lane];
+    // filter groups of this wave: lane = 16 x (filter in group) + frame; group slot i of the wave holds group my_gid[i]
+    // (wave-uniform, -1 = none) and this lane's descriptor first bin / 4 | steps << 8 | tap offset << 16 (steps equal
+    // within a group).  The descriptors are re-read (L1) ahead of every chunk's barrier rather than held in registers
+    // across the FFT, which has none to spare.
+    int my_gid[NGW];
+#pragma unroll
+    for (int i = 0; i < NGW; ++i) my_gid[i] = __builtin_amdgcn_readfirstlane(a.fbg_gid[wave * NGW + i]);
+    const int* my_desc_p = a.fbg_desc + wave * NGW * 4 + (lane >> 4);
     // Use every loop-invariant operand once before the loop: the waits for their loads are placed here, not (with
     // conservative counts that would also drain the sample prefetch) at their first use inside the loop.
 #pragma unroll
     for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(win2[i]), "v"(tw1[i]), "v"(tw2[i]));
 #pragma unroll
     for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(twp[i]));
-    asm volatile("" ::"v"(my_desc));
+#pragma unroll
+    for (int i = 0; i < NGW; ++i) asm volatile("" ::"s"(my_gid[i]));
 
     float vmax = 0.f;
     // Software prefetch: the samples of this wave's NEXT frame are requested as soon as pass 1 has left the registers
@@ -590,7 +602,11 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
     v2f zn[8];
     bool zn_ok = false;                                                  // wave-uniform: zn holds the next frame
     const int fmul = a.frame_mul;
-    if (blockIdx.x * FPB + wave < a.n_frames) zn_ok = load_frame_rp_fast<RING>(x, Lv, rs, a.hop, (blockIdx.x * FPB + wave) * fmul, lane, zn);
+    if (KM_MEL_SKIP & 8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) zn[i] = v2f{0.001f * lane, 0.5f + i};
+        zn_ok = true;
+    } else if (blockIdx.x * FPB + wave < a.n_frames) zn_ok = load_frame_rp_fast<RING>(x, Lv, rs, a.hop, (blockIdx.x * FPB + wave) * fmul, lane, zn);
     for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const int f0 = chunk * FPB;
 #pragma unroll 1
@@ -610,42 +626,52 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) z[i] = zn[i] * win2[i];
                 // ---- pass 1: radix-8 over n0 (m = 64 n0 + lane) ----
-                dif8(z);
-                cmul7(z, tw1);
+                if (!(KM_MEL_SKIP & 4)) { dif8(z); cmul7(z, tw1); }
+                if (!(KM_MEL_SKIP & 2)) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) buf[bitrev(i, 3) * 72 + lane] = z[i];
+                    for (int i = 0; i < 8; ++i) buf[bitrev(i, 3) * 72 + lane] = z[i];
+                }
                 __builtin_amdgcn_wave_barrier();
                 {
                     const int fnext = pi + 1 < FPB / WAVES ? f + WAVES : (chunk + (int)gridDim.x) * FPB + wave;
-                    zn_ok = fnext < a.n_frames && load_frame_rp_fast<RING>(x, Lv, rs, a.hop, fnext * fmul, lane, zn);
+                    if (!(KM_MEL_SKIP & 8)) zn_ok = fnext < a.n_frames && load_frame_rp_fast<RING>(x, Lv, rs, a.hop, fnext * fmul, lane, zn);
                 }
                 // ---- pass 2: radix-8 over n1 (lane = 8 n1 + n2); this lane: n2 = lane & 7, k0 = lane >> 3 ----
                 v2f y[8];
-                lds_read8<64>(rd2, y);                                    // y[n1] = buf[k0 * 72 + 8 n1 + n2]
+                if (!(KM_MEL_SKIP & 2)) lds_read8<64>(rd2, y);            // y[n1] = buf[k0 * 72 + 8 n1 + n2]
+                else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) y[i] = z[i];
+                }
                 __builtin_amdgcn_wave_barrier();
-                dif8(y);
-                cmul7(y, tw2);
+                if (!(KM_MEL_SKIP & 4)) { dif8(y); cmul7(y, tw2); }
                 // transposed image indexed by c = k0 + 8 k1, row stride 9 (padding keeps every address base + immediate;
                 // the residual 2-way conflict on 3 of 32 slots is cheaper than per-access swizzle arithmetic)
+                if (!(KM_MEL_SKIP & 2)) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) buf[(k0 + 8 * bitrev(i, 3)) * 9 + n2] = y[i];
+                    for (int i = 0; i < 8; ++i) buf[(k0 + 8 * bitrev(i, 3)) * 9 + n2] = y[i];
+                }
                 __builtin_amdgcn_wave_barrier();
                 // ---- pass 3: radix-8 over n2; this lane: c = lane; output k = c + 64 k2 ----
-                lds_read8<8>(rd3, y);                                     // y[q] = buf[lane * 9 + q]
+                if (!(KM_MEL_SKIP & 2)) lds_read8<8>(rd3, y);             // y[q] = buf[lane * 9 + q]
                 __builtin_amdgcn_wave_barrier();
-                dif8(y);
+                if (!(KM_MEL_SKIP & 4)) dif8(y);
+                if (!(KM_MEL_SKIP & 2)) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) buf[lane + 64 * bitrev(i, 3)] = y[i];
+                    for (int i = 0; i < 8; ++i) buf[lane + 64 * bitrev(i, 3)] = y[i];
+                }
                 __builtin_amdgcn_wave_barrier();
                 // ---- real-input post-processing + |.|^2, two bins (k and 512 - k) per packed instruction ----
                 float* pwr = pw + fl * NFS;
                 v2f zk[4], zc[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    zk[i] = buf[lane + 64 * i];
-                    zc[i] = buf[(NC - lane - 64 * i) & (NC - 1)];
+                    if (!(KM_MEL_SKIP & 2)) {
+                        zk[i] = buf[lane + 64 * i];
+                        zc[i] = buf[(NC - lane - 64 * i) & (NC - 1)];
+                    } else { zk[i] = y[i]; zc[i] = y[i + 4]; }
                 }
-                post4(zk, zc, twp);                                       // the 1/4 of |X|^2 lives in the filter weights
+                if (!(KM_MEL_SKIP & 4)) post4(zk, zc, twp);                                       // the 1/4 of |X|^2 lives in the filter weights
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     pwr[lane + 64 * i] = zk[i].x;
@@ -657,46 +683,50 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
                 }
             }
         }
+        int my_desc[NGW];
+#pragma unroll
+        for (int i = 0; i < NGW; ++i) my_desc[i] = my_desc_p[4 * i];
         __syncthreads();
-        {   // Sparse triangular mel filters.  One filter per wave at a time (descriptor through v_readlane, scalar loop
-            // control); lanes = 16 frames x 4 phases, a trip covers 16 bins: every lane reads 4 consecutive powers and
-            // 4 weights with one ds_read_b128 each (the plan aligns filters to 4 bins and pads them to whole trips).
-            // Row stride 528 = 16 (mod 64) dwords: the 16 lanes of a b128 beat (4 frames x 16 bins) cover all 64 banks.
-            // Results go straight to HBM (the 80 filters of a frame are written by 8 waves within one chunk, L2 merges
-            // the lines), which saves the staging buffer and its bank-conflicted transposition.
-            const int ph = lane & 3, flm = lane >> 2;
+        {   // Sparse triangular mel filters.  A lane owns one (frame, filter) pair: lane = 16 x (filter in its group of
+            // four) + frame, and walks the filter four bins a step: one ds_read_b128 of powers and one 16-byte load of taps
+            // (the 16 frame lanes of a filter share the address; the taps come through the vector cache, not LDS: the
+            // stage is bound by LDS bandwidth, and the power reads alone are 6 KB per frame here against 16 KB for powers
+            // + taps in 16-bin trips with one filter per wave -- 24 of the kernel's 77 us at the C2 shape).  Row stride
+            // 580 = 4 (mod 64) dwords: the 16 lanes of a b128 beat (16 frames, one filter) cover all 64 banks.  No
+            // cross-lane reduction, no per-filter descriptor traffic.  Results go straight to HBM (the 80 filters of a
+            // frame are written by 8 waves within one chunk, L2 merges the lines).
+            const int slot = lane >> 4, flm = lane & 15;
             const bool fvalid = f0 + flm < a.n_frames;
-            const float4* prow = reinterpret_cast<const float4*>(pw + flm * NFS) + ph;
-            const float4* wrow = reinterpret_cast<const float4*>(fbw) + ph;
-            float* dst = a.melpow + ((int64_t)b * a.n_frames + f0 + flm) * a.n_mels + wave;
-            // After the quad reduction all four phase lanes of a frame hold the filter's sum: phase p keeps the results of
-            // filters j = p (mod 4) and one store per four filters writes them (4 x fewer, fuller store instructions).
-            float keep = 0.f, fmx = 0.f;
-            for (int j = 0; j < n_my; ++j) {
-                const int desc = __builtin_amdgcn_readlane(my_desc, j);
-                const int trips = (desc >> 10) & 63;
-                const float4* pr = prow + ((desc & 1023) >> 2);
-                const float4* wt = wrow + 4 * (int)((unsigned)desc >> 16);
+            const float4* prow = reinterpret_cast<const float4*>(pw + flm * NFS);
+            const float4* wbase = reinterpret_cast<const float4*>(fbw);
+            float* dst = a.melpow + ((int64_t)b * a.n_frames + f0 + flm) * a.n_mels + slot;
+            float fmx = 0.f;
+#pragma unroll
+            for (int i = 0; i < ((KM_MEL_SKIP & 1) ? 0 : NGW); ++i) {
+                if (my_gid[i] < 0) break;                                              // wave-uniform
+                const int desc = my_desc[i];
+                const int steps = __builtin_amdgcn_readfirstlane((desc >> 8) & 255);
+                const float4* pr = prow + (desc & 255);
+                const float4* wt = wbase + ((unsigned)desc >> 16);
                 v2f acc = {0.f, 0.f};
-                for (int t = 0; t < trips; ++t) {
-                    const float4 pv = pr[4 * t], wv = wt[4 * t];
+                float4 wv = wt[0], wn = wt[steps > 1 ? 1 : 0], pv = pr[0];
+                for (int t = 0; t < steps; ++t) {                                      // taps two steps ahead, powers one
+                    const float4 wnn = wt[t + 2 < steps ? t + 2 : t], pn = pr[t + 1 < steps ? t + 1 : t];
                     acc = __builtin_elementwise_fma(v2f{pv.x, pv.y}, v2f{wv.x, wv.y}, acc);
                     acc = __builtin_elementwise_fma(v2f{pv.z, pv.w}, v2f{wv.z, wv.w}, acc);
+                    pv = pn; wv = wn; wn = wnn;
                 }
                 float r = acc.x + acc.y;
-                r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
-                r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
                 r = fvalid ? r : 0.f;
                 asm("v_max_f32 %0, %0, %1" : "+v"(vmax) : "v"(r));
                 asm("v_max_f32 %0, %0, %1" : "+v"(fmx) : "v"(r));
-                keep = ph == (j & 3) ? r : keep;
-                if ((j & 3) == 3 || j == n_my - 1) {                                   // wave-uniform
-                    const int jm = (j & ~3) + ph;
-                    if (fvalid && jm < n_my) dst[WAVES * jm] = keep;
-                }
+                if (fvalid && 4 * my_gid[i] + slot < a.n_mels) dst[4 * my_gid[i]] = r;
             }
-            if (a.frame_max && ph == 0 && fvalid)                         // this wave's filters of frame f0 + flm
-                atomicMax(a.frame_max + (int64_t)b * a.n_frames + f0 + flm, __float_as_uint(fmx));
+            if (a.frame_max) {                                             // this wave's filters of frame f0 + flm
+                fmx = fmaxf(fmx, __shfl_xor(fmx, 16));
+                fmx = fmaxf(fmx, __shfl_xor(fmx, 32));
+                if (slot == 0 && fvalid) atomicMax(a.frame_max + (int64_t)b * a.n_frames + f0 + flm, __float_as_uint(fmx));
+            }
         }
         __syncthreads();                                                 // the power rows are free again
     }
@@ -783,8 +813,11 @@ int upload_mel_plan(MelPlan* p) {
     if (int rc = upload(&p->d_fb_count, p->fb_count)) return rc;
     if (int rc = upload(&p->d_fb_offset, p->fb_offset)) return rc;
     if (int rc = upload(&p->d_fb_weight, p->fb_weight)) return rc;
-    if (int rc = upload(&p->d_fb4_desc, p->fb4_desc)) return rc;
-    if (int rc = upload(&p->d_fb4_weight, p->fb4_weight)) return rc;
+    if (!p->fbg_gid.empty()) {
+        if (int rc = upload(&p->d_fbg_gid, p->fbg_gid)) return rc;
+        if (int rc = upload(&p->d_fbg_desc, p->fbg_desc)) return rc;
+        if (int rc = upload(&p->d_fbg_weight, p->fbg_weight)) return rc;
+    }
     p->uploaded = true;
     return KM_OK;
 }
@@ -793,7 +826,7 @@ void free_mel_plan(MelPlan* p) {
     if (p->uploaded) {
         (void)hipFree(p->d_window); (void)hipFree(p->d_twiddle); (void)hipFree(p->d_fb_start);
         (void)hipFree(p->d_fb_count); (void)hipFree(p->d_fb_offset); (void)hipFree(p->d_fb_weight);
-        (void)hipFree(p->d_fb4_desc); (void)hipFree(p->d_fb4_weight);
+        (void)hipFree(p->d_fbg_gid); (void)hipFree(p->d_fbg_desc); (void)hipFree(p->d_fbg_weight);
     }
     delete p;
 }
@@ -869,7 +902,7 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     a.n_mels = m.n_mels; a.window = p->d_window; a.twiddle = reinterpret_cast<const float2*>(p->d_twiddle);
     a.fb_start = p->d_fb_start; a.fb_count = p->d_fb_count; a.fb_offset = p->d_fb_offset; a.fb_weight = p->d_fb_weight;
     a.fb_nnz = (int)p->fb_weight.size();
-    a.fb4_desc = p->d_fb4_desc; a.fb4_weight = p->d_fb4_weight; a.fb4_nnz = (int)p->fb4_weight.size();
+    a.fbg_gid = p->d_fbg_gid; a.fbg_desc = p->d_fbg_desc; a.fbg_weight = p->d_fbg_weight; a.fbg_nw = (int)p->fbg_weight.size();
     a.melpow = c->ws_melpow; a.melmax = c->ws_melmax;
     a.frame_mul = 1; a.frame_max = nullptr;
     if (seq) { a.melpow = seq->pow; a.frame_max = seq->fmax; a.frame_mul = seq->frame_mul; a.melmax = nullptr; }
@@ -890,8 +923,8 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     if (per_window < 1) per_window = 1;
     const dim3 grid((unsigned)per_window, (unsigned)B);
     const bool use_rp = !c->opt.mel_two_frame;   // A/B switch: the two-frames-per-wave kernel
-    if (m.n_fft == 1024 && use_rp) {
-        const size_t ldsrp = melrp_lds_bytes(a.fb4_nnz);     // 78 KB at the production shape: two workgroups per CU
+    if (m.n_fft == 1024 && use_rp && p->d_fbg_gid) {     // (more than 128 filters have no grouped image: the kernel below)
+        const size_t ldsrp = melrp_lds_bytes(a.fbg_nw);      // 74 KB: two workgroups per CU
         if (!ring_start) hipLaunchKernelGGL((mel_power_rp_kernel<false>), grid, dim3(melrp::NT), ldsrp, st, a);
         else hipLaunchKernelGGL((mel_power_rp_kernel<true>), grid, dim3(melrp::NT), ldsrp, st, a);
         HIP_TRY(hipGetLastError());
