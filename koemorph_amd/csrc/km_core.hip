@@ -123,6 +123,23 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
         if (a.ready && !a.ready[b]) return;     // stream still filling its ring (workgroup-uniform)
     }
 
+    // Operands that do not depend on the window are requested before anything waits: the first two k pairs of the
+    // encoder weight, the bias and the LayerNorm affine of this lane's two columns (each was an exposed L2 round trip
+    // at its point of use).
+    const int n0 = 32 * wave + j;      // this lane's two columns are n0 and n0 + 16
+    float4 bw0 = make_float4(0.f, 0.f, 0.f, 0.f), bw1 = bw0;
+    if constexpr (NP == 0) {
+        const float4* wp0 = reinterpret_cast<const float4*>(a.wce_p) + (size_t)wave * KP * 64 + lane;
+        bw0 = wp0[0];
+    }
+    const float bb0 = a.bce[n0], bb1 = a.bce[n0 + 16];
+    const float g0 = a.ln_g[n0], g1 = a.ln_g[n0 + 16], be0 = a.ln_b[n0], be1 = a.ln_b[n0 + 16];
+    // ... and so are the decoder's per-unit bias / output weight of phase 5 and the tail's scalars
+    float bf4[4], w24[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bf4[r] = a.bf[16 * wave + 4 * g + r]; w24[r] = a.w2[16 * wave + 4 * g + r]; }
+    const float tail_b2 = a.b2[0], tail_ws = tid < 52 ? a.wsum[tid] : 0.f;
+
     // ---- phase 0: X -> LDS, [t][c] exactly as the caller's (t_in, 80) rows --------------------
     if constexpr (FUSE_DB) {
         // rows come from the power-mel workspace; dB / log conversion on the fly (bit-identical to
@@ -295,7 +312,7 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
         }
     } else {
         const float4* wp = reinterpret_cast<const float4*>(a.wce_p) + (size_t)wave * KP * 64 + lane;
-        float4 bw = wp[0];
+        float4 bw = bw0;
         for (int kp = 0; kp < KP; ++kp) {
             const float4 bn = wp[(size_t)(kp + 1 < KP ? kp + 1 : kp) * 64];   // prefetch next pair
 #pragma unroll
@@ -314,10 +331,15 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
             bw = bn;
         }
     }
-    // bias; this lane's two columns are n0 = 32*wave + j and n0 + 16
-    const int n0 = 32 * wave + j;
+    // the first k block of the phase 2+3 operand images is requested here, ahead of LayerNorm and its two barriers
+    f32x4 q0 = f32x4{0, 0, 0, 0}, q1 = q0, v0 = q0, v1 = q0;
+    if constexpr (NP == 0) {
+        const f32x4* qp0 = reinterpret_cast<const f32x4*>(a.qk_p) + (size_t)wave * KB * 2 * 64 + lane;
+        const f32x4* vp0 = reinterpret_cast<const f32x4*>(a.wv_p) + (size_t)wave * KB * 2 * 64 + lane;
+        q0 = qp0[0]; q1 = qp0[64]; v0 = vp0[0]; v1 = vp0[64];
+    }
+    // bias
     {
-        const float bb0 = a.bce[n0], bb1 = a.bce[n0 + 16];
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt)
 #pragma unroll
@@ -365,7 +387,6 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
             }
     }
     {
-        const float g0 = a.ln_g[n0], g1 = a.ln_g[n0 + 16], be0 = a.ln_b[n0], be1 = a.ln_b[n0 + 16];
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt)
 #pragma unroll
@@ -444,7 +465,6 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
     } else {
         const f32x4* qp = reinterpret_cast<const f32x4*>(a.qk_p) + (size_t)wave * KB * 2 * 64 + lane;
         const f32x4* vp = reinterpret_cast<const f32x4*>(a.wv_p) + (size_t)wave * KB * 2 * 64 + lane;
-        f32x4 q0 = qp[0], q1 = qp[64], v0 = vp[0], v1 = vp[64];
         for (int kb = 0; kb < KB; ++kb) {
             const int kn = kb + 1 < KB ? kb + 1 : kb;
             const f32x4 q0n = qp[(size_t)kn * 128], q1n = qp[(size_t)kn * 128 + 64];
@@ -563,8 +583,7 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
         float zp[2] = {0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int hid = 16 * wave + 4 * g + r;
-            const float bfv = a.bf[hid], w2v = a.w2[hid];
+            const float bfv = bf4[r], w2v = w24[r];
             zp[0] += fmaxf(Z[0][r] + bfv, 0.f) * w2v;
             zp[1] += fmaxf(Z[1][r] + bfv, 0.f) * w2v;
         }
@@ -580,14 +599,14 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
         const int slot = mouth_slot_of(tid);
         float z;
         if (slot >= 0) {
-            z = a.b2[0];
+            z = tail_b2;
 #pragma unroll
             for (int w = 0; w < NW; ++w) z += R2[w * 32 + slot];
         } else {
             z = a.zemo[(a.win0 + b) / a.zemo_div];
         }
         const float bs = 1.0f / (1.0f + expf(-z));                      // nn.Sigmoid (:155)
-        float val = fminf(fmaxf(a.wsum[tid] * bs, 0.f), 1.f);           // stream weights + clamp (:264-270)
+        float val = fminf(fmaxf(tail_ws * bs, 0.f), 1.f);               // stream weights + clamp (:264-270)
         if (a.raw) a.raw[(int64_t)b * 52 + tid] = bs;
         if (a.state) {                                                  // EMA (simplified_dual_stream_model.py:357-366)
             float* st = a.state + (int64_t)b * 52 + tid;
