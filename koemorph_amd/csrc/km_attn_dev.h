@@ -34,12 +34,14 @@ __device__ __forceinline__ float row16_max(float v) {
 }
 
 // KM_SC_SKIP (timing harness only, tools/micro/attn_bench.hip; 0 in the library): bit 0 no MFMAs, bit 1 no S store,
-// bit 2 no softmax arithmetic, bit 3 no query-key image loads after the prologue
+// bit 2 no softmax arithmetic, bit 3 no query-key image loads after the prologue (half the A ring is then never written,
+// so the compiler may drop MFMAs: an upper bound on what the loads cost, not a measurement).  Reading 8 or 64 COPIES of
+// the image from different workgroups changed nothing (49.4 / 84.4 us either way): the loads do not contend on addresses.
 #ifndef KM_SC_SKIP
 #define KM_SC_SKIP 0
 #endif
 
-template <int D>
+template <int D, int TPW>
 __global__ __launch_bounds__(512) void scores_softmax_kernel(const float* __restrict__ Y, const float* __restrict__ qk_pg,
                                                              float* __restrict__ S, int rows /* H * 28 */) {
     constexpr int NKc = 80, KB = D / 16, CH = 4, NCH = KB / CH, QS = NKc + 1;
@@ -76,31 +78,31 @@ __global__ __launch_bounds__(512) void scores_softmax_kernel(const float* __rest
             if (idx < NKc * 16) *reinterpret_cast<u32x4*>(&Ys[buf][(q * QS + prow) * 4]) = yst[j];
         }
     };
-    // Row tiles are dealt in passes of up to 16 (two per wave).  A short pass gives two tiles to as few waves as needed
-    // and one to the rest, so that every SIMD (waves w and w + 4) carries the same number: 28 tiles (16 heads) are 7 per
-    // SIMD instead of 8 + 8 + 6 + 6.
-    for (int base = 0; base < MT; base += 16) {
-        const int rem = MT - base;                                         // tiles left, wave-uniform
-        const int n2 = rem >= 16 ? 8 : (rem > 8 ? rem - 8 : 0);            // waves with two tiles
-        const int mt0 = wave < n2 ? base + 2 * wave : base + 2 * n2 + (wave - n2);
-        const bool active = mt0 < MT, two = wave < n2;
-        f32x4 acc[2][5];
+    // Row tiles are dealt in passes of up to 8 TPW, each wave a contiguous run of floor / ceil(tiles / 8) of them with the
+    // longer runs on waves 0..: waves w and w + 4 share a SIMD, so 28 tiles (16 heads, TPW = 4: ONE sweep over Y) are 4 + 3
+    // = 7 per SIMD, and 14 tiles (8 heads, TPW = 2) are 4 / 4 / 3 / 3 -- the best 14 whole row tiles allow.
+    for (int base = 0; base < MT; base += 8 * TPW) {
+        const int ntile = MT - base < 8 * TPW ? MT - base : 8 * TPW;      // tiles of this pass, wave-uniform
+        const int per = ntile >> 3, extra = ntile & 7;
+        const int cnt = per + (wave < extra ? 1 : 0);                      // this wave's tiles (0 .. TPW)
+        const int mt0 = base + wave * per + (wave < extra ? wave : extra);
+        f32x4 acc[TPW][5];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TPW; ++i)
 #pragma unroll
             for (int nt = 0; nt < 5; ++nt) acc[i][nt] = f32x4{0, 0, 0, 0};
         // qk_pg is [k block][row tile][lane][4]: what the workgroup's waves fetch for one k block is ONE contiguous
         // 1 KiB x MT run (with the row tile outermost the 14 runs sat 32 KiB apart -- one L2 channel for all of them)
         const unsigned a0o = (unsigned)((mt0 * 64 + lane) * 16);
         auto lda = [&](int kb, int i) {
-            const bool ok = (i == 0 ? active : two) && kb < KB;
+            const bool ok = i < cnt && kb < KB;
             return as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(ar, ok ? a0o + (unsigned)(i * 1024) + (unsigned)(kb * MT) * 1024u : OOB, 0, 0));
         };
         auto ldy = [&](int buf, int kk, int nt) { return *reinterpret_cast<const f32x4*>(&Ys[buf][((4 * kk + lg) * QS + 16 * nt + lj) * 4]); };
         ystage(0);
-        f32x4 av[4][2], yb[2][5];                                          // A fragments two k blocks ahead, B one ahead
-        av[0][0] = lda(0, 0); av[0][1] = lda(0, 1);
-        av[1][0] = lda(1, 0); av[1][1] = lda(1, 1);
+        f32x4 av[4][TPW], yb[2][5];                                        // A fragments two k blocks ahead, B one ahead
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) { av[0][i] = lda(0, i); av[1][i] = lda(1, i); }
         ycommit(0);
         __syncthreads();
 #pragma unroll
@@ -112,26 +114,24 @@ __global__ __launch_bounds__(512) void scores_softmax_kernel(const float* __rest
 #pragma unroll
             for (int kk = 0; kk < CH; ++kk) {
                 const int cur = kk & 1, nxt = cur ^ 1, kb = CH * ch + kk;
-                if (!(KM_SC_SKIP & 8)) { av[(kk + 2) & 3][0] = lda(kb + 2, 0); av[(kk + 2) & 3][1] = lda(kb + 2, 1); }
+                if (!(KM_SC_SKIP & 8)) {
+#pragma unroll
+                    for (int i = 0; i < TPW; ++i) av[(kk + 2) & 3][i] = lda(kb + 2, i);
+                }
                 if (kk + 1 < CH) {
 #pragma unroll
                     for (int nt = 0; nt < 5; ++nt) yb[nxt][nt] = ldy(buf, kk + 1, nt);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(KM_SC_SKIP & 1)) {
-                    if (two) {
 #pragma unroll
-                        for (int s = 0; s < 4; ++s)
+                    for (int i = 0; i < TPW; ++i) {
+                        if (i < cnt) {                                     // wave-uniform
 #pragma unroll
-                            for (int nt = 0; nt < 5; ++nt) {
-                                acc[0][nt] = KM_MFMA(av[kk][0][s], yb[cur][nt][s], acc[0][nt]);
-                                acc[1][nt] = KM_MFMA(av[kk][1][s], yb[cur][nt][s], acc[1][nt]);
-                            }
-                    } else if (active) {
+                            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                        for (int s = 0; s < 4; ++s)
-#pragma unroll
-                            for (int nt = 0; nt < 5; ++nt) acc[0][nt] = KM_MFMA(av[kk][0][s], yb[cur][nt][s], acc[0][nt]);
+                                for (int nt = 0; nt < 5; ++nt) acc[i][nt] = KM_MFMA(av[kk][i][s], yb[cur][nt][s], acc[i][nt]);
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -143,12 +143,11 @@ __global__ __launch_bounds__(512) void scores_softmax_kernel(const float* __rest
                 for (int nt = 0; nt < 5; ++nt) yb[0][nt] = ldy(buf ^ 1, 0, nt);
             }
         }
-        if (!active) continue;
         // softmax over the 80 keys of every row: C/D layout puts row 4 lg + r of a tile in lanes lj = 0..15 x 5 tiles;
         // this lane's accumulator nt < 4 is key 4 lj + nt (the staging permutation), nt = 4 is key 64 + lj
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (i == 1 && !two) break;
+        for (int i = 0; i < TPW; ++i) {
+            if (i >= cnt) break;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float e[5];

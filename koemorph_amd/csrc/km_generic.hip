@@ -660,7 +660,9 @@ static int core_generic_after_encoder(Context* c, int64_t B, const float* zemo, 
                            B * NKk, d, dv(c, "ln_g"), dv(c, "ln_b"), (float*)nullptr, (float*)nullptr);
     const bool fused_scores = d == 512 && NKk == 80 && c->packed.count("qk_pg") && !c->opt.no_score_fusion;
     if (fused_scores) {
-        hipLaunchKernelGGL(scores_softmax_kernel<512>, dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream, Y, dv(c, "qk_pg"), S, H * 28);
+        // up to 16 row tiles (8 heads): two per wave; more (16 heads: 28): four per wave, still one sweep over Y
+        if (H * 28 <= 256) hipLaunchKernelGGL((scores_softmax_kernel<512, 2>), dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream, Y, dv(c, "qk_pg"), S, H * 28);
+        else hipLaunchKernelGGL((scores_softmax_kernel<512, 4>), dim3((unsigned)B), dim3(512), 0, (hipStream_t)stream, Y, dv(c, "qk_pg"), S, H * 28);
         HIP_TRY(hipGetLastError());
     }
     // S[b] (H*28 x 80) = Qk (H*28 x d) Y_b^T: all heads of a window in ONE product -- the folded query matrix of every

@@ -44,7 +44,8 @@ int main(int argc, char** argv) {
     float ms;
     for (int it = 0; it < 5 + reps; ++it) {
         if (it == 5) CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(km::scores_softmax_kernel<512>, dim3(B), dim3(512), 0, 0, Y, qk, S, rows);
+        if (rows <= 256) hipLaunchKernelGGL((km::scores_softmax_kernel<512, 2>), dim3(B), dim3(512), 0, 0, Y, qk, S, rows);
+        else hipLaunchKernelGGL((km::scores_softmax_kernel<512, 4>), dim3(B), dim3(512), 0, 0, Y, qk, S, rows);
     }
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
     {
