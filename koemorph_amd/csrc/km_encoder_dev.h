@@ -30,7 +30,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // row packing (T long rows, 3 short-term rows, zero rows) happen while a tile is staged, so no packed log-mel image is
 // written and read back (mel_log_packed_kernel disappears from km_forward_audio).
 struct EncSrc {
-    const float* melpow; const unsigned* melmax; int n_frames, T; LogParams lp;
+    const float* melpow; unsigned* melmax; int n_frames, T; LogParams lp;   // melmax[b] is re-zeroed once every thread has read it
 };
 
 // NW waves of CT column tiles each: D = 16 CT NW columns (d = 512 -> 8 waves x 64 columns, two waves per SIMD with 20
@@ -154,6 +154,9 @@ __global__ __launch_bounds__(64 * NW) void encoder_ln_kernel(const float* __rest
     commit_a(1);
     load_a(2);
     __syncthreads();
+    if constexpr (FUSE_DB) {
+        if (tid == 0) src.melmax[b] = 0u;   // every thread has read it: a clean slot for the next front-end launch (no memset)
+    }
     frags_a(0, 0);
     __syncthreads();       // tile 0's fragments are out of buffer 0 before iteration 0 overwrites it
     // iteration `it` (u = it & 1): tile it + 2 (in registers since iteration it - 1) -> buffer u, whose tile `it` went

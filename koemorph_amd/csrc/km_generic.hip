@@ -593,7 +593,7 @@ int launch_core_generic_power(Context* c, MelPlan* plan, int64_t B, int64_t n_fr
     hipStream_t st = (hipStream_t)stream;
     EncSrc src{c->ws_melpow, c->ws_melmax, (int)n_frames, c->T, plan_log_params(plan)};
     if (int rc = launch_encoder_ln_for<true>(c, B, st, nullptr, KP, src)) return rc;
-    c->melmax_dirty = true;      // the maxima stay behind (only the fused d=256 core re-zeroes them)
+    c->melmax_dirty = false;     // every slot the encoder read was just written by the front end and is re-zeroed by the encoder
     return core_generic_after_encoder(c, B, zemo, out, raw, attn, stream, true);
 }
 
