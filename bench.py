@@ -189,8 +189,31 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-def timed(rk: Ranks, step, steps: int, warmup: int, flush=None) -> float:
+SPINUP_SECONDS = 0.3    # sustained load before the W warmup steps: an MI355X reaches its steady-state clock only after
+#                         ~0.1 s of work (C2, same box, same run: 164.6 us/step for W=5 K=20, 149.1 for W=20 K=200, 143.0
+#                         for W=1000 with K=50 or K=4000).  The timed region below is unchanged: exactly K steps.
+
+
+def spin_up(rk: Ranks, step, seconds: float = SPINUP_SECONDS) -> int:
+    """Untimed: run `step` for about `seconds` so that the K timed steps measure the steady state, not the clock ramp."""
+    if seconds <= 0:
+        return 0
+    rk.sync()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        step()
+    rk.sync()
+    per = max((time.perf_counter() - t0) / 10, 1e-6)
+    n = int(min(max(seconds / per, 0), 20000))
+    for _ in range(n):
+        step()
+    rk.sync()
+    return n + 10
+
+
+def timed(rk: Ranks, step, steps: int, warmup: int, flush=None, spin: bool = True) -> float:
     """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; MAX over ranks (seconds)."""
+    spin_up(rk, step, 0.0 if (not spin or os.environ.get("KM_BENCH_NO_SPINUP")) else SPINUP_SECONDS)
     for _ in range(warmup):
         step()
     if flush:
@@ -615,7 +638,7 @@ def run_c5(args, rk: Ranks):
 
 def run_rendezvous(args, rk: Ranks):
     """No GPU, no library: the launcher + rendezvous + barrier/max-over-ranks clock + rank-0 line on their own."""
-    dt = timed(rk, lambda: time.sleep(0.01 * (1 + rk.rank)), args.steps, args.warmup)      # the slowest rank sets the clock
+    dt = timed(rk, lambda: time.sleep(0.01 * (1 + rk.rank)), args.steps, args.warmup, spin=False)      # the slowest rank sets the clock
     return {"metric": "launcher rehearsal (no compute)", "value": round(rk.world * args.steps / dt, 3), "unit": "steps/s",
             "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
@@ -635,6 +658,8 @@ def main():
             _lib.load()
         rk.dist.barrier()
     line = {"c2": run_c2, "c3": run_c3, "c4": run_c4, "c5": run_c5, "rendezvous": run_rendezvous}[args.workload](args, rk)
+    if args.workload != "rendezvous":      # disclosed: untimed sustained load ahead of the W warmup steps (see SPINUP_SECONDS)
+        line["spinup_s"] = 0.0 if os.environ.get("KM_BENCH_NO_SPINUP") else SPINUP_SECONDS
     if rk.rank == 0:
         print(json.dumps(line), flush=True)
     rk.finish()
