@@ -30,9 +30,10 @@ int main(int argc, char** argv) {
     lp.log_mode = KM_LOG_DB_MAX; lp.amin = 1e-10f; lp.top_db = 80.f; lp.db_add = 80.f; lp.db_scale = 1.f / 80.f; lp.log_eps = 1e-8f;
     km::EncSrc src{dx, dm, NF, T, lp};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const int reps = 50;
-    for (int it = 0; it < 5 + reps; ++it) {
-        if (it == 5) CK(hipEventRecord(e0, 0));
+    // 3000 untimed launches first (about 0.3 s): the chip reaches its steady-state clock only under sustained load
+    const int warm = 3000, reps = 200;
+    for (int it = 0; it < warm + reps; ++it) {
+        if (it == warm) CK(hipEventRecord(e0, 0));
         hipLaunchKernelGGL((km::encoder_ln_kernel<8, 4, true>), dim3(B), dim3(512), 0, 0, (const float*)nullptr, dw, db, dg, dbe, dy, KP, src);
     }
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
