@@ -203,7 +203,7 @@ def spin_up(rk: Ranks, step, seconds: float = SPINUP_SECONDS) -> int:
     for _ in range(10):
         step()
     rk.sync()
-    per = max((time.perf_counter() - t0) / 10, 1e-6)
+    per = max(rk.max_over_ranks((time.perf_counter() - t0) / 10), 1e-6)      # the same count on every rank: a step may hold a collective
     n = int(min(max(seconds / per, 0), 20000))
     for _ in range(n):
         step()
