@@ -50,7 +50,7 @@ constexpr int KT = 259, KTP = 264, YS = 264, NW = 8, NT = 512;
 constexpr int KP = 33;               // k-step pairs of the encoder GEMM (66 steps of 4 >= 259)
 constexpr int KB = 16;               // 16-wide k blocks of the d=256 contractions
 constexpr int R1_FLOATS = KTP * NK;  // 21120: X [264][80]  ==  Y [80][264]
-constexpr int R2_FLOATS = 2 * NW * NK;   // 1280: cross-wave reduction scratch, one [80 rows][8 waves] image per LayerNorm pass
+constexpr int R2_FLOATS = 2 * NW * NK + 2 * NK;   // 1440: cross-wave reduction scratch: one [80 rows][8 waves] image of partials and one [80] row of totals per LayerNorm pass
 constexpr int LDS_BYTES = (R1_FLOATS + R2_FLOATS) * 4;
 // split-bf16 variant (NP pieces per fp32 value): Y lives in LDS as NP planes [80][YSB] of bf16
 constexpr int YSB = 264;                            // bf16 per plane row: 132 dwords = 4 (mod 64), conflict-free b128 fragments
@@ -373,18 +373,29 @@ __global__ __launch_bounds__(512) void core_fused_kernel(CoreArgs a) {
                 for (int r = 0; r < 4; ++r) P[(16 * mt + 4 * g + r) * NW + wave] = part[mt][r];
         }
         __syncthreads();   // pass 0: also fences every wave's last read of X
+        // row totals: wave w adds up the 8 partials (waves in index order, as before) of rows 10 w .. 10 w + 9, one row per
+        // lane, then every lane fetches its 20 totals with five 16-byte reads -- a second barrier, but 5 instead of 40
+        // ds_read_b128 per lane and pass
+        float* Tt = R2 + 2 * NW * NK + pass * NK;
+        if (lane < NK / NW) {
+            const int row = wave * (NK / NW) + lane;
+            const f32x4* pr = reinterpret_cast<const f32x4*>(P + row * NW);
+            const f32x4 lo = pr[0], hi = pr[1];
+            float s = 0.f;
+            s += lo[0]; s += lo[1]; s += lo[2]; s += lo[3];
+            s += hi[0]; s += hi[1]; s += hi[2]; s += hi[3];
+            Tt[row] = s;
+        }
+        __syncthreads();
 #pragma unroll
-        for (int mt = 0; mt < 5; ++mt)
+        for (int mt = 0; mt < 5; ++mt) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(Tt + 16 * mt + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const f32x4* pr = reinterpret_cast<const f32x4*>(P + (16 * mt + 4 * g + r) * NW);
-                const f32x4 lo = pr[0], hi = pr[1];
-                float s = 0.f;
-                s += lo[0]; s += lo[1]; s += lo[2]; s += lo[3];
-                s += hi[0]; s += hi[1]; s += hi[2]; s += hi[3];          // waves in index order, as before
-                if (pass == 0) mean[mt][r] = s * (1.0f / D);
-                else rstd[mt][r] = __builtin_amdgcn_rsqf(s * (1.0f / D) + 1e-5f);     // v_rsq_f32 (1 ulp)
+                if (pass == 0) mean[mt][r] = t4[r] * (1.0f / D);
+                else rstd[mt][r] = __builtin_amdgcn_rsqf(t4[r] * (1.0f / D) + 1e-5f);     // v_rsq_f32 (1 ulp)
             }
+        }
     }
     {
 #pragma unroll
