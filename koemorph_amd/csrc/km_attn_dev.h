@@ -34,7 +34,8 @@ __device__ __forceinline__ float row16_max(float v) {
 }
 
 // KM_SC_SKIP (timing harness only, tools/micro/attn_bench.hip; 0 in the library): bit 0 no MFMAs, bit 1 no S store,
-// bit 2 no softmax arithmetic, bit 3 no query-key image loads after the prologue (half the A ring is then never written,
+// bit 2 no softmax arithmetic, bit 4 whole row tiles only (no k split at 8 heads), bit 3 no query-key image loads after the
+// prologue (half the A ring is then never written,
 // so the compiler may drop MFMAs: an upper bound on what the loads cost, not a measurement).  Reading 8 or 64 COPIES of
 // the image from different workgroups changed nothing (49.4 / 84.4 us either way): the loads do not contend on addresses.
 #ifndef KM_SC_SKIP
@@ -80,12 +81,18 @@ __global__ __launch_bounds__(512) void scores_softmax_kernel(const float* __rest
     };
     // Row tiles are dealt in passes of up to 8 TPW, each wave a contiguous run of floor / ceil(tiles / 8) of them with the
     // longer runs on waves 0..: waves w and w + 4 share a SIMD, so 28 tiles (16 heads, TPW = 4: ONE sweep over Y) are 4 + 3
-    // = 7 per SIMD, and 14 tiles (8 heads, TPW = 2) are 4 / 4 / 3 / 3 -- the best 14 whole row tiles allow.
+    // = 7 per SIMD.  14 tiles (8 heads, TPW = 2) would be 4 / 4 / 3 / 3 whole tiles; instead two of them are SPLIT along k
+    // between the second waves of two SIMDs (k blocks 0-1 / 2-3 of every chunk, so every chunk stays balanced) and every
+    // SIMD carries 3.5: waves 0..3 hold tiles 3 w and 3 w + 1, waves 4..7 hold tile 3 (w - 4) + 2 and one half of tile 12
+    // (waves 4, 5) or 13 (waves 6, 7); the halves meet in LDS after the sweep.
     for (int base = 0; base < MT; base += 8 * TPW) {
         const int ntile = MT - base < 8 * TPW ? MT - base : 8 * TPW;      // tiles of this pass, wave-uniform
+        const bool split14 = TPW == 2 && ntile == 14 && !(KM_SC_SKIP & 16);
         const int per = ntile >> 3, extra = ntile & 7;
-        const int cnt = per + (wave < extra ? 1 : 0);                      // this wave's tiles (0 .. TPW)
-        const int mt0 = base + wave * per + (wave < extra ? wave : extra);
+        const int cnt = split14 ? 2 : per + (wave < extra ? 1 : 0);        // this wave's tiles (0 .. TPW)
+        const int mt0 = base + (split14 ? (wave < 4 ? 3 * wave : 3 * (wave - 4) + 2) : wave * per + (wave < extra ? wave : extra));
+        const int mt1 = split14 && wave >= 4 ? base + 12 + ((wave - 4) >> 1) : mt0 + 1;      // second tile (TPW = 2 only uses it)
+        const int half = split14 && wave >= 4 ? (wave & 1) : -1;          // which k blocks of a chunk the second tile takes
         f32x4 acc[TPW][5];
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
@@ -93,10 +100,10 @@ __global__ __launch_bounds__(512) void scores_softmax_kernel(const float* __rest
             for (int nt = 0; nt < 5; ++nt) acc[i][nt] = f32x4{0, 0, 0, 0};
         // qk_pg is [k block][row tile][lane][4]: what the workgroup's waves fetch for one k block is ONE contiguous
         // 1 KiB x MT run (with the row tile outermost the 14 runs sat 32 KiB apart -- one L2 channel for all of them)
-        const unsigned a0o = (unsigned)((mt0 * 64 + lane) * 16);
+        const unsigned a0o = (unsigned)((mt0 * 64 + lane) * 16), a1d = (unsigned)((mt1 - mt0) * 1024);
         auto lda = [&](int kb, int i) {
-            const bool ok = i < cnt && kb < KB;
-            return as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(ar, ok ? a0o + (unsigned)(i * 1024) + (unsigned)(kb * MT) * 1024u : OOB, 0, 0));
+            const bool ok = i < cnt && kb < KB && (i != 1 || half < 0 || ((kb >> 1) & 1) == half);
+            return as_f32x4(__builtin_amdgcn_raw_buffer_load_b128(ar, ok ? a0o + (i == 1 ? a1d : (unsigned)(i * 1024)) + (unsigned)(kb * MT) * 1024u : OOB, 0, 0));
         };
         auto ldy = [&](int buf, int kk, int nt) { return *reinterpret_cast<const f32x4*>(&Ys[buf][((4 * kk + lg) * QS + 16 * nt + lj) * 4]); };
         ystage(0);
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(512) void scores_softmax_kernel(const float* __rest
                 if (!(KM_SC_SKIP & 1)) {
 #pragma unroll
                     for (int i = 0; i < TPW; ++i) {
-                        if (i < cnt) {                                     // wave-uniform
+                        if (i < cnt && (i != 1 || half < 0 || (kk >> 1) == half)) {      // wave-uniform
 #pragma unroll
                             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -143,11 +150,26 @@ __global__ __launch_bounds__(512) void scores_softmax_kernel(const float* __rest
                 for (int nt = 0; nt < 5; ++nt) yb[0][nt] = ldy(buf ^ 1, 0, nt);
             }
         }
+        if (split14) {
+            // the two halves of a split tile meet: the wave that took k blocks 2-3 hands its accumulators over through the
+            // (now idle) Y buffer, the wave that took k blocks 0-1 adds them and finishes the tile
+            f32x4* X = reinterpret_cast<f32x4*>(&Ys[0][0]) + ((wave - 4) >> 1) * (5 * 64) + lane;
+            if (half == 1) {
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) X[nt * 64] = acc[1][nt];
+            }
+            __syncthreads();
+            if (half == 0) {
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) acc[1][nt] += X[nt * 64];
+            }
+            __syncthreads();      // (a later pass would restage Y into this buffer)
+        }
         // softmax over the 80 keys of every row: C/D layout puts row 4 lg + r of a tile in lanes lj = 0..15 x 5 tiles;
         // this lane's accumulator nt < 4 is key 4 lj + nt (the staging permutation), nt = 4 is key 64 + lj
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            if (i >= cnt) break;
+            if (i >= cnt || (i == 1 && half == 1)) break;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float e[5];
@@ -167,7 +189,7 @@ __global__ __launch_bounds__(512) void scores_softmax_kernel(const float* __rest
 #pragma unroll
                     for (int nt = 0; nt < 5; ++nt) e[nt] = acc[i][nt][r];
                 }
-                const int row = 16 * (mt0 + i) + 4 * lg + r;
+                const int row = 16 * (i == 1 ? mt1 : mt0 + i) + 4 * lg + r;
                 if ((KM_SC_SKIP & 2) && e[0] != 12345.f) continue;
                 if (row < rows) {
                     *reinterpret_cast<float4*>(Sb + (int64_t)row * NKc + 4 * lj) = make_float4(e[0], e[1], e[2], e[3]);
