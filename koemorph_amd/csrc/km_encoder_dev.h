@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64 * NW) void encoder_ln_kernel(const float* __rest
     static_assert(NKc % NW == 0, "rows must divide evenly among the waves");
     static_assert(CT == 2 || CT == 4, "a lane's columns are stored as one 8- or 16-byte vector");
     constexpr int ABUF = 4 * NKc * 4;                 // floats of one A tile image [k / 4][row][k % 4]
-    __shared__ __attribute__((aligned(16))) float As[2 * ABUF];
+    __shared__ __attribute__((aligned(16))) float As[2 * 2 * ABUF];     // two buffers of two k blocks each
     __shared__ __attribute__((aligned(16))) float Ps[2][NKc * NW];      // LayerNorm partial sums [pass][row][wave]
     __shared__ __attribute__((aligned(16))) float Ts[2][NKc];           // LayerNorm row totals [pass][row]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -69,22 +69,21 @@ __global__ __launch_bounds__(64 * NW) void encoder_ln_kernel(const float* __rest
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wpg), 0, (unsigned)(D * KP * 4), 0x00020000);
     constexpr unsigned OOB = 0x7fffffffu;
-    // with >= 320 threads one staged row per thread (16 rows x 20 float4): the log conversion is spread over five waves
-    constexpr bool WIDE = NTHR >= 320;
-    constexpr int NA = WIDE ? 1 : 4;                                   // staged rows per loading thread
-    const bool a_thr = tid < (WIDE ? 320 : 80);
-    const int akg = tid / 20, am4 = tid - akg * 20;
+    // A tiles are staged 32 frames (two k blocks) at a time: 640 float4, one per thread and a second one for the first
+    // 640 - NTHR threads (8 waves: waves 0 and 1, so the dB conversion weighs 3 / 3 / 2 / 2 on the four SIMDs per 32 frames
+    // where one k block at a time put 2 / 1 / 1 / 1 on them per 16), and ONE barrier per two k blocks.
+    constexpr int NA = (640 + NTHR - 1) / NTHR;                        // staged float4 per thread and super-block
     float ref_db = 0.f, floor_db = 0.f;
     if (FUSE_DB) log_window_consts(src.lp, __uint_as_float(src.melmax[b]), ref_db, floor_db);
     u32x4 ra[NA];
-    unsigned ravalid = 0;        // FUSE_DB: which of the staged rows hold a real frame (zero rows stay zero)
-    auto load_a = [&](int t) {
-        const int k0 = 16 * t;
-        if constexpr (FUSE_DB) ravalid = 0;
+    unsigned ravalid = 0;        // which of the staged float4 hold a real frame (zero rows, rows past K stay zero)
+    auto load_a = [&](int sb) {  // super-block sb = packed rows 32 sb .. 32 sb + 31
+        ravalid = 0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int r = k0 + (WIDE ? akg : 4 * akg + i);           // packed row of this load
-            int f = r;
+            const int idx = tid + NTHR * i, fr = idx / 20, c4 = idx - fr * 20;
+            const int r = 32 * sb + fr;                               // packed row of this load
+            int f = r < KP ? r : -1;
             if constexpr (FUSE_DB) {                                  // packed row -> frame (mel_log_packed_kernel's mapping)
                 f = -1;
                 if (r < src.T) f = r < src.n_frames ? r : -1;
@@ -92,40 +91,27 @@ __global__ __launch_bounds__(64 * NW) void encoder_ln_kernel(const float* __rest
                     const int q = r - src.T;
                     if (src.n_frames >= 3) f = src.n_frames - 3 + q; else if (q < src.n_frames) f = q;
                 }
-                ravalid |= (f >= 0 ? 1u : 0u) << i;
             }
-            const unsigned off = (a_thr && f >= 0 && t < kt) ? (unsigned)(f * NKc + 4 * am4) * 4u : OOB;
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+            const bool ok = idx < 640 && f >= 0;
+            ravalid |= (ok ? 1u : 0u) << i;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? (unsigned)(f * NKc + 4 * c4) * 4u : OOB, 0, 0);
         }
     };
-    auto commit_a = [&](int buf) {
-        float* Ab = As + buf * ABUF;
+    auto commit_a = [&](int buf) {   // [half = frame / 16][(frame % 16) / 4][channel][frame % 4]: a k block's fragment image per half
+        float* Ab = As + buf * (2 * ABUF);
 #pragma unroll
-        for (int i = 0; i < NA; ++i) asm volatile("" ::"v"(ra[i]));   // an unconditional use: keeps the loads out of the branch below
-        if (a_thr) {
-            float4 a4[NA];
-#pragma unroll
-            for (int i = 0; i < NA; ++i)
-                a4[i] = make_float4(__uint_as_float(ra[i].x), __uint_as_float(ra[i].y), __uint_as_float(ra[i].z), __uint_as_float(ra[i].w));
-            if constexpr (FUSE_DB) {
-                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (src.lp.log_mode == KM_LOG_LN_EPS) {
-#pragma unroll
-                    for (int i = 0; i < NA; ++i) a4[i] = (ravalid >> i) & 1 ? log_four_t<KM_LOG_LN_EPS>(src.lp, a4[i], ref_db, floor_db) : z4;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NA; ++i) a4[i] = (ravalid >> i) & 1 ? log_four_t<KM_LOG_DB_MAX>(src.lp, a4[i], ref_db, floor_db) : z4;
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + NTHR * i, fr = idx / 20, c4 = idx - fr * 20;
+            asm volatile("" ::"v"(ra[i]));                            // an unconditional use: keeps the load out of the branch below
+            if (idx < 640) {
+                float4 a4 = make_float4(__uint_as_float(ra[i].x), __uint_as_float(ra[i].y), __uint_as_float(ra[i].z), __uint_as_float(ra[i].w));
+                if constexpr (FUSE_DB) {
+                    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (src.lp.log_mode == KM_LOG_LN_EPS) a4 = (ravalid >> i) & 1 ? log_four_t<KM_LOG_LN_EPS>(src.lp, a4, ref_db, floor_db) : z4;
+                    else a4 = (ravalid >> i) & 1 ? log_four_t<KM_LOG_DB_MAX>(src.lp, a4, ref_db, floor_db) : z4;
                 }
-            }
-            if constexpr (WIDE) {
-                float* dst = &Ab[((akg >> 2) * NKc + 4 * am4) * 4 + (akg & 3)];
-                dst[0] = a4[0].x; dst[4] = a4[0].y; dst[8] = a4[0].z; dst[12] = a4[0].w;
-            } else {
-                float* dst = &Ab[(akg * NKc + 4 * am4) * 4];
-                *reinterpret_cast<float4*>(dst + 0) = make_float4(a4[0].x, a4[NA > 1 ? 1 : 0].x, a4[NA > 2 ? 2 : 0].x, a4[NA > 3 ? 3 : 0].x);
-                *reinterpret_cast<float4*>(dst + 4) = make_float4(a4[0].y, a4[NA > 1 ? 1 : 0].y, a4[NA > 2 ? 2 : 0].y, a4[NA > 3 ? 3 : 0].y);
-                *reinterpret_cast<float4*>(dst + 8) = make_float4(a4[0].z, a4[NA > 1 ? 1 : 0].z, a4[NA > 2 ? 2 : 0].z, a4[NA > 3 ? 3 : 0].z);
-                *reinterpret_cast<float4*>(dst + 12) = make_float4(a4[0].w, a4[NA > 1 ? 1 : 0].w, a4[NA > 2 ? 2 : 0].w, a4[NA > 3 ? 3 : 0].w);
+                float* dst = &Ab[(fr >> 4) * ABUF + (((fr & 15) >> 2) * NKc + 4 * c4) * 4 + (fr & 3)];
+                dst[0] = a4.x; dst[4] = a4.y; dst[8] = a4.z; dst[12] = a4.w;
             }
         }
     };
@@ -135,8 +121,8 @@ __global__ __launch_bounds__(64 * NW) void encoder_ln_kernel(const float* __rest
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[i][ct] = f32x4{0, 0, 0, 0};
     f32x4 af[2][5], bf[2][CT];
-    auto frags_a = [&](int buf, int slot) {
-        const float* Ab = As + buf * ABUF;
+    auto frags_a = [&](int buf, int half, int slot) {
+        const float* Ab = As + buf * (2 * ABUF) + half * ABUF;
 #pragma unroll
         for (int i = 0; i < 5; ++i) af[slot][i] = *reinterpret_cast<const f32x4*>(&Ab[(lg * NKc + 16 * i + lj) * 4]);
     };
@@ -147,40 +133,45 @@ __global__ __launch_bounds__(64 * NW) void encoder_ln_kernel(const float* __rest
             bf[slot][ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                 wr, t < kt ? bo + (unsigned)(t * NW * CT + ct) * 1024u : OOB, 0, 0));
     };
+    auto mfma_block = [&](int it, int slot) {
+        if (it < kt && !(KM_ENC_SKIP & 1)) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) acc[i][ct] = KM_MFMA(af[slot][i][s], bf[slot][ct][s], acc[i][ct]);
+        }
+    };
     load_a(0);
     load_b(0, 0);
     commit_a(0);
     load_a(1);
-    commit_a(1);
-    load_a(2);
     __syncthreads();
     if constexpr (FUSE_DB) {
         if (tid == 0) src.melmax[b] = 0u;   // every thread has read it: a clean slot for the next front-end launch (no memset)
     }
-    frags_a(0, 0);
-    __syncthreads();       // tile 0's fragments are out of buffer 0 before iteration 0 overwrites it
-    // iteration `it` (u = it & 1): tile it + 2 (in registers since iteration it - 1) -> buffer u, whose tile `it` went
-    // into fragments before the last barrier; request tile it + 3; read tile it + 1's fragments (committed at the top of
-    // iteration it - 1) and its weight image; then the 20 CT MFMAs of tile `it` from registers.
-    for (int it0 = 0; it0 < kt; it0 += 2) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int it = it0 + u;
-            if (!(KM_ENC_SKIP & (8 | 32))) { commit_a(u); load_a(it + 3); }
-            frags_a(u ^ 1, u ^ 1);
-            if (!(KM_ENC_SKIP & (8 | 16))) load_b(it + 1, u ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (it < kt && !(KM_ENC_SKIP & 1)) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int i = 0; i < 5; ++i)
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) acc[i][ct] = KM_MFMA(af[u][i][s], bf[u][ct][s], acc[i][ct]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-        }
+    frags_a(0, 0, 0);
+    // Super-iteration sb = k blocks 2 sb (slot 0) and 2 sb + 1 (slot 1).  Top: super-block sb + 1 (in registers since the
+    // last super-iteration) -> buffer (sb + 1) & 1, whose last reader -- the fragments of block 2 sb - 1 -- ran before the
+    // last barrier; request super-block sb + 2.  Each block's fragments and weight image are read one block ahead: block
+    // 2 sb + 1's from this super-block's second half, block 2 sb + 2's from the buffer just committed, after the
+    // super-iteration's ONE barrier.
+    const int nsb = (kt + 1) / 2;
+    for (int sb = 0; sb < nsb; ++sb) {
+        const int cur = sb & 1;
+        if (!(KM_ENC_SKIP & (8 | 32))) { commit_a(cur ^ 1); load_a(sb + 2); }
+        frags_a(cur, 1, 1);
+        if (!(KM_ENC_SKIP & (8 | 16))) load_b(2 * sb + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(2 * sb, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        frags_a(cur ^ 1, 0, 0);
+        if (!(KM_ENC_SKIP & (8 | 16))) load_b(2 * sb + 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(2 * sb + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     // bias, then LayerNorm over the D columns of each of the 80 rows (this lane: rows 16 i + 4 lg + r, columns n0 + ct)
     const int n0 = 16 * CT * wave + CT * lj;
