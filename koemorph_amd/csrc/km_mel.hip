@@ -679,20 +679,28 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
                 if (!(KM_MEL_SKIP & 2)) lds_read8<8>(rd3, y);             // y[q] = buf[lane * 9 + q]
                 __builtin_amdgcn_wave_barrier();
                 if (!(KM_MEL_SKIP & 4)) dif8(y);
-                if (!(KM_MEL_SKIP & 2)) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) buf[lane + 64 * bitrev(i, 3)] = y[i];
-                }
-                __builtin_amdgcn_wave_barrier();
                 // ---- real-input post-processing + |.|^2, two bins (k and 512 - k) per packed instruction ----
+                // y[i] = Z[lane + 64 bitrev(i)].  The bins k = lane + 64 i, i = 0..3, this lane finishes are its own registers
+                // 0, 4, 2, 6; their partners Z[512 - k] = Z[(64 - lane) + 64 (7 - i)] are registers 7, 3, 5, 1 of lane
+                // 64 - lane: one fixed lane permutation of four complex registers (8 ds_bpermute_b32, no LDS memory) instead of
+                // a third exchange through the buffer (8 ds_write_b64 + 8 ds_read_b64).  Lane 0 pairs with itself, one
+                // register further: Z[512 - 64 i] = Z[64 ((8 - i) & 7)] = its registers 0, 7, 3, 5.
                 float* pwr = pw + fl * NFS;
                 v2f zk[4], zc[4];
+                v2f zmid = y[1];                                          // Z[256] in lane 0 (k = 256 pairs with itself)
+                if (!(KM_MEL_SKIP & 2)) {
+                    const int src = ((64 - lane) & 63) << 2;
+                    auto perm = [&](v2f v) {
+                        return v2f{__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.x))),
+                                   __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.y)))};
+                    };
+                    const v2f p7 = perm(y[7]), p3 = perm(y[3]), p5 = perm(y[5]), p1 = perm(y[1]);
+                    const bool l0 = lane == 0;
+                    zk[0] = y[0]; zk[1] = y[4]; zk[2] = y[2]; zk[3] = y[6];
+                    zc[0] = l0 ? y[0] : p7; zc[1] = l0 ? y[7] : p3; zc[2] = l0 ? y[3] : p5; zc[3] = l0 ? y[5] : p1;
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (!(KM_MEL_SKIP & 2)) {
-                        zk[i] = buf[lane + 64 * i];
-                        zc[i] = buf[(NC - lane - 64 * i) & (NC - 1)];
-                    } else { zk[i] = y[i]; zc[i] = y[i + 4]; }
+                    for (int i = 0; i < 4; ++i) { zk[i] = y[i]; zc[i] = y[i + 4]; }
                 }
                 if (!(KM_MEL_SKIP & 4)) post4(zk, zc, twp);                                       // the 1/4 of |X|^2 lives in the filter weights
 #pragma unroll
@@ -700,10 +708,7 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
                     pwr[lane + 64 * i] = zk[i].x;
                     pwr[2 * 256 - lane - 64 * i] = zk[i].y;
                 }
-                if (lane == 0) {                                                        // k = 256 pairs with itself
-                    const v2f zk = buf[256];
-                    pwr[256] = 4.0f * (zk.x * zk.x + zk.y * zk.y);
-                }
+                if (lane == 0) pwr[256] = 4.0f * (zmid.x * zmid.x + zmid.y * zmid.y);      // k = 256 pairs with itself
             }
         }
         int my_desc[NGW];
