@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "km_context.h"
+#include "km_device.h"
 #include "km_gemm.h"
 
 using namespace km;
@@ -34,6 +35,8 @@ static int need_dual(Context* c) {
     if (c->kind != 0) return fail(KM_ERR_INVALID_ARG, "this entry point needs a dual-stream handle (km_create), not a legacy one");
     return KM_OK;
 }
+
+namespace km { LogParams plan_log_params(MelPlan* p); }
 
 extern "C" {
 
@@ -325,7 +328,7 @@ int km_train_step(km_handle h, const float* mel_dev, int64_t B, int64_t T_in, co
     if (!mel_dev || !mel_short_dev || !emotion_dev || !target_dev || !flat_grad_dev || !loss_dev || T_in <= 0)
         return fail(KM_ERR_INVALID_ARG, "km_train_step: bad argument");
     if (!h->opt.train_chain)
-        return train_forward_backward_phased(h, mel_dev, B, T_in, mel_short_dev, nullptr, emotion_dev, target_dev, mse_weight,
+        return train_forward_backward_phased(h, mel_dev, B, T_in, mel_short_dev, nullptr, nullptr, emotion_dev, target_dev, mse_weight,
                                              l1_weight, flat_grad_dev, loss_dev, out_dev, ema_state_dev, ema_first, stream);
     if (h->tr_dropout_p > 0.f) return fail(KM_ERR_UNSUPPORTED, "the launch-per-op training chain has no dropout: unset train_chain");
     return train_forward_backward(h, mel_dev, B, T_in, mel_short_dev, emotion_dev, target_dev, mse_weight, l1_weight,
@@ -343,10 +346,13 @@ int km_train_step_audio(km_handle h, const float* audio_dev, int64_t B, int64_t 
     if (B > c->ws_windows || n_frames > c->ws_frames)
         return fail(KM_ERR_WORKSPACE, "workspace too small for %lld windows x %lld samples: call km_reserve", (long long)B, (long long)L);
     if (!c->opt.train_chain) {
-        // front end straight into the packed encoder input (B, KP, n_mels) at the head of the phased workspace
-        const int KP = (c->KT + 15) / 16 * 16;
-        if (int rc = launch_mel_packed(c, c->mel_plans[0], audio_dev, B, L, c->trp_act, c->T, KP, stream)) return rc;
-        return train_forward_backward_phased(c, nullptr, B, n_frames, nullptr, c->trp_act, emotion_dev, target_dev, mse_weight,
+        // front end -> power-mel; phase 0 of the program converts and packs it into the encoder input (B, KP, n_mels) at the
+        // head of the phased workspace
+        if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, L, stream)) return rc;
+        c->melmax_dirty = true;      // until phase 1 has re-zeroed the maxima
+        const LogParams lp = plan_log_params(c->mel_plans[0]);
+        const TrainAudioSrc asrc{c->ws_melpow, c->ws_melmax, (int)n_frames, &lp};
+        return train_forward_backward_phased(c, nullptr, B, n_frames, nullptr, c->trp_act, &asrc, emotion_dev, target_dev, mse_weight,
                                              l1_weight, flat_grad_dev, loss_dev, out_dev, ema_state_dev, ema_first, stream);
     }
     if (c->tr_dropout_p > 0.f) return fail(KM_ERR_UNSUPPORTED, "the launch-per-op training chain has no dropout: unset train_chain");

@@ -206,7 +206,11 @@ int64_t trainp_act_floats(Context* c, int64_t* fixed);
 int64_t trainp_mask_alloc_bytes(Context* c);
 int trainp_mask_sizes(Context* c, int64_t B, int64_t* mel, int64_t* emo, int64_t* dec);
 int trainp_copy_masks(Context* c, int64_t B, unsigned char* mel, unsigned char* emo, unsigned char* dec, int to_device, void* stream);
+// from-audio training step: the front end's power-mel + window maxima, converted and packed by phase 0 of the program
+struct LogParams;
+struct TrainAudioSrc { const float* melpow; const unsigned* melmax; int n_frames; const LogParams* lp; };
 int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short, const float* xp_dev,
+                                  const TrainAudioSrc* asrc,
                                   const float* emo, const float* target, float mse_w, float l1_w, float* flat_grad, float* loss_dev,
                                   float* out_dev, float* ema_state, int ema_first, void* stream);
 int launch_audio_energy(const float* feats, int64_t B, int64_t T, int64_t D, float* out, void* stream);

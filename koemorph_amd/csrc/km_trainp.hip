@@ -44,7 +44,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- operations of a phase ------------------------------------------------------------------------------------
 enum OpKind : int {
-    OP_GEMM = 0, OP_ZERO, OP_FILL, OP_MASKGEN, OP_PACKX, OP_LN_FWD, OP_LN_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_RELU_OUTER, OP_REDUCE,
+    OP_GEMM = 0, OP_ZERO, OP_FILL, OP_MASKGEN, OP_PACKX, OP_LOGPACK, OP_LN_FWD, OP_LN_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_RELU_OUTER, OP_REDUCE,
     OP_EMO_EXPAND, OP_EMO_REDUCE
 };
 
@@ -57,6 +57,7 @@ struct ElemArgs {
     int i0, i1, i2, i3;
     float f0;
     unsigned u0, u1;
+    LogParams lp;          // OP_LOGPACK
 };
 
 struct Op {
@@ -282,6 +283,24 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, float* smem) {
         if (t < tv) v = reinterpret_cast<const float4*>(a.p0 + (b * t_in + t) * a.i0)[c4];
         else if (t >= T && t < T + 3) v = reinterpret_cast<const float4*>(a.p1 + (b * 3 + (t - T)) * a.i0)[c4];
         reinterpret_cast<float4*>(a.q0)[i] = v;
+        break;
+    }
+    case OP_LOGPACK: {      // xp (B, KP, NK) <- the front end's power-mel (B, F, NK) + window maxima: dB / log conversion and row
+        // packing (T long rows, the last 3 frames, zero rows) -- mel_log_packed_kernel as an op of phase 0, one launch less
+        const int64_t i = (int64_t)vb * 256 + tid;           // one value each, as the stand-alone kernel (same log_one())
+        const int NKk = a.i0, KP = a.i1, T = a.i2, F = a.i3;
+        if (i >= a.n0 * KP * NKk) break;
+        const int64_t b = i / ((int64_t)KP * NKk);
+        const int j = (int)(i - b * KP * NKk), r = j / NKk, m = j - r * NKk;
+        float ref_db, floor_db;
+        log_window_consts(a.lp, __uint_as_float(reinterpret_cast<const unsigned*>(a.p1)[b]), ref_db, floor_db);
+        int f = -1;
+        if (r < T) f = r < F ? r : -1;
+        else if (r < T + 3) {
+            const int q = r - T;
+            if (F >= 3) f = F - 3 + q; else if (q < F) f = q;
+        }
+        a.q0[i] = f >= 0 ? log_one(a.lp, a.p0[(b * F + f) * NKk + m], ref_db, floor_db) : 0.f;
         break;
     }
     case OP_LN_FWD: {       // y = LayerNorm(x), statistics saved; one wave per row
@@ -557,6 +576,7 @@ int64_t trainp_mask_alloc_bytes(Context* c) {
 // xp_dev: packed encoder input (B, KP, NK) when the caller (the from-audio step) produced it, else null and it is packed
 // here from mel / mel_short.
 int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short, const float* xp_dev,
+                                  const TrainAudioSrc* asrc,
                                   const float* emo, const float* target, float mse_w, float l1_w, float* flat_grad, float* loss_dev,
                                   float* out_dev, float* ema_state, int ema_first, void* stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -643,11 +663,11 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         ElemArgs e{};
         e.q0 = flat_grad; e.n0 = c->tr_nparams;
         pg.elem(OP_ZERO, e, (c->tr_nparams + 1023) / 1024);
-        if (xp_dev && c->melmax_dirty) {      // the front end that just ran left its window maxima behind: clean slots for the next one
-            ElemArgs z{};
-            z.q0 = reinterpret_cast<float*>(c->ws_melmax); z.n0 = c->ws_windows;
-            pg.elem(OP_ZERO, z, (c->ws_windows + 1023) / 1024);
-            c->melmax_dirty = false;
+        if (asrc) {                            // from audio: the power-mel of the front end -> packed log-mel rows (read by P1)
+            ElemArgs e{};
+            e.p0 = asrc->melpow; e.p1 = reinterpret_cast<const float*>(asrc->melmax); e.q0 = const_cast<float*>(xp_dev); e.n0 = B;
+            e.i0 = (int)NKk; e.i1 = (int)KP; e.i2 = (int)T; e.i3 = asrc->n_frames; e.lp = *asrc->lp;
+            pg.elem(OP_LOGPACK, e, blocks256(B * KP * NKk));
         }
         ElemArgs f{};
         f.q0 = ones; f.n0 = R; f.f0 = 1.0f;
@@ -681,6 +701,12 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     pg.gemm(NT(emo, ED, P("emotion_encoder.weight"), ED, E0, d, B, d, P("emotion_encoder.bias"), 0), 1);
     RUN(pg.end_phase(st));
     // ================= P1: channel encoder; folds; emotion LayerNorm =================
+    if (asrc) {       // the window maxima were read in P0: clean slots for the next front-end launch (no memset)
+        ElemArgs z{};
+        z.q0 = reinterpret_cast<float*>(c->ws_melmax); z.n0 = c->ws_windows;
+        pg.elem(OP_ZERO, z, (c->ws_windows + 1023) / 1024);
+        c->melmax_dirty = false;
+    }
     {   // Y0[b] (NK x d) = X_b^T Wce^T + b over the KT packed rows
         GemmArgs g = G(X, 1, NKk, Wce, 1, KT, Y0, d, NKk, d, KT);
         g.a_bs1 = KP * NKk; g.c_bs1 = NKk * d; g.bias = P("mel_channel_encoder.bias"); g.bias_mode = 1;
