@@ -740,12 +740,13 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
                 const float4* pr = prow + (desc & 255);
                 const float4* wt = wbase + ((unsigned)desc >> 16);
                 v2f acc = {0.f, 0.f};
-                float4 wv = wt[0], wn = wt[steps > 1 ? 1 : 0], pv = pr[0];
-                for (int t = 0; t < steps; ++t) {                                      // taps two steps ahead, powers one
-                    const float4 wnn = wt[t + 2 < steps ? t + 2 : t], pn = pr[t + 1 < steps ? t + 1 : t];
+                float4 wv = wt[0], pv = pr[0];
+                for (int t = 0; t < steps; ++t) {                                      // the next step's operands ahead of the FMAs
+                    const int tn = t + 1 < steps ? t + 1 : t;
+                    const float4 wn = wt[tn], pn = pr[tn];
                     acc = __builtin_elementwise_fma(v2f{pv.x, pv.y}, v2f{wv.x, wv.y}, acc);
                     acc = __builtin_elementwise_fma(v2f{pv.z, pv.w}, v2f{wv.z, wv.w}, acc);
-                    pv = pn; wv = wn; wn = wnn;
+                    pv = pn; wv = wn;
                 }
                 float r = acc.x + acc.y;
                 r = fvalid ? r : 0.f;
