@@ -155,3 +155,30 @@ def test_split_bf16_variant_is_opt_in_and_close(terms, tol):
     assert err < tol, err                          # inside the error study's bound
     if terms == 3:
         assert err > 0                             # 16 mantissa bits: a different arithmetic, visibly (six terms can round to the same floats)
+
+
+def test_window_maxima_are_handed_back_clean_without_a_memset():
+    """The dB reference of a window is the maximum of ITS power-mel (librosa power_to_db(ref=np.max)), collected with
+    atomicMax into a per-window slot that the consumer re-zeroes (fused d=256 core, generic encoder).  A loud batch followed
+    by a quiet one on the same engine must give what a fresh engine gives for the quiet one -- a stale maximum would shift
+    every dB value of the second call."""
+    for kw, pk in ((dict(), dict(style="init")), (dict(d_model=512, num_heads=16, mel_sequence_length=512), None)):
+        if pk is None:
+            params = synth.make_core_params(5, 512, 512, 256, "init")
+        else:
+            params = synth.make_core_params(5, **pk)
+        L = 136448 if not kw else 512 * 266
+        loud = dev(synth.make_audio(6, 4, L, "uniform"))
+        quiet = dev(synth.make_audio(7, 4, L, "uniform") * 1e-3)
+        emo = dev(synth.normal(8, (4, 256)))
+        outs = []
+        for fresh in (False, True):
+            from koemorph_amd.engine import Engine, MelConfig
+            e = Engine(**kw, **({"mel": MelConfig.model_batch(target_fps=60)} if kw else {}))
+            e.load_state_dict(params)
+            e.finalize()
+            e.reserve(4, L)
+            if not fresh:
+                e.forward_audio(loud, emo)
+            outs.append(e.forward_audio(quiet, emo).cpu().numpy())
+        assert np.array_equal(outs[0], outs[1])

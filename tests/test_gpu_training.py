@@ -271,3 +271,26 @@ def test_audio_visual_term_and_full_loss_match_reference(name):
     loss = tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target))
     assert abs(float(loss.item()) - float(g["loss"])) < 2e-6 * max(1.0, abs(float(g["loss"])))
     assert_grads_match(tr.grads({k: v.shape for k, v in params.items()}), g, 2e-4)
+
+
+def test_train_step_from_audio_leaves_clean_window_maxima():
+    """The from-audio step converts the front end's power-mel inside phase 0 of the program and re-zeroes the window maxima
+    in phase 1 (no memset launch): loss and gradient of a quiet batch must not depend on a loud batch run before it."""
+    params = synth.make_core_params(81, style="init")
+    loud = dev(synth.make_audio(82, 8, 136448))
+    quiet = dev(synth.make_audio(83, 8, 136448) * 1e-3)
+    emo = dev(synth.normal(84, (8, 256)))
+    target = dev(synth.uniform(85, (8, 52), 0, 1))
+    res = []
+    for fresh in (False, True):
+        e = Engine()
+        e.load_state_dict(params)
+        e.finalize()
+        tr = Trainer(e, max_windows=8, dropout=0.0)
+        if not fresh:
+            tr.forward_backward(loud, emo, target)           # no optimizer step: the weights stay what they were
+            tr.reset_temporal_state()                        # ... and the EMA starts over, as in the fresh trainer
+        loss = float(tr.forward_backward(quiet, emo, target).item())
+        res.append((loss, tr.flat_grad.clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
