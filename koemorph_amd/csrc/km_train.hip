@@ -261,43 +261,73 @@ __global__ void adamw_tick_kernel(int* __restrict__ steps, int alpha_live) {
 // smoothing_alpha is outside the autograd graph whenever the EMA passes its input through (first call / batch-size
 // change / smoothing off): torch leaves its .grad as None and AdamW then skips it entirely (no decay, no moment
 // update, its own step counter).  alpha_idx / alpha_live / (abc1, abc2) reproduce that.
-__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
-                             int64_t n, const float* __restrict__ part, float* __restrict__ gnorm_out, float max_norm, float lr,
-                             float b1, float b2, float eps, float wd, const int* __restrict__ steps, int64_t alpha_idx,
-                             int alpha_live) {
-    // global gradient norm from the 256 partial sums: every block runs the same fixed-order tree, so all agree bit for bit
-    __shared__ float sh[256];
-    sh[threadIdx.x] = part[threadIdx.x];
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                    const float* __restrict__ g, int64_t n, const float* __restrict__ part,
+                                                    float* __restrict__ gnorm_out, float max_norm, float lr, float b1, float b2,
+                                                    float eps, float wd, const int* __restrict__ steps, int64_t alpha_idx,
+                                                    int alpha_live) {
+    // global gradient norm from the 256 partial sums: every block runs the same fixed-order tree (a butterfly inside each
+    // wave, then the four wave sums in wave order), so all blocks agree bit for bit
+    __shared__ float sh[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float s = part[tid];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) sh[wave] = s;
+    // the 1-based step counters live on the device (advanced by sumsq_partial_kernel) so that the launch can be replayed
+    // from a hipGraph: steps[0] = optimizer step, steps[1] = number of updates smoothing_alpha has received.  The bias
+    // corrections are the same for every element but smoothing_alpha: one thread computes them for the block.
+    if (tid == 0) {
+        const int t = steps[0];
+        sh[4] = 1.0f - powf(b1, (float)t);
+        sh[5] = 1.0f - powf(b2, (float)t);
+    }
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
-        __syncthreads();
-    }
-    const float gnorm = sqrtf(sh[0]);
-    if (blockIdx.x == 0 && threadIdx.x == 0) gnorm_out[0] = gnorm;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    // the 1-based step counters live on the device (advanced by adamw_tick_kernel) so that the launch can be replayed
-    // from a hipGraph: steps[0] = optimizer step, steps[1] = number of updates smoothing_alpha has received
-    int t = steps[0];
-    if (i == alpha_idx) {
-        if (!alpha_live) return;
-        t = steps[1];
-    }
-    const float bc1 = 1.0f - powf(b1, (float)t), bc2 = 1.0f - powf(b2, (float)t);
+    const float gnorm = sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3]));
+    if (blockIdx.x == 0 && tid == 0) gnorm_out[0] = gnorm;
     float scale = 1.f;
     if (max_norm > 0.f) {
         const float c = max_norm / (gnorm + 1e-6f);          // clip_coef, clamped to 1
         scale = c < 1.f ? c : 1.f;
     }
-    const float gi = g[i] * scale;
-    float pi = p[i] * (1.0f - lr * wd);
-    const float mi = b1 * m[i] + (1.0f - b1) * gi;
-    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-    m[i] = mi; v[i] = vi;
-    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-    pi -= (lr / bc1) * mi / denom;
-    p[i] = pi;
+    const float bc1_all = sh[4], bc2_all = sh[5];
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + tid) * 4;      // four consecutive parameters per thread
+    if (i0 >= n) return;
+    auto update = [&](float& pi, float& mi, float& vi, float gi, float bc1, float bc2) {
+        gi *= scale;
+        pi *= (1.0f - lr * wd);
+        mi = b1 * mi + (1.0f - b1) * gi;
+        vi = b2 * vi + (1.0f - b2) * gi * gi;
+        const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        pi -= (lr / bc1) * mi / denom;
+    };
+    const bool whole = i0 + 3 < n && (alpha_idx < i0 || alpha_idx > i0 + 3) && (reinterpret_cast<uintptr_t>(g) & 15) == 0;
+    if (whole) {
+        float4 p4 = *reinterpret_cast<const float4*>(p + i0), m4 = *reinterpret_cast<const float4*>(m + i0);
+        float4 v4 = *reinterpret_cast<const float4*>(v + i0);
+        const float4 g4 = *reinterpret_cast<const float4*>(g + i0);
+        update(p4.x, m4.x, v4.x, g4.x, bc1_all, bc2_all);
+        update(p4.y, m4.y, v4.y, g4.y, bc1_all, bc2_all);
+        update(p4.z, m4.z, v4.z, g4.z, bc1_all, bc2_all);
+        update(p4.w, m4.w, v4.w, g4.w, bc1_all, bc2_all);
+        *reinterpret_cast<float4*>(p + i0) = p4;
+        *reinterpret_cast<float4*>(m + i0) = m4;
+        *reinterpret_cast<float4*>(v + i0) = v4;
+        return;
+    }
+    for (int64_t i = i0; i < n && i < i0 + 4; ++i) {
+        float bc1 = bc1_all, bc2 = bc2_all;
+        if (i == alpha_idx) {
+            // smoothing_alpha is outside the autograd graph whenever the EMA passes its input through: no decay, no moment
+            // update, its own step counter
+            if (!alpha_live) continue;
+            const int t = steps[1];
+            bc1 = 1.0f - powf(b1, (float)t); bc2 = 1.0f - powf(b2, (float)t);
+        }
+        float pi = p[i], mi = m[i], vi = v[i];
+        update(pi, mi, vi, g[i], bc1, bc2);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
 }
 
 // ---- host orchestration ----------------------------------------------------------------------------------------
@@ -592,7 +622,7 @@ int train_adamw(Context* c, const float* flat_grad, float lr, float b1, float b2
     // two launches: partial sums of squares (+ the step counters), then norm + clip + AdamW in one kernel
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, flat_grad, n, c->tr_part, c->tr_steps, c->tr_alpha_live ? 1 : 0);
     (void)step;
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->tr_params, c->tr_m, c->tr_v, flat_grad, n,
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, c->tr_params, c->tr_m, c->tr_v, flat_grad, n,
                        c->tr_part, c->tr_gnorm, max_norm, lr, b1, b2, eps, wd, c->tr_steps, c->tr_offset.at("smoothing_alpha"),
                        c->tr_alpha_live ? 1 : 0);
     HIP_TRY(hipGetLastError());
