@@ -182,3 +182,18 @@ def test_window_maxima_are_handed_back_clean_without_a_memset():
                 e.forward_audio(loud, emo)
             outs.append(e.forward_audio(quiet, emo).cpu().numpy())
         assert np.array_equal(outs[0], outs[1])
+
+
+def test_generic_path_at_d256_other_window_against_oracle():
+    """d_model 256 with a window other than 256 does not fit the fused kernel's constants and runs the generic chain with
+    the 8-wave x 32-column instantiation of the encoder + LayerNorm kernel (the d=512 and d=64 goldens cover the others);
+    16 heads of 16 columns go through the unfused output path."""
+    for H, T in ((8, 128), (16, 160)):
+        params = synth.make_core_params(91, 256, T, style="trained")
+        e = engine_for(params, d_model=256, num_heads=H, mel_sequence_length=T)
+        assert not e.fused
+        for B, t_in in ((9, T + 1), (4, T - 37)):
+            mel, short, emo = synth.make_core_inputs(800 + B, B, t_in)
+            ref = core.core_forward_np(params, mel, short, emo, num_heads=H, mel_sequence_length=T)["blendshapes"]
+            got = e.core_forward(dev(mel), dev(short), dev(emo))["blendshapes"].cpu().numpy()
+            assert np.abs(got - ref).max() < TOL
