@@ -63,14 +63,10 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
         for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
         return v;
     };
-    if (w == 0) {   // stream weight softmaxes (dual_stream_attention.py:252-253), lane k = coefficient k
-        const float vm = i < 52 ? a.mel_w[i] / a.temperature : -INFINITY, ve = i < 52 ? a.emo_w[i] / a.temperature : -INFINITY;
-        const float mm = wmax64(vm), me = wmax64(ve);
-        const float em = i < 52 ? expf(vm - mm) : 0.f, ee = i < 52 ? expf(ve - me) : 0.f;
-        const float sm = wsum64(em), se = wsum64(ee);
-        if (i < 52) { wm_s[i] = em / sm; we_s[i] = ee / se; wsum_s[i] = 0.5f * wm_s[i] + 0.5f * we_s[i]; }
-    }
-    __syncthreads();
+    // operands nothing else depends on are requested first: they arrive under the decoder-output pass below (the stream
+    // weight softmaxes used to run -- and wait for their loads -- before it, behind a barrier of their own)
+    const float mel_w_i = (w == 0 && i < 52) ? a.mel_w[i] : 0.f, emo_w_i = (w == 0 && i < 52) ? a.emo_w[i] : 0.f;
+    const float alpha_raw = a.alpha_p[0];
     const float* zr = a.zrows;
     if (a.zrows_out) {   // decoder output layer: one wave per row, lanes stride the hidden units
         // 16 lanes per row, four rows per wave at a time, eight such passes in flight: the stores come after the group's
@@ -101,8 +97,15 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
         zr = a.zrows_out;
         __threadfence_block();
     }
+    if (w == 0) {   // stream weight softmaxes (dual_stream_attention.py:252-253), lane k = coefficient k
+        const float vm = i < 52 ? mel_w_i / a.temperature : -INFINITY, ve = i < 52 ? emo_w_i / a.temperature : -INFINITY;
+        const float mm = wmax64(vm), me = wmax64(ve);
+        const float em = i < 52 ? expf(vm - mm) : 0.f, ee = i < 52 ? expf(ve - me) : 0.f;
+        const float sm = wsum64(em), se = wsum64(ee);
+        if (i < 52) { wm_s[i] = em / sm; we_s[i] = ee / se; wsum_s[i] = 0.5f * wm_s[i] + 0.5f * we_s[i]; }
+    }
     __syncthreads();
-    const float alpha = 1.0f / (1.0f + expf(-a.alpha_p[0]));
+    const float alpha = 1.0f / (1.0f + expf(-alpha_raw));
     const float inv_n = 1.0f / (float)(a.B * 52);
     const bool ema_on = a.ema_state && !a.ema_first;
     // ---- pass A: y = EMA(clamp(wsum * sigmoid(z))) ----
