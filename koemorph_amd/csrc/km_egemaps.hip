@@ -178,26 +178,31 @@ __global__ __launch_bounds__(256) void egm_peak_kernel(const float* __restrict__
     if (threadIdx.x == 0) scale[blockIdx.x] = red[0] > 0.f ? 1.0f / red[0] : 1.0f;
 }
 
-// block-wide reductions through a 256-float LDS scratch, fixed order (tree)
+// block-wide reductions (256 threads = 4 waves), fixed order: an xor butterfly inside each wave, then the four wave results
+// in wave order through 4 floats of LDS scratch -- two barriers instead of the ten of a 256-element LDS tree
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
 __device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
     __syncthreads();
-    red[threadIdx.x] = v;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    return red[0];
+    return (red[0] + red[1]) + (red[2] + red[3]);
 }
 __device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
     __syncthreads();
-    red[threadIdx.x] = v;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
-        __syncthreads();
-    }
-    return red[0];
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 // in-place 1024-point complex FFT of buf (interleaved re, im) in LDS: bit-reversed load order is the caller's; radix-2 DIT
@@ -295,16 +300,20 @@ __global__ __launch_bounds__(256) void egm_frame_kernel(EgmArgs a) {
         E[tid] = acc;
     }
     __syncthreads();
-    if (tid == 0) {
-        float loud = 0.f;
-        for (int j = 0; j < NBANDS; ++j) loud += powf(E[j] * a.tab[a.o_eql + j], 0.33f);
-        rec[R_LOUD] = loud;
-        for (int i = 0; i < 4; ++i) {
-            float c = 0.f;
-            for (int j = 0; j < NBANDS; ++j) c = fmaf(logf(fmaxf(E[j], 1e-8f)), a.tab[a.o_dct + i * NBANDS + j], c);
-            rec[R_MFCC + i] = c;
+    if (tid < 64) {          // wave 0, lane j = band j: the 26 powers / logarithms in parallel, sums by butterfly
+        const bool on = tid < NBANDS;
+        const float ej = on ? E[tid] : 0.f;
+        const float loud = wave_sum(on ? powf(ej * a.tab[a.o_eql + tid], 0.33f) : 0.f);
+        const float le = on ? logf(fmaxf(ej, 1e-8f)) : 0.f;
+        float c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = wave_sum(on ? le * a.tab[a.o_dct + i * NBANDS + tid] : 0.f);
+        if (tid == 0) {
+            rec[R_LOUD] = loud;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rec[R_MFCC + i] = c[i];
+            rec[R_RMS] = rms;
         }
-        rec[R_RMS] = rms;
     }
     // ---- alpha ratio, Hammarberg index, slopes, flux ----
     {
@@ -355,28 +364,36 @@ __global__ __launch_bounds__(256) void egm_frame_kernel(EgmArgs a) {
     const float peak = block_max(tid < nshs ? sv : 0.f, red);
     const float mean = block_sum(tid < nshs ? sv : 0.f, red) / nshs;
     (void)mean;
-    if (tid == 0) {
-        // greedy candidates: highest point (first index on ties), then blank +- 1/6 octave around it
-        float work_peak;
+    // greedy candidates: highest point (first index on ties), then blank +- 1/6 octave around it -- one block arg-max per
+    // candidate (the value first, then the lowest index that reaches it) instead of thread 0 scanning the curve NCAND times
+    {
+        int kprev[NCAND];
+#pragma unroll
         for (int c = 0; c < NCAND; ++c) {
-            int k = -1; work_peak = 0.f;
-            for (int j = 0; j < nshs; ++j) {
-                bool blanked = false;
-                for (int q = 0; q < c; ++q) { const int kq = (int)misc[q]; if (j >= kq - PPO / 6 && j <= kq + PPO / 6) blanked = true; }
-                if (!blanked && shs[j] > work_peak) { work_peak = shs[j]; k = j; }
+            bool blanked = tid >= nshs;
+#pragma unroll
+            for (int q = 0; q < c; ++q) if (kprev[q] >= 0 && tid >= kprev[q] - PPO / 6 && tid <= kprev[q] + PPO / 6) blanked = true;
+            const float v = blanked ? 0.f : sv;
+            const float best = block_max(v, red);
+            const float ki = block_max((best > 0.f && !blanked && v == best) ? (float)(nshs - tid) : 0.f, red);   // first index wins
+            const int k = best > 0.f ? nshs - (int)ki : -1;
+            kprev[c] = k;
+            if (tid == 0) {
+                if (k < 0) { rec[R_CF + c] = 0.f; rec[R_CS + c] = 0.f; misc[c] = -1000.f; }
+                else {
+                    misc[c] = (float)k;
+                    float dlt = 0.f;
+                    if (k > 0 && k < nshs - 1) {
+                        const float y0 = shs[k - 1], y1 = shs[k], y2 = shs[k + 1], den = y0 - 2.f * y1 + y2;
+                        dlt = den == 0.f ? 0.f : fminf(fmaxf(0.5f * (y0 - y2) / den, -0.5f), 0.5f);
+                    }
+                    rec[R_CF + c] = 25.0f * exp2f((a.j0 + k + dlt) / (float)PPO);
+                    rec[R_CS + c] = shs[k] / peak;
+                    if (c == 0) misc[4] = rec[R_CF];
+                }
             }
-            if (k < 0) { rec[R_CF + c] = 0.f; rec[R_CS + c] = 0.f; misc[c] = -1000.f; continue; }
-            misc[c] = (float)k;
-            float dlt = 0.f;
-            if (k > 0 && k < nshs - 1) {
-                const float y0 = shs[k - 1], y1 = shs[k], y2 = shs[k + 1], den = y0 - 2.f * y1 + y2;
-                dlt = den == 0.f ? 0.f : fminf(fmaxf(0.5f * (y0 - y2) / den, -0.5f), 0.5f);
-            }
-            rec[R_CF + c] = 25.0f * exp2f((a.j0 + k + dlt) / (float)PPO);
-            rec[R_CS + c] = shs[k] / peak;
-            if (c == 0) misc[4] = rec[R_CF];
         }
-        if (misc[0] < 0.f) misc[4] = 0.f;
+        if (tid == 0 && kprev[0] < 0) misc[4] = 0.f;
     }
     __syncthreads();
     // ---- voicing: normalised autocorrelation at the strongest candidate's lag (+- 10 %), only if it is a local maximum ----
@@ -411,61 +428,76 @@ __global__ __launch_bounds__(256) void egm_frame_kernel(EgmArgs a) {
             if (tid == 0) R[l] = v;
         }
         __syncthreads();
-        if (tid == 0) {
+        if (tid < 64) {     // wave 0: Levinson-Durbin redundantly in every lane (uniform), then ONE ROOT PER LANE
             float F[3] = {0.f, 0.f, 0.f}, BW[3] = {0.f, 0.f, 0.f};
-            if (R[0] > 0.f) {
+            float* fsel = misc + 24;   // [LPC] candidate frequencies, [LPC] bandwidths behind them
+            float* bsel = fsel + LPC;
+            if (R[0] > 0.f) {           // uniform
                 float ac[LPC + 1], tmp[LPC + 1];
                 ac[0] = 1.f;
+#pragma unroll
                 for (int i = 1; i <= LPC; ++i) ac[i] = 0.f;
                 float err = R[0];
                 bool ok = true;
-                for (int i = 1; i <= LPC && ok; ++i) {                      // Levinson-Durbin
+#pragma unroll
+                for (int i = 1; i <= LPC; ++i) {                            // Levinson-Durbin
+                    if (!ok) continue;
                     float acc = R[i];
+#pragma unroll
                     for (int j = 1; j < i; ++j) acc = fmaf(ac[j], R[i - j], acc);
                     const float kk = -acc / err;
+#pragma unroll
                     for (int j = 1; j < i; ++j) tmp[j] = ac[j] + kk * ac[i - j];
+#pragma unroll
                     for (int j = 1; j < i; ++j) ac[j] = tmp[j];
                     ac[i] = kk;
                     err *= 1.0f - kk * kk;
                     if (err <= 0.f) ok = false;
                 }
-                // roots of z^11 + ac[1] z^10 + ... + ac[11] by Durand-Kerner (Weierstrass) iteration
-                float zr[LPC], zi[LPC];
-                for (int i = 0; i < LPC; ++i) { const float ang = 2.0f * 3.14159265f * (i + 0.35f) / LPC; zr[i] = 0.9f * cosf(ang); zi[i] = 0.9f * sinf(ang); }
+                // roots of z^11 + ac[1] z^10 + ... + ac[11] by Durand-Kerner (Weierstrass) iteration, lane i = root i, all
+                // roots updated together from the previous iterate (the serial version updated them one after another on
+                // thread 0 and was 85 % of this kernel's time); the partners' values come by shuffle
+                const int li = tid < LPC ? tid : 0;
+                const float ang = 2.0f * 3.14159265f * (li + 0.35f) / LPC;
+                float zr = 0.9f * cosf(ang), zi = 0.9f * sinf(ang);
                 for (int it = 0; it < 60; ++it) {
-                    float change = 0.f;
-                    for (int i = 0; i < LPC; ++i) {
-                        float pr = 1.f, pi = 0.f;                           // Horner: p(z_i)
-                        for (int j = 1; j <= LPC; ++j) { const float nr = pr * zr[i] - pi * zi[i] + ac[j], ni = pr * zi[i] + pi * zr[i]; pr = nr; pi = ni; }
-                        float qr = 1.f, qi = 0.f;                           // prod_{j != i} (z_i - z_j)
-                        for (int j = 0; j < LPC; ++j) {
-                            if (j == i) continue;
-                            const float dr = zr[i] - zr[j], di = zi[i] - zi[j];
-                            const float nr = qr * dr - qi * di, ni = qr * di + qi * dr; qr = nr; qi = ni;
-                        }
-                        const float den = qr * qr + qi * qi + 1e-30f;
-                        const float cr = (pr * qr + pi * qi) / den, ci = (pi * qr - pr * qi) / den;
-                        zr[i] -= cr; zi[i] -= ci;
-                        change = fmaxf(change, fabsf(cr) + fabsf(ci));
+                    float pr = 1.f, pi = 0.f;                               // Horner: p(z_i)
+#pragma unroll
+                    for (int j = 1; j <= LPC; ++j) { const float nr = pr * zr - pi * zi + ac[j], ni = pr * zi + pi * zr; pr = nr; pi = ni; }
+                    float qr = 1.f, qi = 0.f;                               // prod_{j != i} (z_i - z_j)
+#pragma unroll
+                    for (int j = 0; j < LPC; ++j) {
+                        const float zjr = __shfl(zr, j), zji = __shfl(zi, j);
+                        const float dr = zr - zjr, di = zi - zji;
+                        const float nr = qr * dr - qi * di, ni = qr * di + qi * dr;
+                        if (j != li) { qr = nr; qi = ni; }
                     }
-                    if (change < 1e-7f) break;
+                    const float den = qr * qr + qi * qi + 1e-30f;
+                    const float cr = (pr * qr + pi * qi) / den, ci = (pi * qr - pr * qi) / den;
+                    zr -= cr; zi -= ci;
+                    const float change = wave_max(tid < LPC ? fabsf(cr) + fabsf(ci) : 0.f);
+                    if (change < 1e-7f) break;                              // uniform
                 }
                 const float fs2 = 11000.0f;
-                int nsel = 0; float fsel[LPC], bsel[LPC];
-                for (int i = 0; i < LPC; ++i) {
-                    if (zi[i] <= 1e-6f) continue;
-                    const float fr = atan2f(zi[i], zr[i]) * fs2 / (2.0f * 3.14159265f);
-                    const float bw = -logf(fmaxf(sqrtf(zr[i] * zr[i] + zi[i] * zi[i]), 1e-12f)) * fs2 / 3.14159265f;
-                    if (fr > 90.f && fr < 5400.f && bw < 1000.f) { fsel[nsel] = fr; bsel[nsel] = bw; ++nsel; }
+                float fr = -1.f, bw = 0.f;
+                if (tid < LPC && zi > 1e-6f) {
+                    const float f = atan2f(zi, zr) * fs2 / (2.0f * 3.14159265f);
+                    const float bq = -logf(fmaxf(sqrtf(zr * zr + zi * zi), 1e-12f)) * fs2 / 3.14159265f;
+                    if (f > 90.f && f < 5400.f && bq < 1000.f) { fr = f; bw = bq; }
                 }
-                for (int c = 0; c < 3; ++c) {                               // three lowest
-                    int best = -1;
-                    for (int i = 0; i < nsel; ++i) if (fsel[i] > 0.f && (best < 0 || fsel[i] < fsel[best])) best = i;
-                    if (best < 0) break;
-                    F[c] = fsel[best]; BW[c] = bsel[best]; fsel[best] = -1.f;
+                if (tid < LPC) { fsel[tid] = fr; bsel[tid] = bw; }
+                __builtin_amdgcn_wave_barrier();
+                if (tid == 0) {
+                    for (int c = 0; c < 3; ++c) {                           // three lowest
+                        int best = -1;
+                        for (int i = 0; i < LPC; ++i) if (fsel[i] > 0.f && (best < 0 || fsel[i] < fsel[best])) best = i;
+                        if (best < 0) break;
+                        F[c] = fsel[best]; BW[c] = bsel[best]; fsel[best] = -1.f;
+                    }
                 }
             }
-            for (int c = 0; c < 3; ++c) { rec[R_F + c] = F[c]; rec[R_BW + c] = BW[c]; }
+            if (tid == 0)
+                for (int c = 0; c < 3; ++c) { rec[R_F + c] = F[c]; rec[R_BW + c] = BW[c]; }
         }
     }
 }
