@@ -615,12 +615,13 @@ __global__ __launch_bounds__(256) void egm_voiced_kernel(EgmArgs a) {
                 for (int n = 0; n < lag; ++n) { const float u = seg[pos + n], v = seg[pos + lag + n]; ab = fmaf(u, v, ab); aa = fmaf(u, u, aa); bb = fmaf(v, v, bb); }
                 c = ab / sqrtf(fmaxf(aa * bb, 1e-20f));
             }
-            if (tid < 128) cc[tid] = c;
-            __syncthreads();
+            // strongest lag, first one on ties: block arg-max (value, then the lowest index reaching it) instead of a scan
+            const int nl = hi - lagA + 1 < 128 ? hi - lagA + 1 : 128;
+            const bool in = tid < nl;
+            const float bc = block_max(in ? c : -INFINITY, red);
+            const float kf = block_max((in && c == bc && bc > -INFINITY) ? (float)(128 - tid) : 0.f, red);
             if (tid == 0) {
-                float bc = -INFINITY; int bl = 0;
-                const int nl = hi - lagA + 1 < 128 ? hi - lagA + 1 : 128;
-                for (int k = 0; k < nl; ++k) if (cc[k] > bc) { bc = cc[k]; bl = lagA + k; }
+                const int bl = kf > 0.f ? lagA + (128 - (int)kf) : 0;
                 if (bl == 0 || bc < 0.5f || marks[63] >= 62) marks[62] = 0;          // stop
                 else { marks[marks[63]] = pos + bl; marks[63] += 1; marks[62] = 1; }
             }
