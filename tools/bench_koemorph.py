@@ -28,6 +28,7 @@ CASES = ((int(os.environ.get("B", 256)), 30), (1024, 1))
 if os.environ.get("ONLY"):
     CASES = (CASES[int(os.environ["ONLY"])],)
 for B, T in CASES:
+    m.reset_temporal_state()                 # a smoother state of another batch size raises, like the reference's expand()
     mel = torch.from_numpy(synth.normal(1, (B, T, 80))).cuda()
     emo = torch.from_numpy(synth.normal(2, (B, T, 256))).cuda()
     prev = torch.from_numpy(synth.uniform(3, (B, 52), 0, 1)).cuda()
