@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256) void egm_voiced_kernel(EgmArgs a) {
     const float r0 = block_sum(r0p, red);
     float best = 0.f;
     {
-        __shared__ float swv[N60];
+        float* swv = reinterpret_cast<float*>(zb);        // the FFT buffer is idle from here on (occupancy: LDS per workgroup)
         for (int n = tid; n < N60; n += 256) swv[n] = seg[n] * g60[n];
         __syncthreads();
         const int lag0 = lo > 1 ? lo : 1;
