@@ -264,7 +264,7 @@ __device__ __forceinline__ void frame_spectra(const EgmArgs& a, const float* xw,
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void egm_frame_kernel(EgmArgs a) {
+__global__ __launch_bounds__(256, 6) void egm_frame_kernel(EgmArgs a) {
     using namespace egm;
     __shared__ float2 zb[NFFT];
     __shared__ float2 tw[NFFT / 2];
