@@ -108,7 +108,7 @@ int km_reserve(km_handle h, int64_t max_windows, int64_t max_samples) {
     }
     c->ws_windows = W; c->ws_frames = F; c->ws_samples = S; c->ws_mels = max_mels;
     c->melmax_dirty = true;
-    return KM_OK;
+    return ensure_chunk_counters(c, W, nullptr);
 }
 
 int km_destroy(km_handle h) {
@@ -117,6 +117,7 @@ int km_destroy(km_handle h) {
     for (auto& kv : c->packed)
         if (kv.second.dev) (void)hipFree(kv.second.dev);
     (void)free_ws(c);
+    if (c->ws_chunkctr) (void)hipFree(c->ws_chunkctr);
     (void)free_streams(c);
     (void)free_train(c);
     (void)free_pipeline(c);

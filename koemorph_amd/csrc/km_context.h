@@ -112,6 +112,8 @@ struct Context {
     float* ws_zemo_win = nullptr;  // (windows)             per-window copy of per-clip logits (generic sequence mode)
     float* ws_melpow = nullptr;    // (windows, frames, 80) power-mel
     unsigned* ws_melmax = nullptr; // (windows)             max power (float bits)
+    unsigned* ws_chunkctr = nullptr;   // (ws_chunkctr_cap) chunk requests per window of mel_power_rp_kernel: zero between launches
+    int64_t ws_chunkctr_cap = 0;
     float* ws_mel = nullptr;       // (windows, frames, 80) log-mel
     float* ws_short = nullptr;     // (windows, 3, 80)
     float* ws_generic = nullptr;   // generic (non-fused) core intermediates, generic_ws_floats() per window
@@ -248,6 +250,7 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
                      const int* ring_start = nullptr, const unsigned char* ready = nullptr,
                      const float* emotion = nullptr, float* zemo = nullptr, const SeqFrames* seq = nullptr);
 bool mel_fuses_emotion(Context* c, MelPlan* p);
+int ensure_chunk_counters(Context* c, int64_t windows, void* stream);
 int launch_ring_push(Context* c, const float* samples, int64_t n_per_stream, void* stream);
 int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, int64_t out_frames,
                float* mel_long, float* mel_short, void* stream, int64_t clip_len = 0, int64_t win_step = 0,

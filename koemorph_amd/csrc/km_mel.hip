@@ -125,6 +125,10 @@ struct MelArgs {
     // maxima go per row into frame_max[(window, row)] instead of per window into melmax
     int frame_mul;
     unsigned* frame_max;  // (B, n_frames) float bits, zero-initialised, or null
+    // mel_power_rp_kernel hands a window's 16-frame chunks (beyond the first two of each workgroup) to its workgroups in the
+    // order they ask for them: chunk_ctr[window] counts the requests, is zero on entry and is put back to zero by the last
+    // request of the launch
+    unsigned* chunk_ctr;
 };
 
 // raw samples of the frame pair (fa, fa+1) into z[i] = (x_a[lane + 64 i], x_b[lane + 64 i]); wave-uniform fa
@@ -365,9 +369,25 @@ __global__ __launch_bounds__(256) void mel_power_kernel(MelArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // KM_MEL_SKIP (A/B builds only, tools/micro/mel_variants.sh; 0 in the library): bit 0 no mel filter stage, bit 1 no LDS
 // exchanges between the FFT passes (data stays in registers: wrong spectra, same arithmetic), bit 2 no FFT arithmetic,
-// bit 3 no audio loads
+// bit 3 no audio loads, bit 4 no emotion rider
 #ifndef KM_MEL_SKIP
 #define KM_MEL_SKIP 0
+#endif
+// KM_MEL_STAMP (timing builds only, tools/micro/mel_stamp.py): every wave sums the shader-clock cycles it spends in each part
+// of the frame loop (s_memtime at the part boundaries; the stamps drain the wave's LDS queue, so the parts are measured with
+// less overlap than they run with) into km_mel_stamps[(workgroup, wave)][part], read back through km_debug_mel_stamps.
+#ifdef KM_MEL_STAMP
+#define KM_ASM asm volatile      /* keeps the arithmetic blocks between their stamps */
+__device__ unsigned long long km_mel_stamps[1024 * 8 * 24];
+#define KM_STAMP(i)                                                  \
+    do {                                                             \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        st_acc[i] += (unsigned)(now_ - st_last);                     \
+        st_last = now_;                                              \
+    } while (0)
+#else
+#define KM_ASM asm
+#define KM_STAMP(i) do {} while (0)
 #endif
 namespace melrp {
 constexpr int WAVES = kMelRpWaves, NT = 64 * WAVES, FPB = 16, NC = 512, FFT_BUF = 576, NGW = kMelRpGroups;
@@ -403,7 +423,7 @@ __device__ __forceinline__ void dif8(v2f (&v)[8]) {
     constexpr float C2 = 0.70710678118654752f;
     const v2f c = {C2, C2};
     v2f r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3], r4 = v[4], r5 = v[5], r6 = v[6], r7 = v[7], t;
-    asm("s_nop 0\n\t"
+    KM_ASM("s_nop 0\n\t"
         // stage 1: s_i = v_i + v_{i+4}, d_i = v_i - v_{i+4};  u1 = d1 + (-i) d1, u3 = (-i) d3 - d3 (their 1/sqrt2 is applied in stage 3)
         KM_ADD(t, r0, r4) KM_SUB(r4, r0, r4)          // s0 = t,  d0 = r4
         KM_ADD(r0, r1, r5) KM_SUB(r5, r1, r5)         // s1 = r0, d1 = r5
@@ -433,7 +453,7 @@ __device__ __forceinline__ void dif8(v2f (&v)[8]) {
 // v[i] *= w[i] for i = 1..7 (14 packed instructions)
 __device__ __forceinline__ void cmul7(v2f (&v)[8], const v2f (&w)[8]) {
     v2f ta, tb;
-    asm("s_nop 0\n\t"
+    KM_ASM("s_nop 0\n\t"
         KM_CMUL1(ta, v1, w1) KM_CMUL1(tb, v2, w2)
         KM_CMUL2(v1, v1, w1, ta) KM_CMUL1(ta, v3, w3)
         KM_CMUL2(v2, v2, w2, tb) KM_CMUL1(tb, v4, w4)
@@ -462,7 +482,7 @@ __device__ __forceinline__ void cmul7(v2f (&v)[8], const v2f (&w)[8]) {
 #define KM_P8(i) "v_pk_fma_f32 %[k" #i "], %[c" #i "], %[c" #i "], %[t" #i "]\n\t"
 __device__ __forceinline__ void post4(v2f (&zk)[4], v2f (&zc)[4], const v2f (&w)[4]) {
     v2f t0, t1, t2, t3;
-    asm("s_nop 0\n\t"
+    KM_ASM("s_nop 0\n\t"
         KM_POST4(KM_P1) KM_POST4(KM_P2) KM_POST4(KM_P3) KM_POST4(KM_P4)
         KM_POST4(KM_P5) KM_POST4(KM_P6) KM_POST4(KM_P7) KM_POST4(KM_P8)
         "s_nop 0"
@@ -493,6 +513,131 @@ __device__ __forceinline__ void lds_read8(unsigned addr, v2f (&y)[8]) {
                  : "memory");
 }
 __device__ __forceinline__ v2f ld2(const float2* p) { const float2 t = *p; return v2f{t.x, t.y}; }
+
+// ---- the exchanges between the FFT passes as REGISTER exchanges (KM_MEL_XCHG bit 0: the one after pass 1, bit 1: the one
+// after pass 2; a cleared bit keeps that exchange in the wave's LDS buffer) -------------------------------------------------
+// An exchange is a transposition of the 8 x 8 grid (register index, three lane bits), done as three stages; stage (j, b)
+// swaps bit j of the register index with lane bit b: for every register pair (r, r | 1 << j) the element of r in the
+// lanes whose bit b is set trades places with the element of r | 1 << j in lane ^ (1 << b).
+//   b = 5: v_permlane32_swap_b32 (one instruction per register pair and dword), b = 4: v_permlane16_swap_b32,
+//   b <= 3: two v_cndmask_b32_dpp per pair and dword -- row_ror:8, row_shr:4 / row_shl:4, quad_perm -- each lane keeps one
+//   element of the pair and takes the other from its partner.
+// 8 + 8 + 16 vector instructions for lane bits 5:3, 48 for lane bits 2:0, no LDS instruction and no dependent LDS round trip
+// (8 ds_write_b64 + 8 ds_read_b64 per exchange).  The arithmetic is untouched, so the spectra are bit-identical; what changes
+// is WHICH lane ends up with which bins (fft_lane_bin below).
+#ifndef KM_MEL_XCHG
+#define KM_MEL_XCHG 1
+#endif
+#ifndef KM_MEL_REMAP
+#define KM_MEL_REMAP 1
+#endif
+#ifndef KM_MEL_FLAT
+#define KM_MEL_FLAT 0
+#endif
+__device__ __forceinline__ void swap_lane32(v2f& a, v2f& b) {
+    const auto r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    a = v2f{__uint_as_float(r0[0]), __uint_as_float(r1[0])}; b = v2f{__uint_as_float(r0[1]), __uint_as_float(r1[1])};
+}
+__device__ __forceinline__ void swap_lane16(v2f& a, v2f& b) {
+    const auto r0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    a = v2f{__uint_as_float(r0[0]), __uint_as_float(r1[0])}; b = v2f{__uint_as_float(r0[1]), __uint_as_float(r1[1])};
+}
+// stage (., B) on two register pairs (a0, b0), (a1, b1) = four dword pairs (a: register bit clear, b: set).  The lanes whose
+// bit B is clear keep a and take the partner's a as their b; the others keep b and take the partner's b as their a.
+//   B = 3, 2: the lanes that receive are whole DPP banks (groups of four lanes), so a write mask does the selection -- three
+//     v_mov_b32_dpp per dword pair: t = a[partner] (row_ror:8 / row_shl:4), a = b[partner] into the banks with bit B set
+//     (bank_mask 0xc / 0xa), b = t into the others (bank_mask 0x3 / 0x5).
+//   B = 1, 0: the partner is inside the quad: two v_mov_b32_dpp (quad_perm) and two v_cndmask_b32_e64 with the lane mask in
+//     an SGPR pair.  NOT v_cndmask_b32_dpp: the VOP2 encoding of v_cndmask_b32 (mask in vcc) issues at 16-24 cycles per
+//     instruction on gfx950 against 4.5-4.9 for the VOP3 encoding (tools/micro/xlane_rate.hip; a DPP move is 4.4, a
+//     v_permlane*_swap 9.0, a packed fp32 instruction 4.9).
+// `s_nop 1`: a DPP read needs two wait states after a vector write of its source and the hazard recogniser does not look into
+// inline assembly; inside a block every DPP source was written at least three instructions earlier.
+#define KM_XM " row_mask:0xf bank_mask:"
+#define KM_XBANK(CT, MT, CA, MA, MB)                                      \
+    "s_nop 1\n\t"                                                        \
+    "v_mov_b32_dpp %[t0], %[a0] " CT KM_XM MT "\n\t"                      \
+    "v_mov_b32_dpp %[t1], %[a1] " CT KM_XM MT "\n\t"                      \
+    "v_mov_b32_dpp %[t2], %[a2] " CT KM_XM MT "\n\t"                      \
+    "v_mov_b32_dpp %[t3], %[a3] " CT KM_XM MT "\n\t"                      \
+    "v_mov_b32_dpp %[a0], %[b0] " CA KM_XM MA "\n\t"                      \
+    "v_mov_b32_dpp %[a1], %[b1] " CA KM_XM MA "\n\t"                      \
+    "v_mov_b32_dpp %[a2], %[b2] " CA KM_XM MA "\n\t"                      \
+    "v_mov_b32_dpp %[a3], %[b3] " CA KM_XM MA "\n\t"                      \
+    "v_mov_b32_dpp %[b0], %[t0] quad_perm:[0,1,2,3]" KM_XM MB "\n\t"      \
+    "v_mov_b32_dpp %[b1], %[t1] quad_perm:[0,1,2,3]" KM_XM MB "\n\t"      \
+    "v_mov_b32_dpp %[b2], %[t2] quad_perm:[0,1,2,3]" KM_XM MB "\n\t"      \
+    "v_mov_b32_dpp %[b3], %[t3] quad_perm:[0,1,2,3]" KM_XM MB "\n\t"      \
+    "s_nop 0"
+#define KM_XBANK_OPERANDS                                                                                              \
+    : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [a0] "+v"(p0), [a1] "+v"(p1), [a2] "+v"(p2), [a3] "+v"(p3), \
+      [b0] "+v"(q0), [b1] "+v"(q1), [b2] "+v"(q2), [b3] "+v"(q3)
+#define KM_XQUAD(QP)                                                       \
+    "s_nop 1\n\t"                                                          \
+    "v_mov_b32_dpp %[t0], %[a0] " QP KM_XM "0xf\n\t"                        \
+    "v_mov_b32_dpp %[t1], %[a1] " QP KM_XM "0xf\n\t"                        \
+    "v_mov_b32_dpp %[u0], %[b0] " QP KM_XM "0xf\n\t"                        \
+    "v_mov_b32_dpp %[u1], %[b1] " QP KM_XM "0xf\n\t"                        \
+    "v_mov_b32_dpp %[t2], %[a2] " QP KM_XM "0xf\n\t"                        \
+    "v_mov_b32_dpp %[t3], %[a3] " QP KM_XM "0xf\n\t"                        \
+    "v_mov_b32_dpp %[u2], %[b2] " QP KM_XM "0xf\n\t"                        \
+    "v_mov_b32_dpp %[u3], %[b3] " QP KM_XM "0xf\n\t"                        \
+    "v_cndmask_b32_e64 %[a0], %[a0], %[u0], %[mk]\n\t"                      \
+    "v_cndmask_b32_e64 %[a1], %[a1], %[u1], %[mk]\n\t"                      \
+    "v_cndmask_b32_e64 %[b0], %[t0], %[b0], %[mk]\n\t"                      \
+    "v_cndmask_b32_e64 %[b1], %[t1], %[b1], %[mk]\n\t"                      \
+    "v_cndmask_b32_e64 %[a2], %[a2], %[u2], %[mk]\n\t"                      \
+    "v_cndmask_b32_e64 %[a3], %[a3], %[u3], %[mk]\n\t"                      \
+    "v_cndmask_b32_e64 %[b2], %[t2], %[b2], %[mk]\n\t"                      \
+    "v_cndmask_b32_e64 %[b3], %[t3], %[b3], %[mk]\n\t"                      \
+    "s_nop 0"
+#define KM_XQUAD_OPERANDS                                                                                              \
+    : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [u0] "=&v"(u0), [u1] "=&v"(u1), [u2] "=&v"(u2), [u3] "=&v"(u3), \
+      [a0] "+v"(p0), [a1] "+v"(p1), [a2] "+v"(p2), [a3] "+v"(p3), [b0] "+v"(q0), [b1] "+v"(q1), [b2] "+v"(q2), [b3] "+v"(q3)       \
+    : [mk] "s"(mk)
+template <int B>
+__device__ __forceinline__ void swap_lane_dpp(v2f& a0, v2f& b0, v2f& a1, v2f& b1) {
+    float p0 = a0.x, p1 = a0.y, p2 = a1.x, p3 = a1.y, q0 = b0.x, q1 = b0.y, q2 = b1.x, q3 = b1.y, t0, t1, t2, t3;
+    if constexpr (B == 3) KM_ASM(KM_XBANK("row_ror:8", "0xf", "row_ror:8", "0xc", "0x3") KM_XBANK_OPERANDS);
+    else if constexpr (B == 2) KM_ASM(KM_XBANK("row_shl:4", "0x5", "row_shr:4", "0xa", "0x5") KM_XBANK_OPERANDS);
+    else {
+        constexpr unsigned long long mk = B == 1 ? 0xCCCCCCCCCCCCCCCCull : 0xAAAAAAAAAAAAAAAAull;
+        float u0, u1, u2, u3;
+        if constexpr (B == 1) KM_ASM(KM_XQUAD("quad_perm:[2,3,0,1]") KM_XQUAD_OPERANDS);
+        else KM_ASM(KM_XQUAD("quad_perm:[1,0,3,2]") KM_XQUAD_OPERANDS);
+    }
+    a0 = v2f{p0, p1}; a1 = v2f{p2, p3}; b0 = v2f{q0, q1}; b1 = v2f{q2, q3};
+}
+// register index bits (2, 1, 0) <-> lane bits (5, 4, 3)
+__device__ __forceinline__ void exchange_hi(v2f (&y)[8]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) swap_lane32(y[r], y[r + 4]);
+#pragma unroll
+    for (int r = 0; r < 8; r += 4) { swap_lane16(y[r], y[r + 2]); swap_lane16(y[r + 1], y[r + 3]); }
+    swap_lane_dpp<3>(y[0], y[1], y[2], y[3]);
+    swap_lane_dpp<3>(y[4], y[5], y[6], y[7]);
+}
+// register index bits (2, 1, 0) <-> lane bits (2, 1, 0)
+__device__ __forceinline__ void exchange_lo(v2f (&y)[8]) {
+    swap_lane_dpp<2>(y[0], y[4], y[1], y[5]);
+    swap_lane_dpp<2>(y[2], y[6], y[3], y[7]);
+    swap_lane_dpp<1>(y[0], y[2], y[1], y[3]);
+    swap_lane_dpp<1>(y[4], y[6], y[5], y[7]);
+    swap_lane_dpp<0>(y[0], y[1], y[2], y[3]);
+    swap_lane_dpp<0>(y[4], y[5], y[6], y[7]);
+}
+// Where the spectrum ends up: after pass 3 register i of a lane holds Z[c + 64 bitrev(i)], c = fft_lane_bin(lane).  An
+// exchange through LDS delivers its digit in natural order, a register exchange bit-reversed (register i of the pass before
+// held digit bitrev(i), and register bit j went to lane bit j [+ 3]).
+__host__ __device__ constexpr int fft_lane_k0(int lane) { return (KM_MEL_XCHG & 1) ? bitrev(lane >> 3, 3) : lane >> 3; }
+__host__ __device__ constexpr int fft_lane_bin(int lane) {
+    return (KM_MEL_XCHG & 2) ? fft_lane_k0(lane) + 8 * bitrev(lane & 7, 3) : lane;
+}
+__host__ __device__ constexpr int fft_bin_lane(int c) {
+    return (KM_MEL_XCHG & 2) ? 8 * ((KM_MEL_XCHG & 1) ? bitrev(c & 7, 3) : (c & 7)) + bitrev(c >> 3, 3) : c;
+}
 }  // namespace melrp
 
 // Interior frames (the common case) are 8 unit-stride 8-byte loads per lane from one base pointer.  Returns false --
@@ -564,11 +709,22 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
     float2* fbuf = reinterpret_cast<float2*>(smem);                     // [WAVES][FFT_BUF]
     float* pw = smem + WAVES * FFT_BUF * 2;                              // [FPB][NFS]
     float* redmax = pw + FPB * NFS;                                      // [WAVES]
-    float* fbw = redmax + WAVES;                                         // [fbg_nw] filter taps x 1/4, four per step
+    int* sched = reinterpret_cast<int*>(redmax + WAVES);                 // [0]: the chunk index handed to this workgroup last ([1..3] pad)
+    float* fbw = redmax + WAVES + 4;                                     // [fbg_nw] filter taps x 1/4, four per step
 
+#ifdef KM_MEL_STAMP
+    const unsigned long long st_entry = __builtin_readcyclecounter(), st_entry_rt = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y;
+    // Workgroup -> (window, chunk phase).  KM_MEL_REMAP: the linear workgroup id counts windows fastest, so the workgroups of
+    // one window are gridDim.y ids apart instead of adjacent (tools/micro: which workgroups share a CU / an XCD's L2).
+#if KM_MEL_REMAP
+    const unsigned lin_ = blockIdx.x + gridDim.x * blockIdx.y;
+    const int b = (int)(lin_ % gridDim.y), bx = (int)(lin_ / gridDim.y);
+#else
+    const int b = blockIdx.y, bx = (int)blockIdx.x;
+#endif
     const int64_t gw = a.win0 + b;
     const int64_t clip = gw / a.wins_per_clip, woff = (gw - clip * a.wins_per_clip) * a.win_step;
     const float* x = a.audio + clip * a.clip_len + woff;
@@ -578,19 +734,45 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
     v2f* buf = reinterpret_cast<v2f*>(fbuf + wave * FFT_BUF);
     const int n_chunks = (a.n_frames + FPB - 1) / FPB;
     const unsigned rd2 = lds_offset(buf + (lane >> 3) * 72 + (lane & 7)), rd3 = lds_offset(buf + lane * 9);
+    const int cbin = fft_lane_bin(lane);                       // this lane finishes the bins cbin + 64 i and 512 - cbin - 64 i
 
-    // The emotion stream of this window (0.2 MFLOP, latency bound, independent of the audio) rides in the workgroup
-    // that has one chunk less to do than its sibling: no separate launch, no exposed latency.
-    if (a.emo.emo && blockIdx.x == gridDim.x - 1) {
+    // Software prefetch: the samples of this wave's NEXT frame are requested as soon as pass 1 has left the registers
+    // (they complete under passes 2-3 and the post-processing; across a chunk boundary under the mel stage).  Without
+    // it every workgroup stalls on HBM latency after each barrier: the kernel is latency bound, not VALU bound.  The first
+    // frame is requested here, ahead of everything else the prologue loads (tables through L2; these come from HBM).
+    v2f zn[8];
+    bool zn_ok = false;                                                  // wave-uniform: zn holds the next frame
+    const int fmul = a.frame_mul;
+    auto first_frame = [&]() {
+        if (KM_MEL_SKIP & 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) zn[i] = v2f{0.001f * lane, 0.5f + i};
+            zn_ok = true;
+        } else if (bx * FPB + wave < a.n_frames) zn_ok = load_frame_rp_fast<RING>(x, Lv, rs, a.hop, (bx * FPB + wave) * fmul, lane, zn);
+    };
+    // The emotion stream of this window (0.2 MFLOP, latency bound, independent of the audio) rides in the last workgroup of
+    // the window: no separate launch, and the chunk hand-out below lets that workgroup take correspondingly fewer chunks.
+    // (It requests its first frame after the rider: the rider's weight loads need the registers.)
+    if (!(KM_MEL_SKIP & 16) && a.emo.emo && bx == (int)gridDim.x - 1) {
         if (a.emo.d == 256 && a.emo.DH == 128) emotion_window_d256(a.emo, gw, pw);
         else emotion_window_generic(a.emo, EmoShape{a.emo.d, a.emo.DH}, gw, pw);
+        first_frame();
+    } else {
+        first_frame();
     }
 
+    // Chunks: the first two of a workgroup are fixed (bx and bx + gridDim.x: their first frames can be requested at once),
+    // the others are handed out on request, so the workgroups of a window finish within one chunk of each other whatever
+    // else they did (the rider above) or shared their CU with.  A workgroup always knows its current and its next chunk (the
+    // next one's first frames are prefetched under the current one) and asks for the one after while it works on the
+    // current one: request k of the launch returns chunk 2 gridDim.x + k.  Every chunk is worked on exactly once and each
+    // costs one request, so a window sees n_chunks requests per launch; the last one puts the counter back to zero.
+    const unsigned ctr_last = (unsigned)n_chunks - 1u;
     for (int i = tid; i < a.fbg_nw; i += NT) fbw[i] = a.fbg_weight[i];
     for (int i = tid; i < FPB * (NFS - 513); i += NT) pw[(i / (NFS - 513)) * NFS + 513 + i % (NFS - 513)] = 0.f;   // row padding the mel steps may read
 
     // lane-constant operands (56 registers)
-    const int n2 = lane & 7, k0 = lane >> 3;
+    const int n2 = lane & 7, k0 = fft_lane_k0(lane);
     v2f win2[8], tw1[8], tw2[8], twp[4];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -599,7 +781,7 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
         tw2[i] = ld2(a.twiddle + ((16 * n2 * bitrev(i, 3)) & 1023));    // W_64^(n2 k1)
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) twp[i] = ld2(a.twiddle + lane + 64 * i);   // W_1024^k, k = lane + 64 i
+    for (int i = 0; i < 4; ++i) twp[i] = ld2(a.twiddle + cbin + 64 * i);   // W_1024^k, k = cbin + 64 i
 
     // filter groups of this wave: lane = 16 x (filter in group) + frame; group slot i of the wave holds group my_gid[i]
     // (wave-uniform, -1 = none) and this lane's descriptor first bin / 4 | steps << 8 | tap offset << 16 (steps equal
@@ -619,18 +801,18 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
     for (int i = 0; i < NGW; ++i) asm volatile("" ::"s"(my_gid[i]));
 
     float vmax = 0.f;
-    // Software prefetch: the samples of this wave's NEXT frame are requested as soon as pass 1 has left the registers
-    // (they complete under passes 2-3 and the post-processing; across a chunk boundary under the mel stage).  Without
-    // it every workgroup stalls on HBM latency after each barrier: the kernel is latency bound, not VALU bound.
-    v2f zn[8];
-    bool zn_ok = false;                                                  // wave-uniform: zn holds the next frame
-    const int fmul = a.frame_mul;
-    if (KM_MEL_SKIP & 8) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) zn[i] = v2f{0.001f * lane, 0.5f + i};
-        zn_ok = true;
-    } else if (blockIdx.x * FPB + wave < a.n_frames) zn_ok = load_frame_rp_fast<RING>(x, Lv, rs, a.hop, (blockIdx.x * FPB + wave) * fmul, lane, zn);
-    for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    int chunk = bx, chunk_next = bx + (int)gridDim.x;
+#if defined(KM_MEL_DELAY)          /* timing experiment: hold the odd workgroups of a window back by KM_MEL_DELAY x 64 cycles */
+    if (bx & 1) { for (int i = 0; i < KM_MEL_DELAY; i += 16) __builtin_amdgcn_s_sleep(16); }
+#endif
+#ifdef KM_MEL_STAMP
+    unsigned st_acc[16] = {0};
+    unsigned long long st_last = __builtin_readcyclecounter();
+    const unsigned long long st_first = st_last;
+#endif
+    while (chunk < n_chunks) {
+        unsigned req = 0;                                                // the chunk after next: requested here, looked at before the barrier
+        if (tid == 0) req = atomicAdd(a.chunk_ctr + b, 1u);
         const int f0 = chunk * FPB;
 #pragma unroll 1
         for (int pi = 0; pi < FPB / WAVES; ++pi) {
@@ -645,51 +827,64 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
                     for (int i = 0; i < 8; ++i) zn[i] = buf[lane + 64 * i];
                     __builtin_amdgcn_wave_barrier();
                 }
+                KM_STAMP(0);                                              // loop overhead, edge frames, waiting for the samples
                 v2f z[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) z[i] = zn[i] * win2[i];
                 // ---- pass 1: radix-8 over n0 (m = 64 n0 + lane) ----
                 if (!(KM_MEL_SKIP & 4)) { dif8(z); cmul7(z, tw1); }
-                if (!(KM_MEL_SKIP & 2)) {
+                KM_STAMP(1);
+                v2f y[8];
+                if ((KM_MEL_XCHG & 1) && !(KM_MEL_SKIP & 2)) {              // register i (digit k0 = bitrev(i)) <-> lane bits 5:3 (n1)
+                    exchange_hi(z);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) y[i] = z[i];
+                } else if (!(KM_MEL_SKIP & 2)) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) buf[bitrev(i, 3) * 72 + lane] = z[i];
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_wave_barrier();
                 {
-                    const int fnext = pi + 1 < FPB / WAVES ? f + WAVES : (chunk + (int)gridDim.x) * FPB + wave;
+                    const int fnext = pi + 1 < FPB / WAVES ? f + WAVES : chunk_next * FPB + wave;
                     if (!(KM_MEL_SKIP & 8)) zn_ok = fnext < a.n_frames && load_frame_rp_fast<RING>(x, Lv, rs, a.hop, fnext * fmul, lane, zn);
                 }
-                // ---- pass 2: radix-8 over n1 (lane = 8 n1 + n2); this lane: n2 = lane & 7, k0 = lane >> 3 ----
-                v2f y[8];
-                if (!(KM_MEL_SKIP & 2)) lds_read8<64>(rd2, y);            // y[n1] = buf[k0 * 72 + 8 n1 + n2]
-                else {
+                // ---- pass 2: radix-8 over n1 (lane = 8 n1 + n2); this lane: n2 = lane & 7, digit k0 = fft_lane_k0(lane) ----
+                if (!(KM_MEL_XCHG & 1) && !(KM_MEL_SKIP & 2)) {
+                    lds_read8<64>(rd2, y);                                // y[n1] = buf[k0 * 72 + 8 n1 + n2]
+                    __builtin_amdgcn_wave_barrier();
+                } else if (KM_MEL_SKIP & 2) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) y[i] = z[i];
                 }
-                __builtin_amdgcn_wave_barrier();
+                KM_STAMP(2);                                              // exchange 1 (+ issuing the next frame's loads)
                 if (!(KM_MEL_SKIP & 4)) { dif8(y); cmul7(y, tw2); }
-                // transposed image indexed by c = k0 + 8 k1, row stride 9 (padding keeps every address base + immediate;
-                // the residual 2-way conflict on 3 of 32 slots is cheaper than per-access swizzle arithmetic)
-                if (!(KM_MEL_SKIP & 2)) {
+                KM_STAMP(3);
+                // ---- pass 3: radix-8 over n2; afterwards register i holds Z[cbin + 64 bitrev(i)] ----
+                if ((KM_MEL_XCHG & 2) && !(KM_MEL_SKIP & 2)) {              // register i (digit k1 = bitrev(i)) <-> lane bits 2:0 (n2)
+                    exchange_lo(y);
+                } else if (!(KM_MEL_SKIP & 2)) {
+                    // transposed image indexed by c = k0 + 8 k1, row stride 9 (padding keeps every address base + immediate;
+                    // the residual 2-way conflict on 3 of 32 slots is cheaper than per-access swizzle arithmetic)
 #pragma unroll
                     for (int i = 0; i < 8; ++i) buf[(k0 + 8 * bitrev(i, 3)) * 9 + n2] = y[i];
+                    __builtin_amdgcn_wave_barrier();
+                    lds_read8<8>(rd3, y);                                 // y[q] = buf[lane * 9 + q]
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_wave_barrier();
-                // ---- pass 3: radix-8 over n2; this lane: c = lane; output k = c + 64 k2 ----
-                if (!(KM_MEL_SKIP & 2)) lds_read8<8>(rd3, y);             // y[q] = buf[lane * 9 + q]
-                __builtin_amdgcn_wave_barrier();
+                KM_STAMP(4);                                              // exchange 2
                 if (!(KM_MEL_SKIP & 4)) dif8(y);
+                KM_STAMP(5);
                 // ---- real-input post-processing + |.|^2, two bins (k and 512 - k) per packed instruction ----
-                // y[i] = Z[lane + 64 bitrev(i)].  The bins k = lane + 64 i, i = 0..3, this lane finishes are its own registers
-                // 0, 4, 2, 6; their partners Z[512 - k] = Z[(64 - lane) + 64 (7 - i)] are registers 7, 3, 5, 1 of lane
-                // 64 - lane: one fixed lane permutation of four complex registers (8 ds_bpermute_b32, no LDS memory) instead of
-                // a third exchange through the buffer (8 ds_write_b64 + 8 ds_read_b64).  Lane 0 pairs with itself, one
+                // y[i] = Z[c + 64 bitrev(i)], c = cbin.  The bins k = c + 64 i, i = 0..3, this lane finishes are its own registers
+                // 0, 4, 2, 6; their partners Z[512 - k] = Z[(64 - c) + 64 (7 - i)] are registers 7, 3, 5, 1 of the lane that
+                // holds 64 - c: one fixed lane permutation of four complex registers (8 ds_bpermute_b32, no LDS memory) instead of
+                // a third exchange through the buffer (8 ds_write_b64 + 8 ds_read_b64).  c = 0 (lane 0) pairs with itself, one
                 // register further: Z[512 - 64 i] = Z[64 ((8 - i) & 7)] = its registers 0, 7, 3, 5.
                 float* pwr = pw + fl * NFS;
                 v2f zk[4], zc[4];
                 v2f zmid = y[1];                                          // Z[256] in lane 0 (k = 256 pairs with itself)
                 if (!(KM_MEL_SKIP & 2)) {
-                    const int src = ((64 - lane) & 63) << 2;
+                    const int src = fft_bin_lane((64 - cbin) & 63) << 2;
                     auto perm = [&](v2f v) {
                         return v2f{__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.x))),
                                    __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.y)))};
@@ -702,19 +897,27 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { zk[i] = y[i]; zc[i] = y[i + 4]; }
                 }
+                KM_STAMP(6);                                              // partner permutation
                 if (!(KM_MEL_SKIP & 4)) post4(zk, zc, twp);                                       // the 1/4 of |X|^2 lives in the filter weights
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    pwr[lane + 64 * i] = zk[i].x;
-                    pwr[2 * 256 - lane - 64 * i] = zk[i].y;
+                    pwr[cbin + 64 * i] = zk[i].x;
+                    pwr[2 * 256 - cbin - 64 * i] = zk[i].y;
                 }
                 if (lane == 0) pwr[256] = 4.0f * (zmid.x * zmid.x + zmid.y * zmid.y);      // k = 256 pairs with itself
+                KM_STAMP(7);                                              // post-processing + power stores
             }
         }
+        KM_STAMP(8);
         int my_desc[NGW];
 #pragma unroll
         for (int i = 0; i < NGW; ++i) my_desc[i] = my_desc_p[4 * i];
+        if (tid == 0) {
+            if (req == ctr_last) a.chunk_ctr[b] = 0u;
+            sched[0] = (int)(req + 2u * gridDim.x);
+        }
         __syncthreads();
+        KM_STAMP(9);                                                      // waiting at the barrier ahead of the mel stage
         {   // Sparse triangular mel filters.  A lane owns one (frame, filter) pair: lane = 16 x (filter in its group of
             // four) + frame, and walks the filter four bins a step: one ds_read_b128 of powers and one 16-byte load of taps
             // (the 16 frame lanes of a filter share the address; the taps come through the vector cache, not LDS: the
@@ -732,6 +935,39 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
             const float4* wbase = reinterpret_cast<const float4*>(fbw);
             float* dst = a.melpow + ((int64_t)b * a.n_frames + f0 + flm) * a.n_mels + slot;
             float fmx = 0.f;
+#if KM_MEL_FLAT
+            // One chain of steps over all groups of the wave: the operands of a step are requested one step ahead, and the
+            // last step of a group requests the first step of the next group (not, as before, its own operands again:
+            // ~2.5 of a wave's ~14.5 steps per chunk were such re-reads, and every group started with an exposed LDS round trip).
+            auto group_pr = [&](int i) { return prow + (my_desc[i] & 255); };
+            auto group_wt = [&](int i) { return wbase + ((unsigned)my_desc[i] >> 16); };
+            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f), pv = wv;
+            if (!(KM_MEL_SKIP & 1) && my_gid[0] >= 0) { wv = group_wt(0)[0]; pv = group_pr(0)[0]; }
+#pragma unroll
+            for (int i = 0; i < ((KM_MEL_SKIP & 1) ? 0 : NGW); ++i) {
+                if (my_gid[i] < 0) break;                                              // wave-uniform
+                const int steps = __builtin_amdgcn_readfirstlane((my_desc[i] >> 8) & 255);
+                const float4* pr = group_pr(i);
+                const float4* wt = group_wt(i);
+                v2f acc = {0.f, 0.f};
+                for (int t = 1; t < steps; ++t) {
+                    const float4 wn = wt[t], pn = pr[t];
+                    acc = __builtin_elementwise_fma(v2f{pv.x, pv.y}, v2f{wv.x, wv.y}, acc);
+                    acc = __builtin_elementwise_fma(v2f{pv.z, pv.w}, v2f{wv.z, wv.w}, acc);
+                    pv = pn; wv = wn;
+                }
+                float4 wn = wv, pn = pv;
+                if (i + 1 < NGW && my_gid[i + 1 < NGW ? i + 1 : i] >= 0) { wn = group_wt(i + 1 < NGW ? i + 1 : i)[0]; pn = group_pr(i + 1 < NGW ? i + 1 : i)[0]; }
+                acc = __builtin_elementwise_fma(v2f{pv.x, pv.y}, v2f{wv.x, wv.y}, acc);
+                acc = __builtin_elementwise_fma(v2f{pv.z, pv.w}, v2f{wv.z, wv.w}, acc);
+                pv = pn; wv = wn;
+                float r = acc.x + acc.y;
+                r = fvalid ? r : 0.f;
+                asm("v_max_f32 %0, %0, %1" : "+v"(vmax) : "v"(r));
+                asm("v_max_f32 %0, %0, %1" : "+v"(fmx) : "v"(r));
+                if (fvalid && 4 * my_gid[i] + slot < a.n_mels) dst[4 * my_gid[i]] = r;
+            }
+#else
 #pragma unroll
             for (int i = 0; i < ((KM_MEL_SKIP & 1) ? 0 : NGW); ++i) {
                 if (my_gid[i] < 0) break;                                              // wave-uniform
@@ -741,19 +977,21 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
                 const float4* wt = wbase + ((unsigned)desc >> 16);
                 v2f acc = {0.f, 0.f};
                 float4 wv = wt[0], pv = pr[0];
-                for (int t = 0; t < steps; ++t) {                                      // the next step's operands ahead of the FMAs
-                    const int tn = t + 1 < steps ? t + 1 : t;
-                    const float4 wn = wt[tn], pn = pr[tn];
+                for (int t = 1; t < steps; ++t) {                                      // the next step's operands ahead of the FMAs
+                    const float4 wn = wt[t], pn = pr[t];
                     acc = __builtin_elementwise_fma(v2f{pv.x, pv.y}, v2f{wv.x, wv.y}, acc);
                     acc = __builtin_elementwise_fma(v2f{pv.z, pv.w}, v2f{wv.z, wv.w}, acc);
                     pv = pn; wv = wn;
                 }
+                acc = __builtin_elementwise_fma(v2f{pv.x, pv.y}, v2f{wv.x, wv.y}, acc);
+                acc = __builtin_elementwise_fma(v2f{pv.z, pv.w}, v2f{wv.z, wv.w}, acc);
                 float r = acc.x + acc.y;
                 r = fvalid ? r : 0.f;
                 asm("v_max_f32 %0, %0, %1" : "+v"(vmax) : "v"(r));
                 asm("v_max_f32 %0, %0, %1" : "+v"(fmx) : "v"(r));
                 if (fvalid && 4 * my_gid[i] + slot < a.n_mels) dst[4 * my_gid[i]] = r;
             }
+#endif
             if (a.frame_max) {                                             // this wave's filters of frame f0 + flm
                 float fall = fmx;
 #pragma unroll
@@ -762,8 +1000,23 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
                 if (slot == 0 && fvalid) atomicMax(a.frame_max + (int64_t)b * a.n_frames + f0 + flm, __float_as_uint(fmx));
             }
         }
+        KM_STAMP(10);                                                     // mel stage
+        chunk = chunk_next;
+        chunk_next = __builtin_amdgcn_readfirstlane(sched[0]);           // written ahead of the barrier that opened the mel stage
         __syncthreads();                                                 // the power rows are free again
+        KM_STAMP(11);
     }
+#ifdef KM_MEL_STAMP
+    if (lane == 0) {
+        unsigned long long* o = km_mel_stamps + ((size_t)(b * gridDim.x + bx) * WAVES + wave) * 24;
+        if (b * gridDim.x + bx < 1024) {
+            for (int i = 0; i < 12; ++i) o[i] = st_acc[i];
+            o[12] = st_last - st_first;
+            o[13] = st_entry; o[14] = st_first; o[15] = st_last; o[16] = st_entry_rt; o[17] = __builtin_amdgcn_s_memrealtime();
+            o[18] = __builtin_readcyclecounter();
+        }
+    }
+#endif
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
     if (lane == 0) redmax[wave] = vmax;
@@ -866,7 +1119,7 @@ void free_mel_plan(MelPlan* p) {
 }
 
 static size_t melrp_lds_bytes(int nnz4) {
-    return (size_t)(melrp::WAVES * melrp::FFT_BUF * 2 + melrp::FPB * melrp::NFS + melrp::WAVES + nnz4) * sizeof(float);
+    return (size_t)(melrp::WAVES * melrp::FFT_BUF * 2 + melrp::FPB * melrp::NFS + melrp::WAVES + 4 + nnz4) * sizeof(float);
 }
 
 static size_t mel_lds_bytes(int nfft, int n_mels = 128, int nnz = 0) {
@@ -880,6 +1133,24 @@ static LogParams log_params(const km_mel_config& m) {
     lp.log_mode = m.log_mode; lp.amin = m.amin; lp.top_db = m.top_db; lp.db_add = m.db_add;
     lp.db_scale = m.db_scale; lp.log_eps = m.log_eps;
     return lp;
+}
+
+// One chunk-request counter per window of a launch (MelArgs::chunk_ctr).  The kernel leaves them at zero, so the buffer is
+// zeroed once, when it is (re)allocated; km_reserve sizes it, a larger launch grows it (not inside a stream capture).
+int ensure_chunk_counters(Context* c, int64_t windows, void* stream) {
+    if (windows <= c->ws_chunkctr_cap) return KM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(KM_ERR_WORKSPACE, "front end: %lld windows exceed the reserved %lld during a stream capture: call km_reserve first",
+                    (long long)windows, (long long)c->ws_chunkctr_cap);
+    if (c->ws_chunkctr) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(c->ws_chunkctr)); c->ws_chunkctr = nullptr; c->ws_chunkctr_cap = 0; }
+    const int64_t cap_n = windows < 4096 ? 4096 : windows;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->ws_chunkctr), (size_t)cap_n * sizeof(unsigned)));
+    HIP_TRY(hipMemsetAsync(c->ws_chunkctr, 0, (size_t)cap_n * sizeof(unsigned), st));
+    HIP_TRY(hipStreamSynchronize(st));            // the caller's later launches may be on another stream
+    c->ws_chunkctr_cap = cap_n;
+    return KM_OK;
 }
 
 // power-mel (B, n_frames, n_mels) + per-window max into the workspace
@@ -923,6 +1194,7 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     hipStream_t st = (hipStream_t)stream;
+    if (int rc = ensure_chunk_counters(c, B, stream)) return rc;
     // ws_melmax is all-zero on entry unless a previous non-fused call left its maxima behind
     // (the fused core kernel re-zeroes the entry it consumes)
     if (!seq && c->melmax_dirty) {
@@ -938,7 +1210,7 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     a.fb_nnz = (int)p->fb_weight.size();
     a.fbg_gid = p->d_fbg_gid; a.fbg_desc = p->d_fbg_desc; a.fbg_weight = p->d_fbg_weight; a.fbg_nw = (int)p->fbg_weight.size();
     a.melpow = c->ws_melpow; a.melmax = c->ws_melmax;
-    a.frame_mul = 1; a.frame_max = nullptr;
+    a.frame_mul = 1; a.frame_max = nullptr; a.chunk_ctr = c->ws_chunkctr;
     if (seq) { a.melpow = seq->pow; a.frame_max = seq->fmax; a.frame_mul = seq->frame_mul; a.melmax = nullptr; }
     if (emotion) {
         if (!mel_fuses_emotion(c, p) || !zemo || wins_per_clip > 1)
@@ -1042,5 +1314,11 @@ int launch_ring_push(Context* c, const float* samples, int64_t n_per_stream, voi
 }
 
 LogParams plan_log_params(MelPlan* p) { return log_params(p->cfg); }
+
+#ifdef KM_MEL_STAMP
+extern "C" __attribute__((visibility("default"))) int km_debug_mel_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(km_mel_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 
 }  // namespace km
