@@ -512,6 +512,23 @@ __device__ __forceinline__ void lds_read8(unsigned addr, v2f (&y)[8]) {
                  : "v"(addr), "i"(0 * S), "i"(1 * S), "i"(2 * S), "i"(3 * S), "i"(4 * S), "i"(5 * S), "i"(6 * S), "i"(7 * S)
                  : "memory");
 }
+// The matching stores: register i (digit bitrev(i)) goes to base + S * bitrev(i) bytes.  Assembly for the same reason as the
+// reads: the compiler pairs the stores into ds_write2_b64.
+template <int S>
+__device__ __forceinline__ void lds_write8_bitrev(unsigned addr, const v2f (&y)[8]) {
+    asm volatile("ds_write_b64 %8, %0 offset:%9\n\t"
+                 "ds_write_b64 %8, %1 offset:%10\n\t"
+                 "ds_write_b64 %8, %2 offset:%11\n\t"
+                 "ds_write_b64 %8, %3 offset:%12\n\t"
+                 "ds_write_b64 %8, %4 offset:%13\n\t"
+                 "ds_write_b64 %8, %5 offset:%14\n\t"
+                 "ds_write_b64 %8, %6 offset:%15\n\t"
+                 "ds_write_b64 %8, %7 offset:%16"
+                 :
+                 : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(addr),
+                   "i"(0 * S), "i"(4 * S), "i"(2 * S), "i"(6 * S), "i"(1 * S), "i"(5 * S), "i"(3 * S), "i"(7 * S)
+                 : "memory");
+}
 __device__ __forceinline__ v2f ld2(const float2* p) { const float2 t = *p; return v2f{t.x, t.y}; }
 
 // ---- the exchanges between the FFT passes as REGISTER exchanges (KM_MEL_XCHG bit 0: the one after pass 1, bit 1: the one
@@ -533,6 +550,9 @@ __device__ __forceinline__ v2f ld2(const float2* p) { const float2 t = *p; retur
 #endif
 #ifndef KM_MEL_FLAT
 #define KM_MEL_FLAT 0
+#endif
+#ifndef KM_MEL_W2
+#define KM_MEL_W2 0     /* 1: let the compiler pair the exchange stores into ds_write2_b64 */
 #endif
 __device__ __forceinline__ void swap_lane32(v2f& a, v2f& b) {
     const auto r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
@@ -734,6 +754,7 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
     v2f* buf = reinterpret_cast<v2f*>(fbuf + wave * FFT_BUF);
     const int n_chunks = (a.n_frames + FPB - 1) / FPB;
     const unsigned rd2 = lds_offset(buf + (lane >> 3) * 72 + (lane & 7)), rd3 = lds_offset(buf + lane * 9);
+    const unsigned wr3 = lds_offset(buf + fft_lane_k0(lane) * 9 + (lane & 7));
     const int cbin = fft_lane_bin(lane);                       // this lane finishes the bins cbin + 64 i and 512 - cbin - 64 i
 
     // Software prefetch: the samples of this wave's NEXT frame are requested as soon as pass 1 has left the registers
@@ -865,8 +886,12 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
                 } else if (!(KM_MEL_SKIP & 2)) {
                     // transposed image indexed by c = k0 + 8 k1, row stride 9 (padding keeps every address base + immediate;
                     // the residual 2-way conflict on 3 of 32 slots is cheaper than per-access swizzle arithmetic)
+#if KM_MEL_W2
 #pragma unroll
                     for (int i = 0; i < 8; ++i) buf[(k0 + 8 * bitrev(i, 3)) * 9 + n2] = y[i];
+#else
+                    lds_write8_bitrev<8 * 9 * 8>(wr3, y);                 // buf[(k0 + 8 bitrev(i)) * 9 + n2] = y[i]
+#endif
                     __builtin_amdgcn_wave_barrier();
                     lds_read8<8>(rd3, y);                                 // y[q] = buf[lane * 9 + q]
                     __builtin_amdgcn_wave_barrier();
