@@ -211,9 +211,7 @@ def spin_up(rk: Ranks, step, seconds: float = SPINUP_SECONDS) -> int:
     return n + 10
 
 
-def timed(rk: Ranks, step, steps: int, warmup: int, flush=None, spin: bool = True) -> float:
-    """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; MAX over ranks (seconds)."""
-    spin_up(rk, step, 0.0 if (not spin or os.environ.get("KM_BENCH_NO_SPINUP")) else SPINUP_SECONDS)
+def _timed_once(rk: Ranks, step, steps: int, warmup: int, flush=None) -> float:
     for _ in range(warmup):
         step()
     if flush:
@@ -226,6 +224,73 @@ def timed(rk: Ranks, step, steps: int, warmup: int, flush=None, spin: bool = Tru
         flush()
     rk.sync()
     return rk.max_over_ranks(time.perf_counter() - t0)
+
+
+def timed(rk: Ranks, step, steps: int, warmup: int, flush=None, spin: bool = True) -> float:
+    """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; MAX over ranks (seconds).
+    The workload's FIRST measurement is taken twice: once exactly as the command line says (W warmup steps on a chip that
+    has done nothing yet -> rk.no_spinup_ms, printed as ``ms_per_step_no_spinup``), then again behind SPINUP_SECONDS of
+    untimed load (the steady-state figure every line reports as ``ms_per_step`` / ``value``)."""
+    use_spin = spin and not os.environ.get("KM_BENCH_NO_SPINUP")
+    if use_spin and getattr(rk, "no_spinup_ms", None) is None:
+        rk.no_spinup_ms = _timed_once(rk, step, steps, warmup, flush) / steps * 1e3
+    spin_up(rk, step, SPINUP_SECONDS if use_spin else 0.0)
+    return _timed_once(rk, step, steps, warmup, flush)
+
+
+GRAD_BUCKET_FLOATS = 837744        # flat gradient bucket of the d_model 256 / window 256 model (km_train_num_params)
+
+
+def measure_collective(args, rk: Ranks, steps: int = 50):
+    """The training step's ONE collective, measured in the same run as the headline (the driver's --gpus N command runs
+    the C2 workload, which has none): the C3 step (8 windows per rank, dropout 0.1, clip, AdamW) and the bare all-reduce of
+    its flat gradient bucket, in both modes of koemorph_amd.parallel -- ``ring`` = one dist.all_reduce per bucket piece
+    (the default; RCCL picks the algorithm), ``direct`` = all-to-all + local sum + all-gather (opt-in, world > 2).
+    Without a GPU (rendezvous workload) only the bare all-reduce of a bucket-sized CPU tensor is timed."""
+    torch = rk.torch
+    from koemorph_amd import parallel
+    out = {"ranks": rk.world, "floats": GRAD_BUCKET_FLOATS, "bytes": 4 * GRAD_BUCKET_FLOATS, "default": parallel.allreduce_mode(),
+           "backend": "RCCL" if rk.backend == "nccl" else rk.backend, "steps": steps}
+    keep = os.environ.get("KM_ALLREDUCE")
+    tr = None
+    if rk.use_gpu:
+        from koemorph_amd import synth
+        from koemorph_amd.engine import Engine
+        from koemorph_amd.training import Trainer
+        B, L = 8, 136448
+        eng = Engine()
+        eng.load_state_dict(synth.make_core_params(0))
+        eng.finalize(rk.dev)
+        tr = Trainer(eng, max_windows=B, dropout=0.1, seed=rk.rank)
+        audio = torch.from_numpy(synth.make_audio(10 + rk.rank, B, L, "uniform")).to(rk.dev)
+        emo = torch.from_numpy(synth.normal(20 + rk.rank, (B, 256))).to(rk.dev)
+        target = torch.from_numpy(synth.uniform(30 + rk.rank, (B, 52), 0, 1)).to(rk.dev)
+        bucket = torch.zeros(tr.n_params, device=rk.dev) if rk.backend == "nccl" else torch.zeros(tr.n_params)
+        out["floats"], out["bytes"] = tr.n_params, 4 * tr.n_params
+    else:
+        bucket = torch.zeros(GRAD_BUCKET_FLOATS)
+    try:
+        for mode in ("ring", "direct"):
+            os.environ["KM_ALLREDUCE"] = mode
+            res = {}
+            if tr is not None:
+                dt = timed(rk, lambda: tr.step(audio, emo, target), steps, 5, spin=False)
+                res["ms_per_step"] = round(dt / steps * 1e3, 4)
+            bucket.fill_(float(rk.rank + 1))
+            parallel.allreduce_gradients(bucket, average=False)
+            res["sum_check"] = bool(abs(float(bucket[0]) - rk.world * (rk.world + 1) / 2) < 1e-3 and
+                                    abs(float(bucket[-1]) - rk.world * (rk.world + 1) / 2) < 1e-3)
+            dt = timed(rk, lambda: parallel.allreduce_gradients(bucket, average=False), steps, 5, spin=False)
+            res["allreduce_ms"] = round(dt / steps * 1e3, 4)
+            if mode == "direct" and rk.world <= 2:
+                res["note"] = "world <= 2: the direct form is the library all-reduce"
+            out[mode] = res
+    finally:
+        if keep is None:
+            os.environ.pop("KM_ALLREDUCE", None)
+        else:
+            os.environ["KM_ALLREDUCE"] = keep
+    return out
 
 
 def load_json(*parts):
@@ -352,6 +417,8 @@ def run_c2(args, rk: Ranks):
         "roofline": roofline, "roofline_other_kernel": other, "step_roofline": step_roof, "kernel_ms": stage_ms,
         "cpu_baseline": cpu, "experimental_split_bf16": split,
     }
+    if rk.world > 1:
+        line["collective"] = measure_collective(args, rk)
     return line
 
 
@@ -495,6 +562,98 @@ def cpu_baseline_c2(args, params, audio_np, emo_np, eng, audio, emo):
             "max_abs_diff_vs_gpu": float(np.abs(chk - ref).max())}
 
 
+def _cpu_rate(fn, units_per_call: int, budget: float, max_calls: int = 200):
+    """(units/s, units done, seconds) of repeated fn() within a time budget (one untimed call first)."""
+    fn()
+    done, t, calls = 0, 0.0, 0
+    while t < budget and calls < max_calls:
+        t0 = time.perf_counter()
+        fn()
+        t += time.perf_counter() - t0
+        done += units_per_call
+        calls += 1
+    return done / t, done, t
+
+
+def _cpu_front_range_cfg(r):
+    """Pool worker: windows r[0] .. r[1] - 1 of the numpy front end at hop r[2] (C4: 266)."""
+    from oracle import mel as omel
+    return [omel.mel_batch_window(_CPU_POOL_AUDIO[i], sample_rate=16000, n_fft=1024, hop=r[2]) for i in range(r[0], r[1])]
+
+
+def cpu_baseline_c3(args, params, audio_np, emo_np, target_np, dropout: float):
+    """BASELINE.md section 3, training: ONE optimizer step of the restated path at B = 8 on all usable host cores -- numpy
+    front end (one window per call, as the reference's extract_mel_features loops), torch-CPU core forward in training
+    mode (dropout), MSE, autograd backward, clip_grad_norm_(1.0), torch.optim.AdamW: what src/train_sequential.py:158-181
+    does per batch.  Bounded by --cpu-seconds."""
+    import numpy as np
+    import torch
+    from oracle import core as ocore, mel as omel
+    n_all = usable_cpus()
+    torch.set_num_threads(n_all)
+    B = audio_np.shape[0]
+    P = {k: torch.from_numpy(np.ascontiguousarray(v)).clone().requires_grad_(True) for k, v in params.items() if k != "smoothing_alpha"}
+    opt = torch.optim.AdamW(list(P.values()), lr=1e-4, weight_decay=1e-5, betas=(0.9, 0.999))
+    tgt = torch.from_numpy(target_np)
+
+    def step():
+        long, short = omel.mel_batch(audio_np, sample_rate=16000, n_fft=1024, hop=533)
+        out = ocore.core_forward(P, long, short, emo_np, dropout_p=dropout)["blendshapes"]
+        loss = torch.nn.functional.mse_loss(out, tgt)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(P.values()), 1.0)
+        opt.step()
+        return float(loss.detach())
+
+    r = _cpu_rate(step, B, min(args.cpu_seconds, 12.0), max_calls=100)
+    return {"value": round(r[0], 2), "unit": "windows/s", "cores": n_all, "kind": "port",
+            "sample": f"{r[1] // B} optimizer steps of {B} windows x 136448 samples in {r[2]:.1f} s: numpy front end (float64 STFT, one window per "
+                      f"call) + torch-CPU fp32 core in training mode (dropout {dropout}) + autograd backward + clip + torch.optim.AdamW, "
+                      f"torch on {n_all} threads",
+            "ms_per_step": round(B / r[0] * 1e3, 2)}
+
+
+def cpu_baseline_c4(args, params, audio_np, emo_np, heads: int):
+    """BASELINE.md section 3, C4 inputs: 64 windows x 136 192 samples at hop 266, window 512, d_model 512, on all usable
+    host cores (front end dealt to a process pool, torch-CPU core) -- front end / core / end to end.  Bounded."""
+    import multiprocessing as mp
+    import numpy as np
+    import torch
+    from oracle import core as ocore, mel as omel
+    n_all = usable_cpus()
+    nb = min(64, audio_np.shape[0])
+    a_s, e_s = np.ascontiguousarray(audio_np[:nb]), emo_np[:nb]
+    torch.set_num_threads(n_all)
+    budget = args.cpu_seconds / 3
+    pool = mp.get_context("spawn").Pool(n_all, initializer=_cpu_pool_init, initargs=(a_s,)) if n_all > 1 else None
+
+    def front():
+        if pool is None:
+            return omel.mel_batch(a_s, sample_rate=16000, n_fft=1024, hop=266)
+        per = -(-nb // n_all)
+        res = sum(pool.map(_cpu_front_range_cfg, [(i, min(i + per, nb), 266) for i in range(0, nb, per)], chunksize=1), [])
+        return (np.stack([r[0] for r in res]).astype(np.float32), np.stack([r[1] for r in res]).astype(np.float32))
+
+    def core(lg, sh):
+        return ocore.core_forward_np(params, lg, sh, e_s, num_heads=heads, mel_sequence_length=512)["blendshapes"]
+
+    long, short = front()
+    r_front = _cpu_rate(front, nb, budget)
+    r_core = _cpu_rate(lambda: core(long, short), nb, budget)
+    ref = core(long, short)
+    r_e2e = _cpu_rate(lambda: core(*front()), nb, budget)
+    if pool is not None:
+        pool.close()
+        pool.join()
+    return {"value": round(r_e2e[0], 2), "unit": "frames/s", "cores": n_all, "kind": "port",
+            "sample": f"{nb} windows of 136192 samples per pass (hop 266, 513 frames, window 512, d_model 512, {heads} heads), 3 legs of <= "
+                      f"{budget:.1f} s: {r_front[1] + r_core[1] + r_e2e[1]} frame-passes in {r_front[2] + r_core[2] + r_e2e[2]:.1f} s of CPU work; numpy "
+                      f"front end dealt to a {n_all}-process pool, torch-CPU fp32 core on {n_all} threads",
+            "breakdown": {"front_end_frames_per_s": round(r_front[0], 2), "core_frames_per_s": round(r_core[0], 2),
+                          "end_to_end_frames_per_s": round(r_e2e[0], 2), "rtf_60fps": round(60.0 / r_e2e[0], 5)}}, ref
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # C3: the training step (forward, loss, backward, ONE gradient all-reduce over RCCL, clip, AdamW)
 # ---------------------------------------------------------------------------------------------------------------------
@@ -512,9 +671,11 @@ def run_c3(args, rk: Ranks):
     if "dropout" in Trainer.__init__.__code__.co_varnames:
         kw["dropout"] = args.dropout
     tr = Trainer(eng, max_windows=B, **kw)
-    audio = torch.from_numpy(synth.make_audio(10 + rk.rank, B, L, "uniform")).to(rk.dev)
-    emo = torch.from_numpy(synth.normal(20 + rk.rank, (B, 256))).to(rk.dev)
-    target = torch.from_numpy(synth.uniform(30 + rk.rank, (B, 52), 0, 1)).to(rk.dev)
+    params = synth.make_core_params(0)
+    audio_np, emo_np, target_np = synth.make_audio(10 + rk.rank, B, L, "uniform"), synth.normal(20 + rk.rank, (B, 256)), synth.uniform(30 + rk.rank, (B, 52), 0, 1)
+    audio = torch.from_numpy(audio_np).to(rk.dev)
+    emo = torch.from_numpy(emo_np).to(rk.dev)
+    target = torch.from_numpy(target_np).to(rk.dev)
     if args.graph:
         for _ in range(3):
             tr.step(audio, emo, target)
@@ -525,6 +686,10 @@ def run_c3(args, rk: Ranks):
     ms = dt / args.steps * 1e3
     value = B * rk.world * args.steps / dt
     tf = TRAIN_FLOPS_PER_WINDOW * B / (ms * 1e-3) / 1e12
+    final_loss = float(tr.loss.item())
+    cpu = None
+    if rk.rank == 0 and rk.world == 1 and args.cpu_seconds > 0:
+        cpu = cpu_baseline_c3(args, params, audio_np, emo_np, target_np, kw.get("dropout", 0.0))
     return {
         "metric": "training windows/sec (train_sequential step, window 256, d_model=256)", "value": round(value, 1),
         "unit": "windows/s", "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
@@ -537,7 +702,7 @@ def run_c3(args, rk: Ranks):
         "roofline": {"kernel": "whole step (launch-bound at this batch)", "bound": "mfma", "achieved": round(tf, 3),
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 5), "traffic": None,
                      "flops_per_window": TRAIN_FLOPS_PER_WINDOW},
-        "cpu_baseline": None, "final_loss": float(tr.loss.item()),
+        "cpu_baseline": cpu, "final_loss": final_loss,
     }
 
 
@@ -554,10 +719,18 @@ def run_c4(args, rk: Ranks):
     eng.load_state_dict(synth.make_core_params(0, 512, 512, 256, "init"))
     eng.finalize(rk.dev)
     eng.reserve(B, L)
-    audio = torch.from_numpy(synth.make_audio(1 + rk.rank, B, L, "uniform")).to(rk.dev)
-    emo = torch.from_numpy(synth.normal(2 + rk.rank, (B, 256))).to(rk.dev)
+    params = synth.make_core_params(0, 512, 512, 256, "init")
+    audio_np, emo_np = synth.make_audio(1 + rk.rank, B, L, "uniform"), synth.normal(2 + rk.rank, (B, 256))
+    audio = torch.from_numpy(audio_np).to(rk.dev)
+    emo = torch.from_numpy(emo_np).to(rk.dev)
     out = torch.empty(B, 52, device=rk.dev)
     dt = timed(rk, lambda: eng.forward_audio(audio, emo, out=out), args.steps, args.warmup)
+    cpu = None
+    if rk.rank == 0 and rk.world == 1 and args.cpu_seconds > 0:
+        import numpy as np
+        cpu, ref = cpu_baseline_c4(args, params, audio_np, emo_np, H)
+        got = eng.forward_audio(audio[:ref.shape[0]], emo[:ref.shape[0]]).cpu().numpy()
+        cpu["max_abs_diff_vs_gpu"] = float(np.abs(got - ref).max())
     ms = dt / args.steps * 1e3
     value = B * rk.world * args.steps / dt
     exe = executed_flops_per_frame_c4(H) * B / (ms * 1e-3) / 1e12
@@ -576,7 +749,7 @@ def run_c4(args, rk: Ranks):
                      "traffic": None, "executed_flops_per_window": executed_flops_per_frame_c4(H),
                      "note": "MFMA FLOPs the three core kernels issue (bench.py header) over the WHOLE step incl. the VALU front end; "
                              "per kernel: profiles/r02_c4_kernel_stats.txt, r02_c4_harness.txt"},
-        "cpu_baseline": None,
+        "cpu_baseline": cpu,
     }
 
 
@@ -642,7 +815,8 @@ def run_rendezvous(args, rk: Ranks):
     return {"metric": "launcher rehearsal (no compute)", "value": round(rk.world * args.steps / dt, 3), "unit": "steps/s",
             "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
-            "rccl_ranks": rk.rccl_ranks, "config": {"workload": "rendezvous"}, "roofline": None, "cpu_baseline": None}
+            "rccl_ranks": rk.rccl_ranks, "config": {"workload": "rendezvous"}, "roofline": None, "cpu_baseline": None,
+            "collective": measure_collective(args, rk, steps=3) if rk.world > 1 else None}
 
 
 def main():
@@ -660,6 +834,8 @@ def main():
     line = {"c2": run_c2, "c3": run_c3, "c4": run_c4, "c5": run_c5, "rendezvous": run_rendezvous}[args.workload](args, rk)
     if args.workload != "rendezvous":      # disclosed: untimed sustained load ahead of the W warmup steps (see SPINUP_SECONDS)
         line["spinup_s"] = 0.0 if os.environ.get("KM_BENCH_NO_SPINUP") else SPINUP_SECONDS
+        # the same K steps behind the W warmup steps alone (the command line's literal protocol, on the clock ramp)
+        line["ms_per_step_no_spinup"] = None if getattr(rk, "no_spinup_ms", None) is None else round(rk.no_spinup_ms, 4)
     if rk.rank == 0:
         print(json.dumps(line), flush=True)
     rk.finish()

@@ -279,6 +279,10 @@ int km_audio_energy(const float* features_dev, int64_t B, int64_t T, int64_t D, 
  *                               oracle.core.core_forward(drop_masks=...)
  *   km_train_set_dropout_masks  the reverse (host -> device) */
 int km_train_set_dropout(km_handle h, float p, uint64_t seed, int32_t external_masks);
+/* The device-side step counter of the mask generator (part of a training checkpoint: a resumed run draws the masks the
+ * uninterrupted run would have drawn). */
+int km_train_get_dropout_step(km_handle h, int64_t* step);
+int km_train_set_dropout_step(km_handle h, int64_t step);
 
 /* Overlapping the data-parallel gradient all-reduce with the end of the backward pass (new construction: the reference is
  * single-process).  The flat bucket is laid out so that the tensors the backward pass finishes last come last:

@@ -103,6 +103,8 @@ SIGNATURES = {
     "km_train_set_loss": (C.c_int, [_h, C.POINTER(KMLossConfig)]),
     "km_audio_energy": (C.c_int, [_p, _i64, _i64, _i64, _p, _p]),
     "km_train_set_dropout": (C.c_int, [_h, C.c_float, C.c_uint64, _i32]),
+    "km_train_get_dropout_step": (C.c_int, [_h, C.POINTER(_i64)]),
+    "km_train_set_dropout_step": (C.c_int, [_h, _i64]),
     "km_train_grad_split": (C.c_int, [_h, C.POINTER(_i64)]),
     "km_train_wait_early": (C.c_int, [_h, _p]),
     "km_train_get_dropout_masks": (C.c_int, [_h, _i64, _p, _p, _p, _p]),

@@ -392,6 +392,28 @@ int km_train_set_dropout(km_handle h, float p, uint64_t seed, int32_t external_m
     return KM_OK;
 }
 
+int km_train_get_dropout_step(km_handle h, int64_t* step) {
+    if (int rc = need_train(h, 1)) return rc;
+    if (!step) return fail(KM_ERR_INVALID_ARG, "km_train_get_dropout_step: NULL argument");
+    int v = 0;
+    if (h->trp_drop_ctr) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(&v, h->trp_drop_ctr, sizeof(int), hipMemcpyDeviceToHost));
+    }
+    *step = v;
+    return KM_OK;
+}
+
+int km_train_set_dropout_step(km_handle h, int64_t step) {
+    if (int rc = need_train(h, 1)) return rc;
+    if (step < 0 || step > 0x7fffffff) return fail(KM_ERR_INVALID_ARG, "km_train_set_dropout_step: step out of range");
+    if (!h->trp_drop_ctr) return fail(KM_ERR_NOT_READY, "km_train_set_dropout_step: the phased training step is not initialised");
+    const int v = (int)step;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h->trp_drop_ctr, &v, sizeof(int), hipMemcpyHostToDevice));
+    return KM_OK;
+}
+
 int km_train_get_dropout_masks(km_handle h, int64_t B, uint8_t* mel_host, uint8_t* emo_host, uint8_t* dec_host, void* stream) {
     if (int rc = need_train(h, B)) return rc;
     if (!mel_host || !emo_host || !dec_host) return fail(KM_ERR_INVALID_ARG, "km_train_get_dropout_masks: NULL argument");

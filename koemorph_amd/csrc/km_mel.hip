@@ -1220,8 +1220,10 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     }
     hipStream_t st = (hipStream_t)stream;
     if (int rc = ensure_chunk_counters(c, B, stream)) return rc;
-    // ws_melmax is all-zero on entry unless a previous non-fused call left its maxima behind
-    // (the fused core kernel re-zeroes the entry it consumes)
+    // ws_melmax is all-zero on entry: the fused core, the generic encoder and phase 1 of the training program re-zero the
+    // entries they consume, and the stand-alone log kernels below are followed by a memset of theirs -- so a step recorded
+    // into a hipGraph needs no memset node and stays correct whatever ran between two replays.  The flag only covers a
+    // freshly (re)allocated workspace.
     if (!seq && c->melmax_dirty) {
         HIP_TRY(hipMemsetAsync(c->ws_melmax, 0, (size_t)c->ws_windows * sizeof(unsigned), st));
         c->melmax_dirty = false;
@@ -1274,13 +1276,13 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
 int launch_mel_packed(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, float* xp, int T, int KP, void* stream) {
     if (int rc = launch_mel_power(c, p, audio, B, L, stream)) return rc;
     const km_mel_config& m = p->cfg;
-    c->melmax_dirty = true;
     LogArgs g;
     g.melpow = c->ws_melpow; g.melmax = c->ws_melmax; g.n_frames = (int)(1 + L / m.hop_length);
     g.out_frames = g.n_frames; g.n_mels = m.n_mels; g.lp = log_params(m); g.mel_long = nullptr; g.mel_short = nullptr;
     const dim3 grid((unsigned)((KP * m.n_mels + 255) / 256), (unsigned)B);
     hipLaunchKernelGGL(mel_log_packed_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, xp, T, KP);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(c->ws_melmax, 0, (size_t)B * sizeof(unsigned), (hipStream_t)stream));   // leave the maxima as found
     return KM_OK;
 }
 
@@ -1290,7 +1292,6 @@ int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L,
     if (int rc = launch_mel_power(c, p, audio, B, L, stream, clip_len, win_step, win0, wins_per_clip)) return rc;
     const km_mel_config& m = p->cfg;
     const int64_t n_frames = 1 + L / m.hop_length;
-    c->melmax_dirty = true;     // mel_log_kernel leaves the maxima in place
     LogArgs g;
     g.melpow = c->ws_melpow; g.melmax = c->ws_melmax; g.n_frames = (int)n_frames;
     g.out_frames = (int)(out_frames > 0 ? out_frames : n_frames); g.n_mels = m.n_mels; g.lp = log_params(m);
@@ -1300,6 +1301,7 @@ int launch_mel(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L,
         hipLaunchKernelGGL(mel_log_kernel, grid2, dim3(256), 0, (hipStream_t)stream, g);
         HIP_TRY(hipGetLastError());
     }
+    HIP_TRY(hipMemsetAsync(c->ws_melmax, 0, (size_t)B * sizeof(unsigned), (hipStream_t)stream));       // leave the maxima as found
     return KM_OK;
 }
 

@@ -76,32 +76,60 @@ def sharded_apply(fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], audi
     return torch.cat([p[: h - l] for p, (l, h) in zip(parts, sizes)], dim=0)
 
 
-def allreduce_sum_direct(t: torch.Tensor) -> torch.Tensor:
-    """Sum of a flat fp32 tensor over the ranks, in place, as ONE exchange over every link at once.
+class DirectAllReduce:
+    """Sum of a flat fp32 tensor over the ranks as ONE exchange over every link at once (opt-in: KM_ALLREDUCE=direct).
 
     xGMI on an MI355X node is point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce of this 3.35 MB bucket is
-    2 (N - 1) latency-bound hops over one link at a time.  Direct form: all-to-all (rank j receives everyone's copy of
-    shard j, one shard per link), a local sum of the N copies in rank order, all-gather of the summed shards (again one
-    shard per link): two hops regardless of N, every link busy, and every rank ends with bit-identical values."""
-    world = dist.get_world_size()
-    n = t.numel()
-    shard = (n + world - 1) // world
-    shard = (shard + 3) // 4 * 4
-    send = torch.zeros(world * shard, dtype=t.dtype, device=t.device)
-    send[:n] = t
-    recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send)
-    mine = recv[:shard].clone()
-    for j in range(1, world):                         # fixed order
-        mine += recv[j * shard:(j + 1) * shard]
-    dist.all_gather_into_tensor(send, mine)
-    t.copy_(send[:n])
-    return t
+    2 (N - 1) hops over one link at a time.  Direct form: all-to-all (rank j receives everyone's copy of shard j, one
+    shard per link), a local sum of the N copies in rank order, all-gather of the summed shards (again one shard per
+    link): two hops regardless of N, every link busy, and every rank ends with bit-identical values.  The three staging
+    buffers are allocated once per (size, world) -- nothing is allocated in a training step.
+
+    Status: correct under gloo (tests/test_parallel_gloo.py); NOT the default -- RCCL's own small-message all-reduce is
+    what the training step uses (``dist.all_reduce``) until a hardware A/B on an 8-GPU node says otherwise; bench.py
+    --gpus N reports both in its ``collective`` object."""
+
+    def __init__(self, numel: int, world: int, device, dtype=torch.float32):
+        shard = (numel + world - 1) // world
+        self.shard = (shard + 3) // 4 * 4
+        self.numel, self.world = numel, world
+        self.send = torch.zeros(world * self.shard, dtype=dtype, device=device)      # the tail beyond numel stays zero
+        self.recv = torch.empty_like(self.send)
+        self.mine = torch.empty(self.shard, dtype=dtype, device=device)
+
+    def __call__(self, t: torch.Tensor) -> torch.Tensor:
+        n, shard = self.numel, self.shard
+        assert t.numel() == n and dist.get_world_size() == self.world
+        self.send[:n].copy_(t.reshape(-1))
+        dist.all_to_all_single(self.recv, self.send)
+        self.mine.copy_(self.recv[:shard])
+        for j in range(1, self.world):                  # fixed order
+            self.mine.add_(self.recv[j * shard:(j + 1) * shard])
+        dist.all_gather_into_tensor(self.recv, self.mine)
+        t.reshape(-1).copy_(self.recv[:n])
+        return t
+
+
+_direct_cache = {}
+
+
+def allreduce_sum_direct(t: torch.Tensor) -> torch.Tensor:
+    """``DirectAllReduce`` with buffers cached per (size, world, device): in-place sum of ``t`` over the ranks."""
+    key = (t.numel(), dist.get_world_size(), str(t.device), t.dtype)
+    ar = _direct_cache.get(key)
+    if ar is None:
+        ar = _direct_cache[key] = DirectAllReduce(t.numel(), dist.get_world_size(), t.device, t.dtype)
+    return ar(t)
+
+
+def allreduce_mode() -> str:
+    """``ring`` (default) = one ``dist.all_reduce`` per bucket piece: the collective the north star names, on RCCL's own
+    algorithm choice; ``direct`` (KM_ALLREDUCE=direct, world > 2) = DirectAllReduce."""
+    return os.environ.get("KM_ALLREDUCE", "ring")
 
 
 def _sum_over_ranks(t: torch.Tensor) -> None:
-    mode = os.environ.get("KM_ALLREDUCE", "direct" if dist.get_backend() == "nccl" else "ring")
-    if mode == "direct" and dist.get_world_size() > 2:
+    if allreduce_mode() == "direct" and dist.get_world_size() > 2:
         allreduce_sum_direct(t)
     else:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

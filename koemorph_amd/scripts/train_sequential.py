@@ -37,14 +37,19 @@ class SequentialTrainer:
     def __init__(self, engine: Engine, train_data: SequentialKoeMorphDataset, val_data: Optional[SequentialKoeMorphDataset] = None,
                  device: str = "cuda", learning_rate: float = 1e-4, weight_decay: float = 1e-5, gradient_clip: float = 1.0,
                  mse_weight: float = 1.0, l1_weight: float = 0.0, extra_loss_terms: Optional[Dict[str, float]] = None,
-                 emotion_provider: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
+                 emotion_provider: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, dropout: float = 0.1, seed: int = 0):
+        """``dropout``: the reference trains under ``model.train()`` (src/train_sequential.py:118) on a model built with
+        dropout 0.1 (simplified_dual_stream_model.py:155): the attention weights of both streams and the decoder's hidden
+        layer are dropped per step; ``validate()`` runs the eval-mode inference kernels.  Every rank draws its own masks
+        (generator seed = ``seed`` + rank); the generator's step counter is part of the checkpoint."""
         self.engine, self.device = engine, torch.device(device)
         self.train_data, self.val_data = train_data, val_data
         self.emotion_provider = emotion_provider
         self.rank, self.world = (torch.distributed.get_rank(), torch.distributed.get_world_size()) \
             if torch.distributed.is_initialized() else (0, 1)
         self.trainer = Trainer(engine, max_windows=train_data.batch_size, lr=learning_rate, weight_decay=weight_decay,
-                               grad_clip=gradient_clip, mse_weight=mse_weight, l1_weight=l1_weight, use_smoothing=True)
+                               grad_clip=gradient_clip, mse_weight=mse_weight, l1_weight=l1_weight, use_smoothing=True,
+                               dropout=dropout, seed=seed + self.rank)
         if extra_loss_terms:
             self.trainer.set_loss_terms(**extra_loss_terms)
         self.epoch = 0
@@ -154,6 +159,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--weight_decay", type=float, default=1e-5)
     p.add_argument("--gradient_clip", type=float, default=1.0)
     p.add_argument("--l1_weight", type=float, default=0.0)
+    p.add_argument("--dropout", type=float, default=0.1, help="train-mode dropout probability (the reference's model: 0.1; 0 = eval-mode arithmetic)")
+    p.add_argument("--seed", type=int, default=0, help="dropout generator seed (rank r uses seed + r)")
     p.add_argument("--checkpoint_dir", default="checkpoints")
     p.add_argument("--resume", help="checkpoint to resume from")
     p.add_argument("--max_files", type=int)
@@ -174,7 +181,7 @@ def main(argv=None):
     train = SequentialKoeMorphDataset(args.data_dir, **kw)
     val = SequentialKoeMorphDataset(args.val_dir, **kw) if args.val_dir else None
     st = SequentialTrainer(eng, train, val, device=device, learning_rate=args.learning_rate, weight_decay=args.weight_decay,
-                           gradient_clip=args.gradient_clip, l1_weight=args.l1_weight)
+                           gradient_clip=args.gradient_clip, l1_weight=args.l1_weight, dropout=args.dropout, seed=args.seed)
     if args.resume:
         st.load_checkpoint(args.resume)
     for _ in range(st.epoch, args.epochs):

@@ -95,23 +95,47 @@ class Trainer:
             flat[off:off + a.size] = a
         check(self._lib.km_train_set_params(self._h, flat.ctypes.data, self.n_params))
 
+    def _param_table(self):
+        """(key, offset, size) of every trainable tensor in the flat bucket (whose order is an implementation detail of
+        the library: tensors the backward pass finishes last come last)."""
+        shapes = {k: tuple(v.shape) for k, v in self.engine.state_dict_shapes().items()}
+        return [(k, self.offset(k), int(np.prod(s, dtype=np.int64)) if len(s) else 1) for k, s in shapes.items()]
+
     def optimizer_state(self) -> Dict[str, object]:
-        """AdamW moments + step counters (host copies) for a checkpoint."""
+        """AdamW moments PER STATE-DICT KEY + step counters (host copies) for a checkpoint.  Keyed, not flat: the order of
+        the tensors inside the library's bucket may change between versions, a checkpoint must not depend on it."""
         m, v = np.empty(self.n_params, np.float32), np.empty(self.n_params, np.float32)
         steps = np.zeros(2, np.int32)
         check(self._lib.km_train_get_optimizer_state(self._h, m.ctypes.data, v.ctypes.data, self.n_params, steps.ctypes.data))
-        return {"exp_avg": torch.from_numpy(m), "exp_avg_sq": torch.from_numpy(v), "steps": torch.from_numpy(steps),
-                "step_count": self.step_count, "epoch": self.epoch, "ema_state": self.ema_state.cpu(),
-                "ema_batch": -1 if self._ema_batch is None else int(self._ema_batch)}
+        import ctypes
+        drop_step = ctypes.c_int64(0)
+        check(self._lib.km_train_get_dropout_step(self._h, ctypes.byref(drop_step)))
+        tab = self._param_table()
+        return {"layout": "per-key-v1",
+                "exp_avg": {k: torch.from_numpy(m[o:o + n].copy()) for k, o, n in tab},
+                "exp_avg_sq": {k: torch.from_numpy(v[o:o + n].copy()) for k, o, n in tab},
+                "steps": torch.from_numpy(steps), "step_count": self.step_count, "epoch": self.epoch,
+                "ema_state": self.ema_state.cpu(), "ema_batch": -1 if self._ema_batch is None else int(self._ema_batch),
+                "dropout_step": int(drop_step.value)}
 
     def load_optimizer_state(self, st: Dict[str, object]) -> None:
-        m = np.ascontiguousarray(st["exp_avg"].numpy(), np.float32); v = np.ascontiguousarray(st["exp_avg_sq"].numpy(), np.float32)
+        if st.get("layout") != "per-key-v1":
+            raise ValueError("optimizer state without a per-key layout (written before the bucket was reordered): the flat "
+                             "moments cannot be assigned to tensors safely -- resume from the model weights only")
+        m, v = np.zeros(self.n_params, np.float32), np.zeros(self.n_params, np.float32)
+        for k, o, n in self._param_table():
+            a, b = st["exp_avg"][k].numpy().ravel(), st["exp_avg_sq"][k].numpy().ravel()
+            if a.size != n or b.size != n:
+                raise ValueError(f"optimizer state of {k}: {a.size} values, the model has {n}")
+            m[o:o + n] = a; v[o:o + n] = b
         steps = np.ascontiguousarray(st["steps"].numpy(), np.int32)
         check(self._lib.km_train_set_optimizer_state(self._h, m.ctypes.data, v.ctypes.data, self.n_params, steps.ctypes.data))
         self.step_count = int(st["step_count"]); self.epoch = int(st["epoch"])
         self.lr = cosine_warm_restarts_lr(self.epoch, self.base_lr)
         self.ema_state.copy_(st["ema_state"].to(self.device))
         self._ema_batch = None if int(st["ema_batch"]) < 0 else int(st["ema_batch"])
+        if "dropout_step" in st:
+            check(self._lib.km_train_set_dropout_step(self._h, int(st["dropout_step"])))
 
     def reset_temporal_state(self):
         self._ema_batch = None
@@ -266,13 +290,17 @@ class Trainer:
         with torch.cuda.graph(g):
             self.forward_backward(self._g_audio, self._g_emo, self._g_target)
         self._graph = g
+        # The "early" event of the step was recorded on a CAPTURING stream: it is a graph node, not an event a side stream
+        # can wait on.  Replayed steps therefore reduce the bucket on the launch stream (two pieces, no overlap).
+        self._last_was_step = False
 
-    def step_graph(self, audio, emotion, target) -> torch.Tensor:
+    def step_graph(self, audio, emotion, target, weight: Optional[float] = None) -> torch.Tensor:
         self._g_audio.copy_(audio, non_blocking=True)
         self._g_emo.copy_(emotion, non_blocking=True)
         self._g_target.copy_(target, non_blocking=True)
         self._graph.replay()
-        self.optimizer_step()
+        self._last_was_step = False      # see capture(): no side-stream overlap behind a replay
+        self.optimizer_step(weight)
         return self.loss
 
     def end_epoch(self):

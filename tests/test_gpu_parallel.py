@@ -103,6 +103,49 @@ def test_two_rank_training_with_unequal_shares(n_global):
     assert worst < 2e-5, worst
 
 
+def _worker_graph(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from koemorph_amd import parallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    synth, eng, tr, audio, emo, target = _setup(4)
+    lo, hi = parallel.shard_range(8, rank, world)
+    tr.step(audio[lo:hi], emo[lo:hi], target[lo:hi], global_batch=8)        # one eager step, then the replayed ones
+    tr.capture(hi - lo, audio.shape[1])
+    assert tr._last_was_step is False                                        # no side-stream overlap behind a capture
+    for _ in range(2):
+        tr.step_graph(audio[lo:hi], emo[lo:hi], target[lo:hi], weight=(hi - lo) / 8.0)
+    shapes = {k: v.shape for k, v in synth.make_core_params(3, style="trained").items()}
+    q.put((rank, tr.params(shapes)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_graph_replay_matches_single_process():
+    """capture() + step_graph() on two ranks: the gradient exchange behind a replayed step has to see the replay's
+    gradients (the step's "early" event is recorded on a capturing stream, so nothing may wait on it): the weights follow
+    the single-process eager trajectory."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_graph, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    synth, eng, tr, audio, emo, target = _setup(8)
+    for _ in range(3):
+        tr.step(audio, emo, target)
+    shapes = {k: v.shape for k, v in synth.make_core_params(3, style="trained").items()}
+    ref = tr.params(shapes)
+    for k in ref:
+        assert np.array_equal(res[0][1][k], res[1][1][k]), k
+    worst = max(float(np.abs(res[0][1][k] - ref[k]).max()) for k in ref)
+    assert worst < 2e-5, worst
+
+
 def test_bench_two_rank_rehearsal():
     """bench.py's N > 1 path exactly as the driver invokes it -- plain `python bench.py --gpus 2`, NO torchrun: bench.py
     starts the two ranks itself (rendezvous, per-rank inputs, barrier + max-over-ranks clock, whole-job value, rank-0
@@ -124,3 +167,8 @@ def test_bench_two_rank_rehearsal():
     B = d["config"]["windows_per_gpu"]
     assert abs(d["value"] * d["ms_per_step"] / 1e3 - 2 * B) < 0.01 * 2 * B      # whole-job frames per step = 2 ranks x B
     assert d["roofline"]["frac"] > 0 and d["vs_baseline"] is None
+    col = d["collective"]                                    # the training step's gradient exchange, measured in the same run
+    assert col["ranks"] == 2 and col["bytes"] == 4 * col["floats"] and col["floats"] > 837000
+    for mode in ("ring", "direct"):
+        assert col[mode]["ms_per_step"] > 0 and col[mode]["allreduce_ms"] > 0
+    assert col["default"] == "ring"

@@ -102,6 +102,10 @@ def test_bench_starts_its_own_ranks(n):
     d = json.loads(lines[0])
     assert d["n_gpus"] == n and d["rccl_ranks"] == n and d["steps"] == 4
     assert d["ms_per_step"] >= 10.0 * n * 0.9                 # the clock is the SLOWEST rank's (rank r sleeps 10 (r+1) ms per step)
+    col = d["collective"]                                     # the gradient bucket's all-reduce in both modes, N ranks, same run
+    assert col["ranks"] == n and col["floats"] == 837744 and col["bytes"] == 3350976 and col["default"] == "ring"
+    for mode in ("ring", "direct"):
+        assert col[mode]["allreduce_ms"] > 0 and col[mode]["sum_check"] is True
 
 
 def _direct_worker(rank, world, port, q):
