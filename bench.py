@@ -606,7 +606,7 @@ def cpu_baseline_c3(args, params, audio_np, emo_np, target_np, dropout: float):
         opt.step()
         return float(loss.detach())
 
-    r = _cpu_rate(step, B, min(args.cpu_seconds, 12.0), max_calls=100)
+    r = _cpu_rate(step, B, min(args.cpu_seconds, 12.0), max_calls=2000)
     return {"value": round(r[0], 2), "unit": "windows/s", "cores": n_all, "kind": "port",
             "sample": f"{r[1] // B} optimizer steps of {B} windows x 136448 samples in {r[2]:.1f} s: numpy front end (float64 STFT, one window per "
                       f"call) + torch-CPU fp32 core in training mode (dropout {dropout}) + autograd backward + clip + torch.optim.AdamW, "

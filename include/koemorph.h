@@ -261,6 +261,15 @@ typedef struct km_loss_config {
     const float* audio_energy_dev;   /* (B) per-window audio energy (km_audio_energy) or NULL: adds the audio-visual term
                                         0.5 * (1 - cos(mean mouth activation, audio energy)) to the perceptual loss
                                         (PerceptualBlendshapeLoss.forward with audio_features, losses.py:340-378) */
+    /* DualStreamLoss (src/train_dual_stream.py:434-516).  Its L1 / L2 terms are l1_weight / mse_weight of km_train_step*
+     * (defaults there 1.0 / 0.1); the two others:
+     *   ds_velocity    weight x MSE(pred - prev_predictions, target - prev_predictions)   (:489-495), prev_predictions =
+     *                  ds_prev_pred_dev (B, 52), a constant (no gradient); skipped when NULL, as the reference skips it
+     *   ds_separation  weight x mean over the batch of | mean(pred[:, MOUTH]) - mean(pred[:, EXPRESSION]) |  (:498-514;
+     *                  index sets of src/model/dual_stream_attention.py:14-45).  The reference computes it only when both
+     *                  attention maps are passed in; here weight > 0 switches it on */
+    float ds_velocity_weight, ds_separation_weight;
+    const float* ds_prev_pred_dev;
 } km_loss_config;
 int km_train_set_loss(km_handle h, const km_loss_config* cfg);
 /* (B, T, D) or (B, 1, D) audio features -> (B) energies for km_loss_config.audio_energy_dev: mean over T of the L2 norm
@@ -323,8 +332,8 @@ int km_legacy_forward_mel(km_handle h, const float* mel_dev, int64_t B, int64_t 
  * exact GELU; src/model/dual_stream_attention.py:296-390), their average, BlendshapeQueryEmbedding conditioned on the
  * previous frame (src/model/attention.py:481-514), num_attention_layers x [MultiHeadCrossAttention with the causal and
  * window masks of attention.py:208-246, residual, LayerNorm], BlendshapeDecoder (diagonal of output_proj, sigmoid,
- * 0.9 / 0.1 mix with the previous frame; src/model/decoder.py:108-177), exponential learnable TemporalSmoother
- * (decoder.py:278-292) and BlendshapeConstraints (decoder.py:434-466).  d_query must equal d_model (the reference's
+ * 0.9 / 0.1 mix with the previous frame; src/model/decoder.py:108-177), learnable TemporalSmoother (exponential,
+ * gaussian or median: decoder.py:278-340) and BlendshapeConstraints (decoder.py:434-466).  d_query must equal d_model (the reference's
  * residual `attn_out + attention_output` needs it; its default d_query = 128 does not run).  State-dict keys are the
  * reference's; the buffers of the smoother / constraints are NOT parameters here: the smoother state is the caller's
  * (B, 52) device array (zero it for reset_temporal_state).  A query row whose keys are all masked yields NaN, as in
@@ -346,12 +355,23 @@ typedef struct km_koemorph_config {
     int32_t num_attention_layers;   /* 4 */
     int32_t decoder_hidden_dim;     /* 128 */
     int32_t decoder_layers;         /* 2 */
-    int32_t decoder_activation;     /* 0 relu, 1 gelu (default) */
+    int32_t decoder_activation;     /* 0 relu, 1 gelu (default), 2 swish = nn.SiLU, 3 leaky_relu(0.1)  (decoder.py:68-75) */
     int32_t causal;                 /* 1 */
     int32_t window_size;            /* 30; < 0 = None */
     int32_t use_temporal_smoothing; /* 1: temporal_smoother.alpha is a parameter */
     int32_t use_constraints;        /* 1 */
     int32_t num_blendshapes;        /* 52 */
+    int32_t output_activation;      /* 0 sigmoid (default), 1 tanh, 2 none  (decoder.py:162-167) */
+    int32_t smoothing_method;       /* TemporalSmoother (decoder.py:179-340), learnable=True as KoeMorphModel builds it:
+                                       0 exponential: parameter temporal_smoother.alpha, state (B, 52);
+                                       1 gaussian: parameter temporal_smoother.gaussian_weights (window), y = sum_k softmax(w)_k *
+                                         ring[k] over the SLOTS of the history ring (:299-317: the weights go with the slot, not
+                                         with the age of its content);
+                                       2 median: torch.median over the ring's slots (:319-331; the lower middle value for an
+                                         even window, NaN if a slot holds NaN).
+                                       1 and 2 keep smoother_state_dev as (B, smoothing_window * 52 + 1) floats per call: each
+                                       batch element's ring (window, 52) followed by its slot pointer; all zero = reset */
+    int32_t smoothing_window;       /* 5 (TemporalSmoother's default; KoeMorphModel never passes another), 1..16 */
 } km_koemorph_config;
 int km_koemorph_create(const km_koemorph_config* cfg, km_handle* out);
 int km_koemorph_reserve(km_handle h, int64_t max_batch, int64_t max_frames);

@@ -43,14 +43,16 @@ class KMLegacyConfig(C.Structure):
 class KMKoeMorphConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("abi_version", "mel_dim", "emotion_dim", "d_model", "num_heads", "num_encoder_layers",
                                          "num_attention_layers", "decoder_hidden_dim", "decoder_layers", "decoder_activation",
-                                         "causal", "window_size", "use_temporal_smoothing", "use_constraints", "num_blendshapes")]
+                                         "causal", "window_size", "use_temporal_smoothing", "use_constraints", "num_blendshapes",
+                                         "output_activation", "smoothing_method", "smoothing_window")]
 
 
 class KMLossConfig(C.Structure):
     _fields_ = [("perceptual_weight", C.c_float), ("temporal_weight", C.c_float), ("sparsity_weight", C.c_float),
                 ("smoothness_weight", C.c_float), ("landmark_weight", C.c_float), ("velocity_weight", C.c_float),
                 ("prev_pred_dev", C.c_void_p), ("prev_target_dev", C.c_void_p), ("landmark_w_dev", C.c_void_p),
-                ("audio_energy_dev", C.c_void_p)]
+                ("audio_energy_dev", C.c_void_p), ("ds_velocity_weight", C.c_float), ("ds_separation_weight", C.c_float),
+                ("ds_prev_pred_dev", C.c_void_p)]
 
 
 KM_MEL_SLANEY, KM_MEL_HTK = 0, 1

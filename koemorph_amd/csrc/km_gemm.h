@@ -18,7 +18,7 @@ struct GemmArgs {
     int64_t a_kbs, b_kbs;
     float alpha, beta;
     int bias_mode;                               // 0 none, 1 bias[n], 2 bias[m]
-    int relu;                                    // epilogue activation: 0 none, 1 ReLU, 2 exact-erf GELU
+    int relu;                                    // epilogue activation (gemm_act): 0 none, 1 ReLU, 2 exact-erf GELU, 3 SiLU, 4 LeakyReLU(0.1)
     // training-mode dropout in the epilogue (after the activation): v *= drop[mask_row(m) * N + n] ? drop_scale : 0.
     // drop_map: 0 rows map 1:1, 1 rows are (window, mouth slot) -> window * 52 + MOUTH_INDICES[slot], 2 the same for
     // (window, expression slot).  Only the 64 x 64 tile path (gemm_kernel / gemm_tile_dev) implements it.
@@ -26,6 +26,17 @@ struct GemmArgs {
     float drop_scale;
     int drop_map;
 };
+
+#if defined(__HIPCC__)
+// GemmArgs::relu.  NaN stays NaN in every branch, as in torch.
+__device__ __forceinline__ float gemm_act(float v, int code) {
+    if (code == 1) return v < 0.f ? 0.f : v;                                          // nn.ReLU
+    if (code == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));         // nn.GELU (exact erf)
+    if (code == 3) return v / (1.0f + expf(-v));                                      // nn.SiLU: x sigmoid(x)
+    if (code == 4) return v < 0.f ? 0.1f * v : v;                                     // nn.LeakyReLU(0.1)
+    return v;
+}
+#endif
 
 // row of a (rows, N) activation buffer -> row of the (B, 52, N) dropout mask (see GemmArgs::drop_map)
 #if defined(__HIPCC__)

@@ -193,8 +193,7 @@ __device__ __forceinline__ void gemm_tile_dev(const GemmArgs& g, int bx, int by,
                     else if (g.bias_mode == 2) v += g.bias[m];
                     float* cp = C + (int64_t)m * g.c_rs + n;
                     if (g.beta != 0.f) v += g.beta * (*cp);
-                    if (g.relu == 1) v = v < 0.f ? 0.f : v;
-                    else if (g.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                    v = gemm_act(v, g.relu);
                     if (g.drop) v = g.drop[gemm_drop_row(g.drop_map, m) * g.N + n] ? v * g.drop_scale : 0.f;
                     *cp = v;
                 }

@@ -128,8 +128,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                     else if (g.bias_mode == 2) v += g.bias[m];
                     float* cp = C + (int64_t)m * g.c_rs + n;
                     if (g.beta != 0.f) v += g.beta * (*cp);
-                    if (g.relu == 1) v = v < 0.f ? 0.f : v;          // NaN stays NaN, as torch.relu
-                    else if (g.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // exact GELU (nn.GELU default)
+                    v = gemm_act(v, g.relu);
                     *cp = v;
                 }
             }
@@ -258,8 +257,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
                     else if (g.bias_mode == 2) v += g.bias[m];
                     float* cp = C + (int64_t)m * g.c_rs + n;
                     if (g.beta != 0.f) v += g.beta * (*cp);
-                    if (g.relu == 1) v = v < 0.f ? 0.f : v;          // NaN stays NaN, as torch.relu
-                    else if (g.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // exact GELU (nn.GELU default)
+                    v = gemm_act(v, g.relu);
                     *cp = v;
                 }
             }

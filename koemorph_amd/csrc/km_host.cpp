@@ -663,8 +663,14 @@ int km_koemorph_create(const km_koemorph_config* cfg, km_handle* out) {
     if (cfg->mel_dim <= 0 || cfg->emotion_dim <= 0 || cfg->decoder_hidden_dim <= 0 || cfg->num_encoder_layers < 0 ||
         cfg->num_attention_layers < 0 || cfg->decoder_layers < 0 || cfg->num_blendshapes <= 0 || cfg->num_blendshapes > 64)
         return fail(KM_ERR_INVALID_ARG, "km_koemorph_create: bad dimension");
-    if (cfg->decoder_activation != 0 && cfg->decoder_activation != 1)
-        return fail(KM_ERR_UNSUPPORTED, "decoder_activation: only relu (0) and gelu (1)");
+    if (cfg->decoder_activation < 0 || cfg->decoder_activation > 3)
+        return fail(KM_ERR_INVALID_ARG, "decoder_activation: 0 relu, 1 gelu, 2 swish, 3 leaky_relu (got %d)", cfg->decoder_activation);
+    if (cfg->output_activation < 0 || cfg->output_activation > 2)
+        return fail(KM_ERR_INVALID_ARG, "output_activation: 0 sigmoid, 1 tanh, 2 none (got %d)", cfg->output_activation);
+    if (cfg->smoothing_method < 0 || cfg->smoothing_method > 2)
+        return fail(KM_ERR_INVALID_ARG, "smoothing_method: 0 exponential, 1 gaussian, 2 median (got %d)", cfg->smoothing_method);
+    if (cfg->use_temporal_smoothing && cfg->smoothing_method != 0 && (cfg->smoothing_window < 1 || cfg->smoothing_window > 16))
+        return fail(KM_ERR_INVALID_ARG, "smoothing_window has to be 1..16, got %d", cfg->smoothing_window);
     if (cfg->use_constraints && cfg->num_blendshapes < 27)
         return fail(KM_ERR_INVALID_ARG, "the default exclusion pairs (25, 26), (20, 21) need >= 27 blendshapes");
     km_context* c = new km_context();
@@ -727,7 +733,8 @@ int km_koemorph_create(const km_koemorph_config* cfg, km_handle* out) {
     }
     expect(c, "decoder.output_proj.weight", {nb, hid});
     expect(c, "decoder.output_proj.bias", {nb});
-    if (cfg->use_temporal_smoothing) expect(c, "temporal_smoother.alpha", {});
+    if (cfg->use_temporal_smoothing && cfg->smoothing_method == 0) expect(c, "temporal_smoother.alpha", {});
+    if (cfg->use_temporal_smoothing && cfg->smoothing_method == 1) expect(c, "temporal_smoother.gaussian_weights", {(int64_t)cfg->smoothing_window});
     *out = c;
     return KM_OK;
 }

@@ -177,6 +177,7 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
     const bool have_prev = lc.prev_pred_dev && lc.prev_target_dev;
     const bool t_on = lc.temporal_weight > 0.f && have_prev, v_on = lc.velocity_weight > 0.f && have_prev;
     const bool lm_on = lc.landmark_weight > 0.f && lc.landmark_w_dev;
+    const bool dsv_on = lc.ds_velocity_weight > 0.f && lc.ds_prev_pred_dev;
     // perceptual groups (losses.py:306-338): weight / group size
     float pg = 0.f;
     if (i < 52) pg = i < 12 ? 1.0f / 12.f : (i < 32 ? 2.0f / 20.f : (i < 44 ? 1.0f / 12.f : 1.5f / 8.f));
@@ -200,6 +201,12 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
                 if (t_on) { loss_acc += lc.temporal_weight * dd * dd * inv_n; dy += lc.temporal_weight * 2.0f * dd * inv_n; }
                 if (v_on) { loss_acc += lc.velocity_weight * fabsf(dd) * inv_n; dy += lc.velocity_weight * sgnf(dd) * inv_n; }
             }
+            if (dsv_on) {   // DualStreamLoss velocity (train_dual_stream.py:489-495): both differences against the SAME previous prediction
+                const float pp = lc.ds_prev_pred_dev[(int64_t)b * 52 + i];
+                const float dd = (y - pp) - (a.target[(int64_t)b * 52 + i] - pp);
+                loss_acc += lc.ds_velocity_weight * dd * dd * inv_n;
+                dy += lc.ds_velocity_weight * 2.0f * dd * inv_n;
+            }
             if (lc.sparsity_weight > 0.f) { loss_acc += lc.sparsity_weight * fabsf(y) * inv_n; dy += lc.sparsity_weight * sgnf(y) * inv_n; }
             if (lc.smoothness_weight > 0.f) {   // torch.diff along the 52 coefficients: 51 pairs per row
                 const float wgt = lc.smoothness_weight / (float)(a.B * 51);
@@ -207,6 +214,14 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
                 if (i < 51) { const float dr = a.out[(int64_t)b * 52 + i + 1] - y; dy -= wgt * sgnf(dr); }
             }
             e_s[w][i] = e;
+        }
+        if (lc.ds_separation_weight > 0.f) {   // DualStreamLoss separation (train_dual_stream.py:498-514), one value per window
+            const bool mouth = i < 52 && tr_mouth_slot(i) >= 0;
+            const float ms = wsum64(mouth ? y : 0.f), es = wsum64((i < 52 && !mouth) ? y : 0.f);
+            const float diff = ms * (1.0f / 28.0f) - es * (1.0f / 24.0f);
+            const float wgt = lc.ds_separation_weight / (float)a.B;
+            if (i == 0) loss_acc += wgt * fabsf(diff);
+            if (i < 52) dy += wgt * sgnf(diff) * (mouth ? 1.0f / 28.0f : -1.0f / 24.0f);
         }
         if (lm_on) {   // u = e W^T (136), loss = mean u^2, dL/de = 2/(B 136) u W; only this wave touches e_s[w], u_s[w]
             __builtin_amdgcn_wave_barrier();

@@ -78,9 +78,16 @@ class _Decoder(nn.Module):
 
 
 class _Smoother(nn.Module):
-    def __init__(self, num_blendshapes, alpha, window_size=5):
+    """State-dict layout of TemporalSmoother(learnable=True) (decoder.py:212-236): ``alpha`` is a parameter only for the
+    exponential method, ``gaussian_weights`` (ones / window) only for the gaussian one, median has no parameter."""
+
+    def __init__(self, num_blendshapes, alpha, window_size=5, method="exponential"):
         super().__init__()
-        self.alpha = nn.Parameter(torch.tensor(float(alpha)))
+        self.window_size = window_size
+        if method == "exponential":
+            self.alpha = nn.Parameter(torch.tensor(float(alpha)))
+        elif method == "gaussian":
+            self.gaussian_weights = nn.Parameter(torch.ones(window_size) / window_size)
         self.register_buffer("prev_output", torch.zeros(1, num_blendshapes))
         self.register_buffer("history", torch.zeros(window_size, 1, num_blendshapes))
         self.register_buffer("history_ptr", torch.tensor(0, dtype=torch.long))
@@ -94,7 +101,20 @@ class _Constraints(nn.Module):
         self.register_buffer("prev_blendshapes", torch.zeros(1, num_blendshapes))
 
 
+_DECODER_ACT = {"relu": 0, "gelu": 1, "swish": 2, "leaky_relu": 3}          # km_koemorph_config.decoder_activation
+_OUTPUT_ACT = {"sigmoid": 0, "tanh": 1, "none": 2}
+_SMOOTHING = {"exponential": 0, "gaussian": 1, "median": 2}
+
+
 class KoeMorphModel(nn.Module):
+    """Mirror of the reference's KoeMorphModel (src/model/gaussian_face.py:29-268) on km_koemorph_*.
+
+    ``smoothing_method`` "gaussian" / "median": the reference's TemporalSmoother raises on the first call of either
+    (decoder.py:339 assigns a Python int to the registered buffer ``history_ptr`` -> TypeError), so no reference output
+    exists for them; what is built is what that code evidently means -- a ring of ``window_size`` = 5 past outputs, one slot
+    overwritten per call, combined by the softmax of the learnable slot weights or by torch.median -- pinned to
+    oracle/koemorph_model.py only (parity unpinned).  Everything else is pinned to the reference's own outputs."""
+
     def __init__(
         self,
         mel_dim: int = 80,
@@ -126,17 +146,17 @@ class KoeMorphModel(nn.Module):
                              "(d_model) to the queries (d_query) and fails otherwise (gaussian_face.py:230-231)")
         if d_model % num_heads != 0:                       # attention.py:68-71
             raise ValueError(f"d_model ({d_model}) must be divisible by num_heads ({num_heads})")
-        if decoder_activation not in ("relu", "gelu"):
-            raise NotImplementedError(f"decoder_activation {decoder_activation!r}: relu and gelu are built")
-        if output_activation != "sigmoid":
-            raise NotImplementedError("output_activation: only 'sigmoid' is built")
-        if use_temporal_smoothing and smoothing_method != "exponential":
-            raise NotImplementedError("smoothing_method: only 'exponential' is built")
+        if decoder_activation not in _DECODER_ACT:                       # decoder.py:68-77
+            raise ValueError(f"Unknown activation: {decoder_activation}")
+        if output_activation not in _OUTPUT_ACT:                         # decoder.py:162-169 (raised there at the first forward)
+            raise ValueError(f"Unknown output activation: {output_activation}")
+        if use_temporal_smoothing and smoothing_method not in _SMOOTHING:  # decoder.py:260-273 (likewise)
+            raise ValueError(f"Unknown smoothing method: {smoothing_method}")
         self.mel_dim, self.emotion_dim, self.d_model, self.num_blendshapes = mel_dim, emotion_dim, d_model, num_blendshapes
         self.num_heads = num_heads
         self.use_temporal_smoothing, self.use_constraints = use_temporal_smoothing, use_constraints
         self.causal, self.window_size = causal, window_size
-        self.decoder_activation = decoder_activation
+        self.decoder_activation, self.output_activation, self.smoothing_method = decoder_activation, output_activation, smoothing_method
         self.audio_encoder = _DualStreamEncoder(mel_dim, emotion_dim, d_model, num_encoder_layers, dropout)
         self.num_encoder_layers = num_encoder_layers
         self.query_embeddings = _QueryEmbedding(num_blendshapes, d_query, dropout)
@@ -144,7 +164,7 @@ class KoeMorphModel(nn.Module):
         self.attention_layer_norms = nn.ModuleList([nn.LayerNorm(d_model) for _ in range(num_attention_layers)])
         self.decoder = _Decoder(d_model, decoder_hidden_dim, num_blendshapes, decoder_layers)
         if use_temporal_smoothing:
-            self.temporal_smoother = _Smoother(num_blendshapes, smoothing_alpha)
+            self.temporal_smoother = _Smoother(num_blendshapes, smoothing_alpha, method=smoothing_method)
         if use_constraints:
             self.constraints = _Constraints(num_blendshapes)
         self._h: Optional[C.c_void_p] = None
@@ -156,9 +176,11 @@ class KoeMorphModel(nn.Module):
     def _c_config(self) -> KMKoeMorphConfig:
         return KMKoeMorphConfig(_lib.KM_ABI_VERSION, self.mel_dim, self.emotion_dim, self.d_model, self.num_heads,
                                 self.num_encoder_layers, len(self.cross_attention_layers), self.decoder.input_proj.out_features,
-                                len(self.decoder.hidden_layers), 1 if self.decoder_activation == "gelu" else 0,
+                                len(self.decoder.hidden_layers), _DECODER_ACT[self.decoder_activation],
                                 1 if self.causal else 0, -1 if self.window_size is None else int(self.window_size),
-                                1 if self.use_temporal_smoothing else 0, 1 if self.use_constraints else 0, self.num_blendshapes)
+                                1 if self.use_temporal_smoothing else 0, 1 if self.use_constraints else 0, self.num_blendshapes,
+                                _OUTPUT_ACT[self.output_activation], _SMOOTHING[self.smoothing_method],
+                                self.temporal_smoother.window_size if self.use_temporal_smoothing else 5)
 
     def _learnable(self):
         return {k: v for k, v in self.named_parameters()}
@@ -217,7 +239,13 @@ class KoeMorphModel(nn.Module):
                 raise ValueError(f"audio_mask must be (B, T) = {(B, T)}, got {tuple(audio_mask.shape)}")
             valid = audio_mask.to(device=dev, dtype=torch.uint8).contiguous()
         smooth = apply_smoothing and self.use_temporal_smoothing
-        if smooth and (self._smoother_state is None or self._smoother_state.shape[0] != B):
+        if smooth and self.smoothing_method != "exponential" and (self._smoother_state is None or self._smoother_state.shape[0] != B):
+            # gaussian / median: every batch element's history ring (window, 52) + its slot pointer (include/koemorph.h).  A
+            # new batch size continues from batch element 0's history, as decoder.py:333-337 expands history[:, :1, :]
+            W = self.temporal_smoother.window_size
+            first = torch.zeros(1, W * nb + 1, device=dev) if self._smoother_state is None else self._smoother_state[:1]
+            self._smoother_state = first.expand(B, -1).contiguous()
+        if smooth and self.smoothing_method == "exponential" and (self._smoother_state is None or self._smoother_state.shape[0] != B):
             # decoder.py:282-283: the (1, 52) state is expanded to the batch (zeros after a reset); a state that already
             # holds another batch size cannot be expanded -- torch raises there, and so does this mirror
             if self._smoother_state is not None and self._smoother_state.shape[0] != 1:

@@ -234,6 +234,9 @@ class KoeMorphConfig:
     use_temporal_smoothing: bool = True
     use_constraints: bool = True
     num_blendshapes: int = 52
+    output_activation: str = "sigmoid"        # sigmoid | tanh | none           (decoder.py:162-167)
+    smoothing_method: str = "exponential"     # exponential | gaussian | median (decoder.py:260-331)
+    smoothing_window: int = 5                 # TemporalSmoother's default; KoeMorphModel never passes another
 
     def to_dict(self):
         return asdict(self)
@@ -271,8 +274,10 @@ def koemorph_param_shapes(c: KoeMorphConfig):
     for i in range(c.decoder_layers):
         s += [(f"decoder.layer_norms.{i}.weight", (hid,)), (f"decoder.layer_norms.{i}.bias", (hid,))]
     s += [("decoder.output_proj.weight", (nb, hid)), ("decoder.output_proj.bias", (nb,))]
-    if c.use_temporal_smoothing:
+    if c.use_temporal_smoothing and c.smoothing_method == "exponential":
         s += [("temporal_smoother.alpha", ())]
+    if c.use_temporal_smoothing and c.smoothing_method == "gaussian":
+        s += [("temporal_smoother.gaussian_weights", (c.smoothing_window,))]
     return s
 
 
@@ -283,6 +288,8 @@ def make_koemorph_params(seed: int, c: KoeMorphConfig, scale: float = 1.0) -> Di
         sd = seed * 1000 + i
         if k == "temporal_smoother.alpha":
             out[k] = np.float32(0.8 + 0.1 * float(normal(sd, (1,))[0])).reshape(())
+        elif k == "temporal_smoother.gaussian_weights":
+            out[k] = normal(sd, shp, std=0.7)                  # softmaxed by the smoother: clearly non-uniform slot weights
         elif k == "query_embeddings.query_embeddings":
             out[k] = normal(sd, shp, std=0.5 * scale)
         elif (".norm" in k or "layer_norms" in k or "_encoder.3." in k) and k.endswith("weight"):

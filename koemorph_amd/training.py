@@ -170,10 +170,15 @@ class Trainer:
     def set_loss_terms(self, perceptual_weight: float = 0.0, temporal_weight: float = 0.0, sparsity_weight: float = 0.0,
                        smoothness_weight: float = 0.0, landmark_weight: float = 0.0, velocity_weight: float = 0.0,
                        prev_pred: Optional[torch.Tensor] = None, prev_target: Optional[torch.Tensor] = None,
-                       landmark_weights: Optional[torch.Tensor] = None, audio_features: Optional[torch.Tensor] = None) -> None:
+                       landmark_weights: Optional[torch.Tensor] = None, audio_features: Optional[torch.Tensor] = None,
+                       ds_velocity_weight: float = 0.0, ds_separation_weight: float = 0.0,
+                       ds_prev_pred: Optional[torch.Tensor] = None) -> None:
         """The remaining terms of the reference's KoeMorphLoss (src/model/losses.py:29-178), added to mse/l1.
         prev_pred / prev_target (B,52) and landmark_weights (136,52) are device tensors the trainer keeps alive;
-        call with no arguments to switch the extra terms off."""
+        call with no arguments to switch the extra terms off.
+        ``ds_*``: the velocity and stream-separation terms of ``DualStreamLoss`` (src/train_dual_stream.py:434-516; its
+        L1 / L2 terms are ``l1_weight`` / ``mse_weight`` of the trainer: 1.0 / 0.1 there); ``ds_prev_pred`` (B,52) = the
+        previous step's predictions (a constant)."""
         from ._lib import KMLossConfig
         keep = []
         def dev(t, shape_tail):
@@ -194,7 +199,8 @@ class Trainer:
             keep.append(energy)
         cfg = KMLossConfig(perceptual_weight, temporal_weight, sparsity_weight, smoothness_weight, landmark_weight,
                            velocity_weight, dev(prev_pred, (52,)), dev(prev_target, (52,)), dev(landmark_weights, (136, 52)),
-                           None if energy is None else _ptr(energy))
+                           None if energy is None else _ptr(energy), ds_velocity_weight, ds_separation_weight,
+                           dev(ds_prev_pred, (52,)))
         self._loss_tensors = keep
         import ctypes
         check(self._lib.km_train_set_loss(self._h, ctypes.byref(cfg)))

@@ -190,6 +190,35 @@ def koemorph_loss(pred, target, mse_weight=1.0, l1_weight=0.1, perceptual_weight
     return total
 
 
+def dual_stream_loss(pred, target, l1_weight=1.0, l2_weight=0.1, velocity_weight=0.05, stream_separation_weight=0.01,
+                     prev_predictions=None, with_attention: bool = True):
+    """DualStreamLoss.forward restated (src/train_dual_stream.py:434-516): l1_weight * L1 + l2_weight * MSE (:478-483),
+    + velocity_weight * MSE(pred - prev, target - prev) when prev_predictions is given (:489-495), + stream_separation_weight
+    * mean | mean(pred[:, MOUTH]) - mean(pred[:, EXPRESSION]) | when both attention maps are passed (:498-514;
+    ``with_attention`` stands for that condition).  PARITY UNPINNED: the module imports hydra (absent here), and its
+    separation branch cannot run in the reference either (``from .dual_stream_attention import ...`` inside ``src/`` resolves
+    to a module that does not exist) -- restated from the source text."""
+    total = l1_weight * F.l1_loss(pred, target) + l2_weight * F.mse_loss(pred, target)
+    if prev_predictions is not None and velocity_weight > 0:
+        total = total + velocity_weight * F.mse_loss(pred - prev_predictions, target - prev_predictions)
+    if with_attention and stream_separation_weight > 0:
+        sep = (pred[:, MOUTH_INDICES].mean(dim=1) - pred[:, EXPRESSION_INDICES].mean(dim=1)).abs().mean()
+        total = total + stream_separation_weight * sep
+    return total
+
+
+def core_dual_stream_loss_and_grads(params, mel, short, emo, target, prev_predictions, weights=None, num_heads=8,
+                                    mel_sequence_length=256, dtype=torch.float32):
+    """DualStreamLoss of the core's prediction and d loss / d param through torch.autograd on the restated forward."""
+    P = {k: _t(v, dtype).clone().requires_grad_(True) for k, v in params.items()}
+    out = core_forward(P, mel, short, emo, num_heads=num_heads, mel_sequence_length=mel_sequence_length, dtype=dtype)
+    loss = dual_stream_loss(out["blendshapes"], _t(target, dtype),
+                            prev_predictions=None if prev_predictions is None else _t(prev_predictions, dtype), **(weights or {}))
+    loss.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).detach().numpy() for k, v in P.items()}
+    return float(loss.detach()), grads, out["blendshapes"].detach().numpy()
+
+
 def core_full_loss_and_grads(params, mel, short, emo, target, prev_pred, prev_target, landmark_w, weights=None,
                              num_heads=8, mel_sequence_length=256, dtype=torch.float32, audio_features=None,
                              dropout_p=0.0, drop_masks=None):

@@ -165,6 +165,19 @@ KOEMORPH_CASES = [
     # default mask at T = 256: rows >= 5 have every key masked -> NaN in the reference (SURVEY: "default config is broken")
     dict(name="koemorph_d64_T256_masked", cfg=dict(d_model=64, num_heads=4, num_encoder_layers=1, num_attention_layers=1,
                                                    decoder_hidden_dim=32, decoder_layers=1, emotion_dim=24), B=1, T=256, seed=64),
+    # decoder activations swish / leaky_relu (decoder.py:68-75) and output activations tanh / none (:162-167), three chained
+    # frames.  The gaussian and median TemporalSmoother methods have NO fixture: the reference raises on their first call
+    # (decoder.py:339 assigns a Python int to the registered buffer history_ptr -> TypeError), so they cannot be pinned.
+    dict(name="koemorph_d64_T20_swish", cfg=dict(d_model=64, num_heads=4, num_encoder_layers=1, num_attention_layers=2,
+                                                 decoder_hidden_dim=32, decoder_layers=2, emotion_dim=24, decoder_activation="swish"),
+         B=3, T=20, seed=66, frames=3),
+    dict(name="koemorph_d64_T20_leaky_tanh", cfg=dict(d_model=64, num_heads=4, num_encoder_layers=1, num_attention_layers=2,
+                                                      decoder_hidden_dim=32, decoder_layers=1, emotion_dim=24,
+                                                      decoder_activation="leaky_relu", output_activation="tanh", use_constraints=False),
+         B=2, T=20, seed=67, frames=3),
+    dict(name="koemorph_d64_T20_none", cfg=dict(d_model=64, num_heads=4, num_encoder_layers=1, num_attention_layers=1,
+                                                decoder_hidden_dim=32, decoder_layers=1, emotion_dim=24, output_activation="none"),
+         B=2, T=20, seed=68, frames=3),
 ]
 
 
@@ -190,6 +203,7 @@ def main_koemorph():
                           num_heads=kc.num_heads, num_encoder_layers=kc.num_encoder_layers,
                           num_attention_layers=kc.num_attention_layers, decoder_hidden_dim=kc.decoder_hidden_dim,
                           decoder_layers=kc.decoder_layers, decoder_activation=kc.decoder_activation,
+                          output_activation=kc.output_activation, smoothing_method=kc.smoothing_method,
                           use_temporal_smoothing=kc.use_temporal_smoothing, use_constraints=kc.use_constraints,
                           causal=kc.causal, window_size=kc.window_size).eval()
         sd = m.state_dict()
@@ -198,21 +212,25 @@ def main_koemorph():
         sd.update({k: torch.from_numpy(np.asarray(v)) for k, v in params.items()})
         m.load_state_dict(sd, strict=True)
         m.reset_temporal_state()
-        mel, emo = koemorph_inputs(synth, c["seed"], c["B"], c["T"], kc.mel_dim, kc.emotion_dim)
-        mel2, emo2 = koemorph_inputs(synth, c["seed"] + 100, c["B"], c["T"], kc.mel_dim, kc.emotion_dim)
-        rec = {"config": json.dumps(dict(cfg=kc.to_dict(), B=c["B"], T=c["T"], seed=c["seed"]))}
+        assert m.temporal_smoother.window_size == kc.smoothing_window if kc.use_temporal_smoothing else True
+        nf = c.get("frames", 2)
+        rec = {"config": json.dumps(dict(cfg=kc.to_dict(), B=c["B"], T=c["T"], seed=c["seed"], frames=nf))}
         am = None
         if c.get("valid"):
             am = torch.arange(c["T"])[None, :] < torch.tensor(c["valid"])[:, None]
             rec["valid"] = np.asarray(c["valid"], dtype=np.int32)
-        with torch.no_grad():
-            o1 = m(torch.from_numpy(mel), torch.from_numpy(emo), audio_mask=am, return_attention=True)
-            o2 = m(torch.from_numpy(mel2), torch.from_numpy(emo2), audio_mask=am, prev_blendshapes=o1["blendshapes"], return_attention=True)
-        for tag, o in (("f1", o1), ("f2", o2)):
+        prev = None
+        for fi in range(nf):                                   # frame i: inputs seeded seed + 100 i, previous frame's output fed back
+            mel, emo = koemorph_inputs(synth, c["seed"] + 100 * fi, c["B"], c["T"], kc.mel_dim, kc.emotion_dim)
+            with torch.no_grad():
+                o = m(torch.from_numpy(mel), torch.from_numpy(emo), audio_mask=am, prev_blendshapes=prev, return_attention=True)
+            prev = o["blendshapes"]
+            tag = f"f{fi + 1}"
             rec[tag + "/blendshapes"] = o["blendshapes"].numpy()
             rec[tag + "/raw_blendshapes"] = o["raw_blendshapes"].numpy()
-            for li, w in enumerate(o["attention_weights"]):
-                rec[f"{tag}/attn{li}"] = w.numpy()[:, :, ::13, :].copy()        # query rows 0, 13, 26, 39 of every head
+            if fi < 2:
+                for li, w in enumerate(o["attention_weights"]):
+                    rec[f"{tag}/attn{li}"] = w.numpy()[:, :, ::13, :].copy()        # query rows 0, 13, 26, 39 of every head
         path = os.path.join(OUT, c["name"] + ".npz")
         np.savez_compressed(path, **rec)
         print(f"{c['name']}: f1[0,:3]={rec['f1/blendshapes'][0,:3]} f2[0,:3]={rec['f2/blendshapes'][0,:3]} -> {os.path.getsize(path)/1024:.1f} KB")

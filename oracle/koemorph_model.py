@@ -10,8 +10,9 @@ TEST INFRASTRUCTURE (see oracle/__init__.py).  Follows, in /root/reference/src/m
   attention.py:481-514          BlendshapeQueryEmbedding (learned rows + conditioning MLP of the previous frame)
   decoder.py:108-177            BlendshapeDecoder (input_proj, residual hidden layers with LayerNorm, the diagonal
                                 of output_proj, sigmoid, 0.9 / 0.1 mix with the previous frame)
-  decoder.py:278-292            TemporalSmoother, exponential + learnable: alpha = sigmoid(param),
-                                y = alpha * prev + (1 - alpha) * x, state starts at zero
+  decoder.py:278-340            TemporalSmoother, learnable=True as the model builds it: exponential (alpha = sigmoid(param),
+                                y = alpha * prev + (1 - alpha) * x, state starts at zero), gaussian (softmax of the learnable
+                                weights over the history ring's slots) and median (torch.median over the slots)
   decoder.py:434-466            BlendshapeConstraints: clamp to [0, 1], pairs (25, 26) and (20, 21) divided by their
                                 sum + 1e-8
 The reference module is importable in the build container: oracle/gen_golden.py runs it on seeded parameters
@@ -40,7 +41,20 @@ def _gelu(x):
 
 
 def _act(x, name):
-    return _gelu(x) if name == "gelu" else torch.relu(x)
+    """BlendshapeDecoder's activation (decoder.py:68-75): nn.ReLU / nn.GELU / nn.SiLU / nn.LeakyReLU(0.1)."""
+    if name == "gelu":
+        return _gelu(x)
+    if name == "swish":
+        return x * torch.sigmoid(x)
+    if name == "leaky_relu":
+        return torch.where(x >= 0, x, 0.1 * x)
+    return torch.relu(x)
+
+
+def smoother_state_shape(c: KoeMorphConfig, B: int):
+    """The smoother's state as km_koemorph_forward keeps it: (B, 52) for the exponential method; for gaussian / median every
+    batch element's history ring (window, 52) followed by its slot pointer: (B, window * 52 + 1).  Zeros = reset."""
+    return (B, c.num_blendshapes) if c.smoothing_method == "exponential" else (B, c.smoothing_window * c.num_blendshapes + 1)
 
 
 def _ln(x, P, prefix, eps=1e-5):
@@ -133,16 +147,29 @@ def koemorph_forward(params: Dict[str, np.ndarray], c: KoeMorphConfig, mel, emot
         h = F.linear(h, P[f"decoder.hidden_layers.{i}.weight"], P[f"decoder.hidden_layers.{i}.bias"])
         h = _act(_ln(h, P, f"decoder.layer_norms.{i}."), c.decoder_activation) + r
     z = (h * P["decoder.output_proj.weight"].unsqueeze(0)).sum(-1) + P["decoder.output_proj.bias"]     # diagonal of (B, 52, 52)
-    raw = torch.sigmoid(z)
+    raw = torch.sigmoid(z) if c.output_activation == "sigmoid" else (torch.tanh(z) if c.output_activation == "tanh" else z)   # decoder.py:162-167
     if prev is not None:
         raw = 0.9 * raw + 0.1 * prev
     y = raw
     state = None
     if apply_smoothing and c.use_temporal_smoothing:
-        st = torch.zeros(B, nb, dtype=dtype) if smoother_state is None else torch.as_tensor(np.asarray(smoother_state)).to(dtype)
-        alpha = torch.sigmoid(P["temporal_smoother.alpha"])
-        y = alpha * st + (1 - alpha) * y
-        state = y.clone()
+        st = torch.zeros(smoother_state_shape(c, B), dtype=dtype) if smoother_state is None else torch.as_tensor(np.asarray(smoother_state)).to(dtype)
+        if c.smoothing_method == "exponential":                       # decoder.py:278-292
+            alpha = torch.sigmoid(P["temporal_smoother.alpha"])
+            y = alpha * st + (1 - alpha) * y
+            state = y.clone()
+        else:                                                         # decoder.py:294-340: ring of `window` slots, one written per call
+            W = c.smoothing_window
+            state = st.clone()
+            ring = state[:, :W * nb].view(B, W, nb)
+            ptr = int(round(float(state[0, W * nb])))
+            ring[:, ptr] = y
+            state[:, W * nb] = float((ptr + 1) % W)
+            if c.smoothing_method == "gaussian":                      # the (learnable) weights go with the SLOT, not the age (:307-317)
+                w = torch.softmax(P["temporal_smoother.gaussian_weights"], dim=0)
+                y = (w.view(1, W, 1) * ring).sum(dim=1)
+            else:                                                     # torch.median over the slots (:319-331)
+                y = torch.median(ring, dim=1)[0]
     if apply_constraints and c.use_constraints:
         y = y.clamp(0.0, 1.0).clone()
         for a, b in EXCLUSION_PAIRS:

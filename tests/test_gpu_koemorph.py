@@ -10,7 +10,7 @@ import torch
 from koemorph_amd import _lib
 from koemorph_amd.model import KoeMorphModel, create_koemorph_model
 from oracle import koemorph_model as okm
-from test_oracle_koemorph import GOLDEN, assert_same, case_mask, load_case
+from test_oracle_koemorph import GOLDEN, assert_same, case_frames, case_mask, load_case
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4          # north-star tolerance on the 52 coefficients; observed <= 3e-6
@@ -21,6 +21,7 @@ def build(cfg: okm.KoeMorphConfig, params):
                       num_heads=cfg.num_heads, num_encoder_layers=cfg.num_encoder_layers,
                       num_attention_layers=cfg.num_attention_layers, decoder_hidden_dim=cfg.decoder_hidden_dim,
                       decoder_layers=cfg.decoder_layers, decoder_activation=cfg.decoder_activation,
+                      output_activation=cfg.output_activation, smoothing_method=cfg.smoothing_method,
                       use_temporal_smoothing=cfg.use_temporal_smoothing, use_constraints=cfg.use_constraints, causal=cfg.causal,
                       window_size=cfg.window_size)
     sd = m.state_dict()
@@ -45,6 +46,57 @@ def test_two_frames_match_reference_golden(path):
         assert len(o["attention_weights"]) == cfg.num_attention_layers
         for li, w in enumerate(o["attention_weights"]):
             assert_same(w.cpu().numpy()[:, :, ::13, :], z[f"{tag}/attn{li}"], TOL)
+
+
+@pytest.mark.parametrize("path", [p for p in GOLDEN if "swish" in p or "leaky" in p or "none" in p],
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_activation_variants_match_reference_golden(path):
+    """decoder_activation swish / leaky_relu, output_activation tanh / none: three chained frames of the reference module."""
+    z, cfg, params, _, _ = load_case(path)
+    m = build(cfg, params)
+    prev = None
+    for i, (mel, emo) in enumerate(case_frames(path)):
+        with torch.no_grad():
+            o = m(torch.from_numpy(mel).cuda(), torch.from_numpy(emo).cuda(), prev_blendshapes=prev)
+        prev = o["blendshapes"]
+        assert_same(o["blendshapes"].cpu().numpy(), z[f"f{i + 1}/blendshapes"], TOL)
+        assert_same(o["raw_blendshapes"].cpu().numpy(), z[f"f{i + 1}/raw_blendshapes"], TOL)
+
+
+@pytest.mark.parametrize("method,T", [("gaussian", 20), ("median", 20), ("median", 256)])
+def test_windowed_smoothers_match_oracle(method, T):
+    """TemporalSmoother gaussian / median (decoder.py:294-340) over eight chained frames (the 5-slot ring wraps), and a batch
+    size change in between (the history of batch element 0 carries on, :333-337).  PARITY UNPINNED: the reference raises on
+    the first call of these methods (decoder.py:339), the oracle restates what the code means.  T = 256 with the default
+    mask: rows >= 5 are NaN, and a median over a window that holds a NaN is NaN (torch.median)."""
+    from koemorph_amd import synth
+    cfg = okm.KoeMorphConfig(d_model=64, num_heads=4, num_encoder_layers=1, num_attention_layers=1, decoder_hidden_dim=32,
+                             decoder_layers=1, emotion_dim=24, smoothing_method=method)
+    params = okm.make_koemorph_params(91, cfg)
+    m = build(cfg, params)
+    state, prev_o, prev_g = None, None, None
+    for i in range(8):
+        B = 3 if i < 5 else 2
+        mel, emo = synth.normal(500 + i, (B, T, 80)), synth.normal(600 + i, (B, T, 24))
+        if state is not None and state.shape[0] != B:
+            state = np.repeat(state[:1], B, axis=0)
+            if prev_o is not None:
+                prev_o, prev_g = prev_o[:B], prev_g[:B]
+        want = okm.koemorph_forward(params, cfg, mel, emo, prev_blendshapes=prev_o, smoother_state=state)
+        with torch.no_grad():
+            got = m(torch.from_numpy(mel).cuda(), torch.from_numpy(emo).cuda(), prev_blendshapes=prev_g)
+        state = want["smoother_state"]
+        if T != 256:                                          # (a NaN fed back through prev_blendshapes makes every row NaN)
+            prev_o, prev_g = want["blendshapes"], got["blendshapes"]
+        assert_same(got["blendshapes"].cpu().numpy(), want["blendshapes"], TOL)
+        assert_same(got["raw_blendshapes"].cpu().numpy(), want["raw_blendshapes"], TOL)
+        if T == 256:
+            assert np.isnan(want["blendshapes"][:, 5:]).all() and not np.isnan(want["blendshapes"][:, :5]).any()
+    m.reset_temporal_state()                                  # a new sequence starts from an empty ring
+    mel, emo = synth.normal(500, (3, T, 80)), synth.normal(600, (3, T, 24))
+    with torch.no_grad():
+        again = m(torch.from_numpy(mel).cuda(), torch.from_numpy(emo).cuda())
+    assert_same(again["blendshapes"].cpu().numpy(), okm.koemorph_forward(params, cfg, mel, emo)["blendshapes"], TOL)
 
 
 def test_options_against_oracle():
@@ -95,8 +147,9 @@ def test_error_paths():
         KoeMorphModel()                                   # d_query 128 != d_model 256: the reference's default does not run
     with pytest.raises(ValueError):
         KoeMorphModel(d_model=100, d_query=100, num_heads=8)
-    with pytest.raises(NotImplementedError):
-        KoeMorphModel(d_query=256, smoothing_method="median")
+    for bad in (dict(smoothing_method="kalman"), dict(decoder_activation="mish"), dict(output_activation="softmax")):
+        with pytest.raises(ValueError, match="Unknown"):  # the reference's messages (decoder.py:76-77, :168-169, :272-273)
+            KoeMorphModel(d_query=256, **bad)
     m = KoeMorphModel(d_model=64, d_query=64, num_heads=4, num_encoder_layers=0, num_attention_layers=1, decoder_hidden_dim=32,
                       emotion_dim=8).cuda().eval()
     with pytest.raises(ValueError):

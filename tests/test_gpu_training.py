@@ -65,6 +65,34 @@ def test_full_koemorph_loss_gradients_match_reference(name):
     assert abs(l2 - want) < 2e-6 * max(1.0, want)
 
 
+@pytest.mark.parametrize("name", ["core_d64_T32_H4_small", "core_d256_T256_H8_grads"])
+def test_dual_stream_loss_terms_match_oracle_autograd(name):
+    """DualStreamLoss (src/train_dual_stream.py:434-516: L1 + 0.1 L2 + 0.05 velocity vs prev_predictions + 0.01 stream
+    separation) in the HIP loss tail: loss and every parameter gradient against torch.autograd on the oracle's
+    restatement.  PARITY UNPINNED: the reference module imports hydra (absent) -- the oracle restates it from the text."""
+    from oracle import core as ocore
+    c, params, (mel, short, emo), g = golden_case(name)
+    target, prev_pred, _, _ = full_loss_inputs(c["seed"], c["B"])
+    e, tr = make(params, c, mse_weight=0.1, l1_weight=1.0)
+    tr.set_loss_terms(ds_velocity_weight=0.05, ds_separation_weight=0.01, ds_prev_pred=dev(prev_pred))
+    loss = float(tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target)).item())
+    want, grads, _ = ocore.core_dual_stream_loss_and_grads(params, mel, short, emo, target, prev_pred, num_heads=c["H"],
+                                                           mel_sequence_length=c["T"])
+    assert abs(loss - want) < 2e-6 * max(1.0, abs(want))
+    got = tr.grads({k: v.shape for k, v in params.items()})
+    for k, ref in grads.items():
+        np.testing.assert_allclose(got[k], ref, atol=1e-7 + 2e-4 * np.abs(ref).max(), rtol=2e-4, err_msg=k)
+    # the separation term alone (large weight): its gradient is +-1/(28 B) / -+1/(24 B) per coefficient before the chain rule
+    tr.set_loss_terms(ds_separation_weight=5.0)
+    l2 = float(tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target)).item())
+    w2, g2, _ = ocore.core_dual_stream_loss_and_grads(params, mel, short, emo, target, None, num_heads=c["H"], mel_sequence_length=c["T"],
+                                                       weights=dict(velocity_weight=0.0, stream_separation_weight=5.0))
+    assert abs(l2 - w2) < 2e-6 * max(1.0, abs(w2))
+    got = tr.grads({k: v.shape for k, v in params.items()})
+    for k, ref in g2.items():
+        np.testing.assert_allclose(got[k], ref, atol=1e-7 + 2e-4 * np.abs(ref).max(), rtol=2e-4, err_msg=k)
+
+
 def test_training_loop_matches_torch_adamw_with_ema_and_l1():
     """4 optimisation steps, EMA inside the forward (stateful across steps like the reference), MSE + L1, global-norm
     clipping, AdamW: compared with the same loop in torch (autograd on the oracle forward, torch.optim.AdamW)."""

@@ -123,3 +123,24 @@ def test_oracle_audio_visual_term_matches_reference(name):
                                    temporal_weight=0, sparsity_weight=0, smoothness_weight=0, landmark_weight=0, velocity_weight=0,
                                    audio_features=torch.from_numpy(af)))
     assert abs(per - float(g["metric/perceptual"])) <= 2e-6 * max(1.0, abs(float(g["metric/perceptual"])))
+
+
+def test_dual_stream_loss_restatement_known_values():
+    """oracle.core.dual_stream_loss (src/train_dual_stream.py:434-516, restated; parity unpinned): the velocity term is the
+    MSE again (both differences are taken against the same previous prediction), the separation term is the mean absolute
+    difference of the two index sets' means."""
+    import torch
+    from oracle import core as ocore
+    g = torch.Generator().manual_seed(5)
+    pred, target, prev = (torch.rand(6, 52, generator=g) for _ in range(3))
+    base = float(ocore.dual_stream_loss(pred, target, velocity_weight=0.0, stream_separation_weight=0.0))
+    l1, l2 = float((pred - target).abs().mean()), float(((pred - target) ** 2).mean())
+    assert abs(base - (l1 + 0.1 * l2)) < 1e-6
+    vel = float(ocore.dual_stream_loss(pred, target, stream_separation_weight=0.0, prev_predictions=prev)) - base
+    assert abs(vel - 0.05 * l2) < 1e-6
+    sep = float(ocore.dual_stream_loss(pred, target, velocity_weight=0.0)) - base
+    m = pred[:, ocore.MOUTH_INDICES].mean(1); x = pred[:, ocore.EXPRESSION_INDICES].mean(1)
+    assert abs(sep - 0.01 * float((m - x).abs().mean())) < 1e-7
+    assert len(ocore.MOUTH_INDICES) == 28 and len(ocore.EXPRESSION_INDICES) == 24
+    # without the attention maps the reference skips the separation term
+    assert abs(float(ocore.dual_stream_loss(pred, target, velocity_weight=0.0, with_attention=False)) - base) < 1e-7

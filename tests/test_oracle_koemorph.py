@@ -24,6 +24,15 @@ def load_case(path):
     return z, cfg, params, f1, f2
 
 
+def case_frames(path):
+    """Inputs of every chained frame of a fixture: frame i is seeded seed + 100 i (oracle/gen_golden.py)."""
+    z = np.load(path)
+    meta = json.loads(str(z["config"]))
+    cfg = km.KoeMorphConfig(**meta["cfg"])
+    return [koemorph_inputs(synth, meta["seed"] + 100 * i, meta["B"], meta["T"], cfg.mel_dim, cfg.emotion_dim)
+            for i in range(meta.get("frames", 2))]
+
+
 def case_mask(z, T):
     """audio_mask (B, T) of a padded-batch fixture (True = valid frame), or None."""
     return None if "valid" not in z.files else np.arange(T)[None, :] < z["valid"][:, None]
@@ -37,7 +46,58 @@ def assert_same(got, want, atol):
 
 
 def test_golden_files_present():
-    assert len(GOLDEN) == 5
+    assert len(GOLDEN) == 8
+
+
+@pytest.mark.parametrize("path", [p for p in GOLDEN if "swish" in p or "leaky" in p or "none" in p],
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_oracle_matches_reference_activation_variants(path):
+    """Decoder activations swish / leaky_relu and output activations tanh / none (decoder.py:68-75, :162-167): three chained
+    frames of the reference's own module."""
+    z, cfg, params, _, _ = load_case(path)
+    prev, state = None, None
+    for i, (mel, emo) in enumerate(case_frames(path)):
+        o = km.koemorph_forward(params, cfg, mel, emo, prev_blendshapes=prev, smoother_state=state)
+        prev, state = o["blendshapes"], o["smoother_state"]
+        assert_same(o["blendshapes"], z[f"f{i + 1}/blendshapes"], 2e-6)
+        assert_same(o["raw_blendshapes"], z[f"f{i + 1}/raw_blendshapes"], 2e-6)
+
+
+def test_windowed_smoothers_restatement():
+    """gaussian / median TemporalSmoother (decoder.py:294-340).  PARITY UNPINNED: the reference raises TypeError on the first
+    call of either (decoder.py:339), so this only checks the restatement against its definition: a 5-slot ring, one slot
+    per call, softmax-weighted sum over the SLOTS / torch.median over the slots."""
+    import torch
+    cfg = km.KoeMorphConfig(d_model=64, num_heads=4, num_encoder_layers=1, num_attention_layers=1, decoder_hidden_dim=32,
+                            decoder_layers=1, emotion_dim=24, use_constraints=False, smoothing_method="gaussian")
+    params = km.make_koemorph_params(90, cfg)
+    assert params["temporal_smoother.gaussian_weights"].shape == (5,) and "temporal_smoother.alpha" not in params
+    w = torch.softmax(torch.from_numpy(params["temporal_smoother.gaussian_weights"]).double(), 0).numpy()
+    raws, state = [], None
+    for i in range(7):
+        mel, emo = koemorph_inputs(synth, 900 + i, 2, 12, 80, 24)
+        o = km.koemorph_forward(params, cfg, mel, emo, smoother_state=state)
+        state = o["smoother_state"]
+        raws.append(o["raw_blendshapes"].astype(np.float64))
+        ring = [np.zeros_like(raws[0]) for _ in range(5)]
+        for j, r in enumerate(raws):
+            ring[j % 5] = r                                    # slot j mod 5 holds the newest value written there
+        want = sum(w[k] * ring[k] for k in range(5))
+        np.testing.assert_allclose(o["blendshapes"], want, atol=1e-6)
+        assert int(state[0, -1]) == (i + 1) % 5 and state.shape == km.smoother_state_shape(cfg, 2)
+    cfg_m = km.KoeMorphConfig(**{**cfg.to_dict(), "smoothing_method": "median"})
+    params_m = km.make_koemorph_params(90, cfg_m)
+    assert not any(k.startswith("temporal_smoother.") for k in params_m)
+    raws, state = [], None
+    for i in range(7):
+        mel, emo = koemorph_inputs(synth, 900 + i, 2, 12, 80, 24)
+        o = km.koemorph_forward(params_m, cfg_m, mel, emo, smoother_state=state)
+        state = o["smoother_state"]
+        raws.append(o["raw_blendshapes"])
+        ring = [np.zeros_like(raws[0]) for _ in range(5)]
+        for j, r in enumerate(raws):
+            ring[j % 5] = r
+        np.testing.assert_allclose(o["blendshapes"], np.sort(np.stack(ring), axis=0)[2], atol=1e-7)
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
