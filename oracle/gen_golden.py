@@ -50,6 +50,10 @@ CASES = [
     dict(name="core_d256_T256_H8_train_fullloss_av", d=256, T=256, H=8, B=8, t_in=257, pstyle="trained", istyle="mel01", seed=73,
          grads="full", train=0.1, av=True),
     dict(name="core_d64_T32_H4_fullloss_av", d=64, T=32, H=4, B=5, t_in=33, pstyle="trained", istyle="randn", seed=74, grads="full", av=True),
+    # gradients at the 60 fps TRAINING shape (configs/experiment/dual_stream_60fps.yaml:7-24: d_model 512, window 512), eval and
+    # training mode
+    dict(name="core_d512_T512_H8_grads", d=512, T=512, H=8, B=4, t_in=513, pstyle="trained", istyle="mel01", seed=81, grads=True),
+    dict(name="core_d512_T512_H8_train", d=512, T=512, H=8, B=4, t_in=513, pstyle="trained", istyle="mel01", seed=82, grads=True, train=0.1),
 ]
 
 

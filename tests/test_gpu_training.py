@@ -25,7 +25,7 @@ def make(params, c, **kw):
     return e, Trainer(e, max_windows=c["B"], use_smoothing=False, **kw)
 
 
-@pytest.mark.parametrize("name", ["core_d64_T32_H4_small", "core_d256_T256_H8_grads"])
+@pytest.mark.parametrize("name", ["core_d64_T32_H4_small", "core_d256_T256_H8_grads", "core_d512_T512_H8_grads"])
 def test_gradients_match_reference_autograd(name):
     c, params, (mel, short, emo), g = golden_case(name)
     target = synth.uniform(c["seed"] * 3 + 1, (c["B"], 52), 0.0, 1.0)
@@ -229,7 +229,7 @@ def test_phased_step_agrees_with_the_launch_per_op_chain():
         np.testing.assert_allclose(g_ph[k], g_ch[k], atol=1e-8 + 2e-5 * np.abs(g_ch[k]).max(), rtol=2e-4, err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["core_d64_T32_H4_train", "core_d256_T256_H8_train"])
+@pytest.mark.parametrize("name", ["core_d64_T32_H4_train", "core_d256_T256_H8_train", "core_d512_T512_H8_train"])
 def test_training_mode_dropout_gradients_match_reference(name):
     """model.train() with dropout 0.1: the step replays the three dropout masks of the fixture (drawn by torch in the
     reference run) and must reproduce the reference's training-mode output, loss and autograd gradients."""

@@ -42,7 +42,7 @@ def test_properties_mirroring_reference_tests():
     np.testing.assert_allclose(eb, np.broadcast_to(eb[:, :1], eb.shape), atol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["core_d64_T32_H4_small", "core_d256_T256_H8_grads"])
+@pytest.mark.parametrize("name", ["core_d64_T32_H4_small", "core_d256_T256_H8_grads", "core_d512_T512_H8_grads"])
 def test_oracle_gradients_match_reference_autograd(name):
     from koemorph_amd import synth
     c, params, (mel, short, emo), g = golden_case(name)
@@ -84,7 +84,7 @@ def test_oracle_full_koemorph_loss_matches_reference(name):
         assert abs(v - float(g["metric/" + term])) <= 2e-6 * max(1.0, abs(float(g["metric/" + term]))), term
 
 
-@pytest.mark.parametrize("name", ["core_d64_T32_H4_train", "core_d256_T256_H8_train"])
+@pytest.mark.parametrize("name", ["core_d64_T32_H4_train", "core_d256_T256_H8_train", "core_d512_T512_H8_train"])
 def test_oracle_training_mode_dropout_matches_reference(name):
     """model.train(): the restated forward with the fixture's three dropout masks reproduces the reference module's
     training-mode output and autograd gradients (dual_stream_attention.py:106,115,153; train_sequential.py:118)."""
