@@ -219,6 +219,9 @@ static int free_train(Context* c) {
     c->tr_steps = nullptr;
     if (c->tr_red2) { HIP_TRY(hipFree(c->tr_red2)); c->tr_red2 = nullptr; }
     if (c->trp_act) { HIP_TRY(hipFree(c->trp_act)); c->trp_act = nullptr; c->trp_act_floats = 0; }
+    if (c->trp_split) { HIP_TRY(hipFree(c->trp_split)); c->trp_split = nullptr; c->trp_split_floats = 0; }
+    if (c->trp_tail_part) { HIP_TRY(hipFree(c->trp_tail_part)); c->trp_tail_part = nullptr; }
+    if (c->trp_tail_ctr) { HIP_TRY(hipFree(c->trp_tail_ctr)); c->trp_tail_ctr = nullptr; }
     if (c->trp_masks) { HIP_TRY(hipFree(c->trp_masks)); c->trp_masks = nullptr; }
     if (c->trp_drop_ctr) { HIP_TRY(hipFree(c->trp_drop_ctr)); c->trp_drop_ctr = nullptr; }
     if (c->tr_s2) { (void)hipStreamDestroy((hipStream_t)c->tr_s2); c->tr_s2 = nullptr; }
@@ -297,6 +300,12 @@ int km_train_init(km_handle h, int64_t max_windows, void* stream) {
         const int64_t KP = (c->KT + 15) / 16 * 16;
         c->trp_act_floats = max_windows * (per + KP * c->NK) + fixed + 4096;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_act), (size_t)c->trp_act_floats * sizeof(float)));
+        // split-K partials: up to 16 partial outputs of every weight / bias gradient that is a product over the rows of the batch
+        c->trp_split_floats = 16 * (5 * (int64_t)c->d * c->d + 2 * (int64_t)c->DH * c->d + 16 * (int64_t)c->d) + 1024;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_split), (size_t)c->trp_split_floats * sizeof(float)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_tail_part), (size_t)32 * 64 * sizeof(float)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_tail_ctr), sizeof(unsigned)));
+        HIP_TRY(hipMemsetAsync(c->trp_tail_ctr, 0, sizeof(unsigned), (hipStream_t)stream));
         HIP_TRY(hipMalloc(&c->trp_masks, (size_t)trainp_mask_alloc_bytes(c)));
         HIP_TRY(hipMemsetAsync(c->trp_masks, 1, (size_t)trainp_mask_alloc_bytes(c), (hipStream_t)stream));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_drop_ctr), sizeof(int)));

@@ -71,6 +71,9 @@ struct Options {
     int emotion_separate = 0;      // 1: emotion logits in their own kernel
     int no_ln_fusion = 0, no_db_fusion = 0, no_score_fusion = 0, no_out_fusion = 0, no_v_fusion = 0;   // generic chain A/B
     int train_chain = 0;           // 1: training step as the round-1 launch-per-op chain (A/B reference; no dropout)
+    int train_no_split = 0;        // 1: no split-K of the long gradient products of the phased training step (A/B)
+    int train_dwce_parts = 0;      // > 0: partial sums of the channel-encoder gradient per step (a divisor of the batch; A/B)
+    int train_tail_groups = 0;     // > 0: workgroups of the loss tail (A/B; default: one per 4 windows, at most 32)
 };
 void options_from_env(Options& o);
 int set_option(struct Context* c, const char* name, long long value);
@@ -144,6 +147,8 @@ struct Context {
     km_loss_config tr_loss_cfg{};    // extra KoeMorphLoss terms (all weights 0 = off)
     // phased training step (km_trainp.hip): its own activation workspace, dropout masks and per-step mask counter
     float* trp_act = nullptr; int64_t trp_act_floats = 0;
+    float* trp_split = nullptr; int64_t trp_split_floats = 0;   // partial outputs of the split-K gradient products of one step
+    float* trp_tail_part = nullptr; unsigned* trp_tail_ctr = nullptr;   // per-workgroup sums of the loss tail + its arrival counter
     void* trp_masks = nullptr;       // bytes: mel (W,H,28,NK) | emo (W,H,24) | dec (W,52,DH), W = tr_windows
     int* trp_drop_ctr = nullptr;     // device-side step counter of the mask generator (graph-replay safe)
     float tr_dropout_p = 0.f;        // training-mode dropout probability (0 = eval-mode arithmetic)

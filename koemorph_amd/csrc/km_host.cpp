@@ -541,6 +541,8 @@ const OptName kOptNames[] = {
     {"emotion_separate", &Options::emotion_separate}, {"no_ln_fusion", &Options::no_ln_fusion},
     {"no_db_fusion", &Options::no_db_fusion}, {"no_score_fusion", &Options::no_score_fusion},
     {"no_out_fusion", &Options::no_out_fusion}, {"no_v_fusion", &Options::no_v_fusion}, {"train_chain", &Options::train_chain},
+    {"train_no_split", &Options::train_no_split}, {"train_dwce_parts", &Options::train_dwce_parts},
+    {"train_tail_groups", &Options::train_tail_groups},
 };
 }  // namespace
 

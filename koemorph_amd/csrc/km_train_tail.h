@@ -33,6 +33,12 @@ struct TailArgs {
     int B, DH;
     int expr_rows;        // expression rows per window in zrows: 1 (eval-mode arithmetic: the 24 rows are identical) or 24
     const float* audio_energy;   // (B) or null: per-window audio energy for the audio-visual term (losses.py:340-378)
+    // more than one workgroup (gridDim.x = G > 1; not with the audio-visual term, which couples the whole batch): window b
+    // belongs to workgroup b % G; every workgroup leaves its sums in part[G][64] (0..51 d stream-weight sum, 52 loss, 53 d alpha,
+    // 54 d b2) and the one that arrives last (ctr, put back to zero by it) adds them up in workgroup order
+    float* part; unsigned* ctr;
+    float* d_b2;          // or null: gradient of the decoder's output bias = sum of every dL/dz
+    int* drop_ctr;        // or null: the dropout generator's step counter, advanced once per step
 };
 
 // One workgroup: decoder output layer, sigmoid, stream weights, clamp, EMA, loss and the gradient of the loss
@@ -68,19 +74,27 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
     const float mel_w_i = (w == 0 && i < 52) ? a.mel_w[i] : 0.f, emo_w_i = (w == 0 && i < 52) ? a.emo_w[i] : 0.f;
     const float alpha_raw = a.alpha_p[0];
     const float* zr = a.zrows;
-    if (a.zrows_out) {   // decoder output layer: one wave per row, lanes stride the hidden units
-        // 16 lanes per row, four rows per wave at a time, eight such passes in flight: the stores come after the group's
-        // loads (a store to zrows_out between them would order every later load behind it), so a wave pays the memory
-        // latency once per 32 rows
-        const int64_t rm = (int64_t)a.B * 28, rows = rm + (int64_t)a.B * a.expr_rows;
+    const int G = (int)gridDim.x, wg = (int)blockIdx.x;
+    const int n_own = a.B > wg ? (a.B - wg + G - 1) / G : 0;          // windows wg, wg + G, ... of this workgroup
+    if (a.zrows_out) {   // decoder output layer of this workgroup's windows: 16 lanes per row, lanes stride the hidden units
+        // four rows per wave at a time, eight such passes in flight: the stores come after the group's loads (a store to
+        // zrows_out between them would order every later load behind it), so a wave pays the memory latency once per 32 rows
+        const int64_t rm = (int64_t)a.B * 28;
+        const int per_win = 28 + a.expr_rows, rows = n_own * per_win;
         const int sub = i >> 4, l16 = i & 15;
-        for (int64_t g0 = (int64_t)w * 4; g0 < rows; g0 += (int64_t)NW * 4 * 8) {
+        auto row_of = [&](int lr) -> int64_t {                         // local row -> row of zrows / h1 | he
+            const int wl = lr / per_win, r = lr - wl * per_win;
+            const int64_t b = wg + (int64_t)wl * G;
+            return r < 28 ? b * 28 + r : rm + b * a.expr_rows + (r - 28);
+        };
+        for (int g0 = w * 4; g0 < rows; g0 += NW * 4 * 8) {
             float zl[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int64_t r = g0 + (int64_t)u * NW * 4 + sub;
+                const int lr = g0 + u * NW * 4 + sub;
                 float s = 0.f;
-                if (r < rows) {
+                if (lr < rows) {
+                    const int64_t r = row_of(lr);
                     const float* h = r < rm ? a.h1 + r * a.DH : a.he + (r - rm) * a.DH;
                     for (int k = l16; k < a.DH; k += 16) s = fmaf(h[k], a.w2[k], s);
                 }
@@ -90,8 +104,8 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int64_t r = g0 + (int64_t)u * NW * 4 + sub;
-                if (l16 == 0 && r < rows) a.zrows_out[r] = zl[u] + a.b2[0];
+                const int lr = g0 + u * NW * 4 + sub;
+                if (l16 == 0 && lr < rows) a.zrows_out[row_of(lr)] = zl[u] + a.b2[0];
             }
         }
         zr = a.zrows_out;
@@ -111,7 +125,7 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
     // ---- pass A: y = EMA(clamp(wsum * sigmoid(z))) ----
     if (i < 52) {
         const int slot = tr_mouth_slot(i);
-        for (int b = w; b < a.B; b += NW) {
+        for (int b = wg + G * w; b < a.B; b += G * NW) {
             const float z = slot >= 0 ? zr[(int64_t)b * 28 + slot]
                                       : zr[(int64_t)a.B * 28 + (a.expr_rows == 1 ? b : (int64_t)b * 24 + tr_expr_slot(i))];
             const float bs = 1.0f / (1.0f + expf(-z));
@@ -141,7 +155,7 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
     // audio-visual consistency (PerceptualBlendshapeLoss._compute_audiovisual_loss, losses.py:340-378):
     //   1 - cos(m, e), m_b = mean of the 20 mouth coefficients of window b, e_b = audio energy; couples the whole batch.
     //   d/dy[b, i in 12..31] = -(1/20) (e^_b - cos m^_b) / |m|   (the two F.normalize + cosine_similarity collapse to this)
-    const bool av_on = lc.perceptual_weight > 0.f && a.audio_energy && a.B <= TAIL_AV_MAX;
+    const bool av_on = lc.perceptual_weight > 0.f && a.audio_energy && a.B <= TAIL_AV_MAX && G == 1;
     if (av_on) {
         for (int b = threadIdx.x; b < a.B; b += 64 * NW) {
             float m = 0.f;
@@ -181,8 +195,8 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
     // perceptual groups (losses.py:306-338): weight / group size
     float pg = 0.f;
     if (i < 52) pg = i < 12 ? 1.0f / 12.f : (i < 32 ? 2.0f / 20.f : (i < 44 ? 1.0f / 12.f : 1.5f / 8.f));
-    float loss_acc = 0.f, dws = 0.f, dal = 0.f;
-    for (int b = w; b < a.B; b += NW) {
+    float loss_acc = 0.f, dws = 0.f, dal = 0.f, db2 = 0.f;
+    for (int b = wg + G * w; b < a.B; b += G * NW) {
         float y = 0.f, e = 0.f, dy = 0.f;
         if (i < 52) {
             y = a.out[(int64_t)b * 52 + i];
@@ -247,6 +261,7 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
             dws += df * bs;
             const float dzv = df * wsum_s[i] * bs * (1.0f - bs);
             a.dz[(int64_t)b * 52 + i] = dzv;
+            db2 += dzv;
             if (a.grow) {
                 const int slot = tr_mouth_slot(i);
                 if (slot >= 0) a.grow[(int64_t)b * 28 + slot] = dzv;
@@ -254,15 +269,18 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
             }
         }
     }
+    // this workgroup's sums: waves in index order per coefficient, then (for the scalars) the butterfly over the coefficients
+    __shared__ float tot_s[64];
     if (i < 52) dws_p[w][i] = dws;
     red[w][i] = i < 52 ? loss_acc : 0.f;
     __syncthreads();
-    if (w == 0) {   // waves in index order per coefficient, then the butterfly over the coefficients
+    float loss_wg = 0.f, dal_wg = 0.f, db2_wg = 0.f, dws_wg = 0.f;
+    if (w == 0) {
         float t = 0.f;
         for (int ww = 0; ww < NW; ++ww) t += red[ww][i];
-        float s = wsum64(t);
-        if (av_on) s += lc.perceptual_weight * 0.5f * (1.0f - av_c[0]);
-        if (i == 0) a.loss[0] = s;
+        loss_wg = wsum64(t);
+        if (i < 52)
+            for (int ww = 0; ww < NW; ++ww) dws_wg += dws_p[ww][i];
     }
     __syncthreads();
     red[w][i] = i < 52 ? dal : 0.f;
@@ -270,12 +288,54 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
     if (w == 0) {
         float t = 0.f;
         for (int ww = 0; ww < NW; ++ww) t += red[ww][i];
-        const float s = wsum64(t);
-        if (i == 0) a.d_alpha[0] = s;
+        dal_wg = wsum64(t);
+    }
+    __syncthreads();
+    red[w][i] = i < 52 ? db2 : 0.f;
+    __syncthreads();
+    if (w == 0) {
+        float t = 0.f;
+        for (int ww = 0; ww < NW; ++ww) t += red[ww][i];
+        db2_wg = wsum64(t);
+    }
+    // all workgroups: leave the sums, the last one to arrive adds them up in workgroup order
+    __shared__ int last_s;
+    if (w == 0) {
+        const float mine = i < 52 ? dws_wg : (i == 52 ? loss_wg : (i == 53 ? dal_wg : (i == 54 ? db2_wg : 0.f)));
+        tot_s[i] = mine;
+        if (G > 1) {
+            a.part[(int64_t)wg * 64 + i] = mine;
+            __threadfence();
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int last = 1;
+        if (G > 1) {
+            const unsigned arrived = atomicAdd(a.ctr, 1u);
+            last = arrived == (unsigned)G - 1u;
+            if (last) a.ctr[0] = 0u;
+        }
+        last_s = last;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    if (w == 0) {
+        float v = tot_s[i];
+        if (G > 1) {
+            __threadfence();
+            v = 0.f;
+            for (int g = 0; g < G; ++g) v += a.part[(int64_t)g * 64 + i];
+        }
+        const float loss_t = __shfl(v, 52), dal_t = __shfl(v, 53), db2_t = __shfl(v, 54);
+        if (i == 0) {
+            a.loss[0] = loss_t + (av_on ? lc.perceptual_weight * 0.5f * (1.0f - av_c[0]) : 0.f);
+            a.d_alpha[0] = dal_t;
+            if (a.d_b2) a.d_b2[0] = db2_t;
+            if (a.drop_ctr) a.drop_ctr[0] += 1;           // the next step draws fresh dropout masks
+        }
         // softmax backward for both stream-weight vectors: d w_j = (1/tau) w_j (g_j - sum_k g_k w_k), g = 0.5 dwsum
-        float dws_t = 0.f;
-        if (i < 52)
-            for (int ww = 0; ww < NW; ++ww) dws_t += dws_p[ww][i];
+        const float dws_t = i < 52 ? v : 0.f;
         const float dm = wsum64(i < 52 ? 0.5f * dws_t * wm_s[i] : 0.f), de = wsum64(i < 52 ? 0.5f * dws_t * we_s[i] : 0.f);
         if (i < 52) {
             a.d_melw[i] = wm_s[i] * (0.5f * dws_t - dm) / a.temperature;

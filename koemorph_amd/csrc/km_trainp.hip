@@ -45,7 +45,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---- operations of a phase ------------------------------------------------------------------------------------
 enum OpKind : int {
     OP_GEMM = 0, OP_ZERO, OP_FILL, OP_MASKGEN, OP_PACKX, OP_LOGPACK, OP_LN_FWD, OP_LN_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_RELU_OUTER, OP_REDUCE,
-    OP_EMO_EXPAND, OP_EMO_REDUCE
+    OP_EMO_EXPAND, OP_EMO_REDUCE, OP_REDUCE4
 };
 
 struct ElemArgs {
@@ -58,7 +58,13 @@ struct ElemArgs {
     float f0;
     unsigned u0, u1;
     LogParams lp;          // OP_LOGPACK
+    // OP_REDUCE4: up to four reductions out_j[c] (+)= sum_{y < rS[j]} p_j[y * rn[j] + c], c < rn[j] (p0..p3 -> q0..q3); the
+    // partial products of the split-K gradient GEMMs of the phase before
+    // (separate fields, read through select chains: an array indexed at run time would move the whole kernel argument into
+    // scratch memory -- 4 KB per thread and every phase six times slower)
+    int rn0, rn1, rn2, rn3, rS0, rS1, rS2, rS3, racc0, racc1, racc2, racc3;
 };
+static_assert(sizeof(ElemArgs) <= 208, "ElemArgs shares a union with GemmArgs");
 
 struct Op {
     int kind;
@@ -71,13 +77,14 @@ struct Op {
     };
 };
 
-constexpr int kMaxOps = 14;
+constexpr int kMaxOps = 17;     // 4 + 17 * 4 + 17 * sizeof(Op) stays under the 4 KB kernel-argument limit
 static_assert(sizeof(GemmArgs) <= 208, "Phase has to stay under the 4 KB kernel-argument limit");
 struct Phase {
     int n_ops;
     int block_end[kMaxOps];
     Op ops[kMaxOps];
 };
+static_assert(sizeof(Phase) <= 4096, "Phase is passed by value: 4 KB of kernel arguments");
 
 // Philox4x32-10 (Salmon et al. 2011): counter (c0..c3), key (k0, k1) -> 4 x 32 random bits
 __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
@@ -359,6 +366,22 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, float* smem) {
         a.q0[c0] = a.i1 ? a.q0[c0] + s : s;
         break;
     }
+    case OP_REDUCE4: {      // the workgroup's blocks are dealt to the (up to four) reductions in order
+        const int b0 = (a.rn0 + 255) / 256, b1 = b0 + (a.rn1 + 255) / 256, b2 = b1 + (a.rn2 + 255) / 256;
+        const int j = vb < b0 ? 0 : (vb < b1 ? 1 : (vb < b2 ? 2 : 3));                                  // workgroup-uniform
+        const int base = j == 0 ? 0 : (j == 1 ? b0 : (j == 2 ? b1 : b2));
+        const float* part = j == 0 ? a.p0 : (j == 1 ? a.p1 : (j == 2 ? a.p2 : a.p3));
+        float* out = j == 0 ? a.q0 : (j == 1 ? a.q1 : (j == 2 ? a.q2 : a.q3));
+        const int n = j == 0 ? a.rn0 : (j == 1 ? a.rn1 : (j == 2 ? a.rn2 : a.rn3));
+        const int S = j == 0 ? a.rS0 : (j == 1 ? a.rS1 : (j == 2 ? a.rS2 : a.rS3));
+        const int acc = j == 0 ? a.racc0 : (j == 1 ? a.racc1 : (j == 2 ? a.racc2 : a.racc3));
+        const int64_t c0 = (int64_t)(vb - base) * 256 + tid;
+        if (c0 >= n) break;
+        float sacc = 0.f;
+        for (int y = 0; y < S; ++y) sacc += part[(int64_t)y * n + c0];
+        out[c0] = acc ? out[c0] + sacc : sacc;
+        break;
+    }
     case OP_EMO_EXPAND: {   // Ae[(b, q), c] = Ve[b, c] * keep[b, c / hd, q] / (1 - p): the one-key attention of the emotion stream
         const int64_t i = (int64_t)vb * 256 + tid;
         const int d = a.i0, hd = a.i1, H = d / hd;
@@ -418,32 +441,36 @@ __global__ __launch_bounds__(256) void phase_kernel(Phase p) {
     }
 }
 
-// 1024 threads: 16 waves compute the 52 B decoder logits (one row per wave at a time) before the loss tail proper
-__global__ __launch_bounds__(1024) void trainp_tail_kernel(TailArgs a, float* d_b2, int* drop_ctr) {
-    train_tail_dev<16>(a);
-    // decoder output bias: sum of every logit gradient, in a fixed order (row_grads_kernel of the chain)
-    __shared__ float red[1024];
-    __syncthreads();
-    float s = 0.f;
-    for (int i = threadIdx.x; i < a.B * 52; i += 1024) s += a.dz[i];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int st = 512; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        d_b2[0] = red[0];
-        if (drop_ctr) drop_ctr[0] += 1;           // the next step draws fresh dropout masks
-    }
-}
+// 1024 threads per workgroup: its 16 waves compute the decoder logits of the workgroup's windows, then the loss tail proper
+__global__ __launch_bounds__(1024) void trainp_tail_kernel(TailArgs a) { train_tail_dev<16>(a); }
 
 // ---- host: building and launching the program ----------------------------------------------------------------
+// Split-K: a gradient product over all rows of the batch (K = 80 B, 28 B or 24 B) with an output of a few tiles is a few
+// long serial chains on a few CUs -- at 64 windows K = 5120 is 160 k-steps on 32 of 256 CUs and sets the duration of its
+// phase.  Such a product is cut along K into S batch entries that write S partial outputs; the partials are summed in a
+// fixed order (OP_REDUCE4) by the NEXT phase, which is early enough: nothing but the optimizer reads a parameter gradient.
+// Products of up to kSplitMinK stay whole: the 8-window step (K <= 640) runs exactly as before.
+constexpr int kSplitMinK = 1024;
+struct PendingReduce { const float* part; float* out; int n, S, acc; };
+
 struct Program {
     Phase cur{};
     int blocks = 0;
     int rc = KM_OK;
     size_t lds = 0;
+    float* scratch = nullptr;            // bump allocator for the partials of a step
+    int64_t scratch_left = 0;
+    std::vector<PendingReduce> pend_prev, pend_cur;
+    bool allow_split = true;
+    // S for a product of K rows with `tiles` output tiles, or 1
+    static int split_factor(int64_t K, int tiles) {
+        if (K <= kSplitMinK || tiles >= 128) return 1;
+        const int want = (int)((K + 639) / 640);
+        int best = 1;
+        for (int S = 2; S <= 16; ++S)
+            if (K % S == 0 && K / S >= 224 && tiles * S <= 512 && std::abs(S - want) < std::abs(best - want)) best = S;
+        return best;
+    }
     void add(const Op& op, int nblocks) {
         if (nblocks <= 0) return;
         if (cur.n_ops >= kMaxOps) { rc = fail(KM_ERR_UNSUPPORTED, "training program: more than %d operations in one phase", kMaxOps); return; }
@@ -452,7 +479,28 @@ struct Program {
         cur.block_end[cur.n_ops] = blocks;
         ++cur.n_ops;
     }
-    void gemm(const GemmArgs& g, int batch) {
+    void gemm(const GemmArgs& g_in, int batch) {
+        GemmArgs g = g_in;
+        const int tiles0 = ((g.N + 63) / 64) * ((g.M + 31) / 32);
+        const bool splittable = allow_split && batch == 1 && g.kb_count == 1 && g.bias_mode == 0 && g.relu == 0 && !g.drop && g.alpha == 1.f &&
+                                g.c_rs == g.N && (g.beta == 0.f || g.beta == 1.f);
+        const int S = splittable ? split_factor(g.K, tiles0) : 1;
+        // an output some pending reduction (of this or the previous phase) still has to write must not be touched directly:
+        // the product then goes through a partial of its own (S = 1) and is added behind that reduction
+        bool conflict = false;
+        for (const auto& r : pend_prev) conflict = conflict || r.out == g.C;
+        for (const auto& r : pend_cur) conflict = conflict || r.out == g.C;
+        if (conflict && !splittable) { rc = fail(KM_ERR_UNSUPPORTED, "training program: a product writes an output with a pending reduction"); return; }
+        if ((S > 1 || conflict) && (int64_t)S * g.M * g.N + 4 <= scratch_left) {
+            float* part = scratch;
+            const int64_t n = (int64_t)g.M * g.N;
+            scratch += ((int64_t)S * n + 3) / 4 * 4; scratch_left -= ((int64_t)S * n + 3) / 4 * 4;
+            pend_cur.push_back({part, g.C, (int)n, S, g.beta == 1.f ? 1 : 0});
+            const int64_t chunk = g.K / S;
+            g.K = (int)chunk; g.beta = 0.f; g.C = part;
+            g.a_bs1 = chunk * g.a_cs; g.b_bs1 = chunk * g.b_rs; g.c_bs1 = n; g.a_bs2 = g.b_bs2 = g.c_bs2 = 0; g.batch2 = 1;
+            batch = S;
+        }
         Op op{};
         op.kind = OP_GEMM; op.g = g;
         op.gx = (g.N + 63) / 64; op.gy = (g.M + 63) / 64; op.bm = 64;
@@ -478,7 +526,27 @@ struct Program {
         op.kind = kind; op.e = e;
         add(op, (int)nblocks);
     }
+    void add_pending_reduces() {          // the partials written by the previous phase, four reductions per operation
+        for (size_t i = 0; i < pend_prev.size(); i += 4) {
+            ElemArgs e{};
+            const float** ps[4] = {&e.p0, &e.p1, &e.p2, &e.p3};
+            float** qs[4] = {&e.q0, &e.q1, &e.q2, &e.q3};
+            int* ns[4] = {&e.rn0, &e.rn1, &e.rn2, &e.rn3};
+            int* Ss[4] = {&e.rS0, &e.rS1, &e.rS2, &e.rS3};
+            int* as[4] = {&e.racc0, &e.racc1, &e.racc2, &e.racc3};
+            int nblocks = 0;
+            for (size_t j = 0; j < 4 && i + j < pend_prev.size(); ++j) {
+                const PendingReduce& r = pend_prev[i + j];
+                *ps[j] = r.part; *qs[j] = r.out; *ns[j] = r.n; *Ss[j] = r.S; *as[j] = r.acc;
+                nblocks += (r.n + 255) / 256;
+            }
+            elem(OP_REDUCE4, e, nblocks);
+        }
+        pend_prev.clear();
+    }
     int end_phase(hipStream_t st) {
+        add_pending_reduces();
+        pend_prev.swap(pend_cur);
         if (rc) return rc;
         if (cur.n_ops > 0) {
             hipLaunchKernelGGL(phase_kernel, dim3((unsigned)blocks), dim3(256), lds, st, cur);
@@ -642,6 +710,8 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         return fail(KM_ERR_UNSUPPORTED, "the fused training attention blocks are built for heads of 16, 32 or 64 columns (got %lld)", (long long)hd);
 
     Program pg;
+    pg.scratch = c->trp_split; pg.scratch_left = c->trp_split_floats;
+    pg.allow_split = !c->opt.train_no_split;
     auto blocks4 = [](int64_t rows) { return (rows + 3) / 4; };            // one wave per row, 4 rows per block
     auto blocks256 = [](int64_t n) { return (n + 255) / 256; };
     // column sums as products with a vector: out (1 x n) (+)= w^T (1 x rows) M (rows x n); w = ones, or per-row loss gradients
@@ -763,8 +833,15 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         t.mse_w = mse_w; t.l1_w = l1_w; t.lc = c->tr_loss_cfg; t.fac = tfac; t.xp = txp; t.loss = loss_dev;
         t.d_melw = Gd("mel_weights"); t.d_emow = Gd("emotion_weights"); t.d_alpha = Gd("smoothing_alpha");
         t.B = (int)B; t.DH = (int)DH; t.expr_rows = 24; t.audio_energy = c->tr_loss_cfg.audio_energy_dev; t.out2 = out_dev;
-        hipLaunchKernelGGL(trainp_tail_kernel, dim3(1), dim3(1024), 0, st, t, Gd("blendshape_decoder.3.bias"),
-                           (drop && c->tr_dropout_mode == 0) ? c->trp_drop_ctr : nullptr);
+        t.d_b2 = Gd("blendshape_decoder.3.bias"); t.drop_ctr = (drop && c->tr_dropout_mode == 0) ? c->trp_drop_ctr : nullptr;
+        t.part = c->trp_tail_part; t.ctr = c->trp_tail_ctr;
+        // one workgroup per two windows (the 8-window step: four, 231.7 us against 240 with one), at most 32; the audio-visual term
+        // couples the whole batch: one
+        const bool av = c->tr_loss_cfg.perceptual_weight > 0.f && c->tr_loss_cfg.audio_energy_dev;
+        int groups = av ? 1 : (int)((B + 1) / 2);
+        if (c->opt.train_tail_groups > 0 && !av) groups = c->opt.train_tail_groups;
+        groups = groups < 1 ? 1 : (groups > 32 ? 32 : groups);
+        hipLaunchKernelGGL(trainp_tail_kernel, dim3((unsigned)groups), dim3(1024), 0, st, t);
         HIP_TRY(hipGetLastError());
     }
     // ================= P7: decoder output layer backward; O2 (needed from P8 on) =================
@@ -814,13 +891,6 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     pg.gemm(TN(dKV, 2 * d, Y, d, gin_w + d * d, d, 2 * d, d, R), 1);
     colsum(dKV, R, 2 * d, 2 * d, gin_b + d, 0, ones);
     reduce(dQ_part, (int)B, 28 * d, 28 * d, dQb, 0);
-    {   // query rows of in_proj straight from the per-window partials (contraction batch over the windows), so that the whole
-        // in_proj gradient is final here: dWq = sum_b dQ[b]^T mq, dbq = column sums over all B * 28 rows
-        GemmArgs g = TN(dQ_part, d, P("mouth_queries"), d, gin_w, d, d, d, 28);
-        g.kb_count = (int)B; g.a_kbs = 28 * d; g.b_kbs = 0;
-        pg.gemm(g, 1);
-        colsum(dQ_part, Rm, d, d, gin_b, 0, ones);
-    }
     pg.gemm(TN(dO1, d, A, d, Gd("mel_attention.out_proj.weight"), d, d, d, Rm), 1);
     pg.gemm(TN(dOe1, d, Ae, d, Gd("emotion_attention.out_proj.weight"), d, d, d, Re), 1);
     colsum(dO1, Rm, d, d, Gd("mel_attention.out_proj.bias"), 0, ones);
@@ -829,10 +899,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     colsum(dVe, B, d, d, gein_b + 2 * d, 0, ones);
     pg.gemm(NN(dVe, d, einw + 2 * d * d, d, dE, d, B, d, d), 1);
     RUN(pg.end_phase(st));
-    // everything but the "late" group of the bucket (km_train_init) is final: a side stream may start its all-reduce
-    HIP_TRY(hipEventRecord((hipEvent_t)c->tr_ev[0], st));
-    c->tr_early_recorded = true;
-    // ================= P11: LayerNorm backward (both streams); query-side gradients =================
+    // ================= P11: LayerNorm backward (both streams); query-side gradients (+ the partial sums of P10's products) =========
     {
         ElemArgs b{};
         b.p0 = dY; b.p1 = Y0; b.p2 = P("mel_norm.weight"); b.p3 = mu; b.p4 = rs; b.q0 = dY0; b.q1 = Tm; b.n0 = R; b.i0 = (int)d;
@@ -842,12 +909,24 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         pg.elem(OP_LN_BWD, e, blocks4(B));
     }
     pg.gemm(NN(dQb, d, inw, d, Gd("mouth_queries"), d, 28, d, d), 1);
+    pg.gemm(TN(dQb, d, P("mouth_queries"), d, gin_w, d, d, d, 28), 1);       // query rows of in_proj: dWq = dQ^T mq, dbq = column sums of dQ
+    colsum(dQb, 28, d, d, gin_b, 0, ones);
     RUN(pg.end_phase(st));
+    // everything but the "late" group of the bucket (km_train_init) is final: a side stream may start its all-reduce
+    HIP_TRY(hipEventRecord((hipEvent_t)c->tr_ev[0], st));
+    c->tr_early_recorded = true;
     // ================= P12: channel encoder gradients (per-window partials); LayerNorm parameters; emotion encoder =================
+    // dWce = sum_b dY0_b^T X_b: `parts` partial sums over groups of B / parts consecutive windows (contraction batch), summed
+    // by P13; parts == 1 writes the gradient itself and P13 has nothing to do
+    int parts = 1;
+    for (int q = 1; q <= 16 && q <= B; ++q) if (B % q == 0) parts = q;
+    if (c->opt.train_dwce_parts > 0 && B % c->opt.train_dwce_parts == 0) parts = c->opt.train_dwce_parts;
     {
-        GemmArgs g = G(dY0, 1, d, X, 1, NKk, dWce_part, KT, d, KT, NKk);                                    // dWce[b] = dY0_b^T X_b
-        g.a_bs1 = NKk * d; g.b_bs1 = KP * NKk; g.c_bs1 = d * KT;
-        pg.gemm(g, (int)B);
+        const int64_t gsz = B / parts;
+        GemmArgs g = G(dY0, 1, d, X, 1, NKk, parts == 1 ? Gd("mel_channel_encoder.weight") : dWce_part, KT, d, KT, NKk);
+        g.kb_count = (int)gsz; g.a_kbs = NKk * d; g.b_kbs = KP * NKk;
+        g.a_bs1 = gsz * NKk * d; g.b_bs1 = gsz * KP * NKk; g.c_bs1 = d * KT;
+        pg.gemm(g, parts);
     }
     colsum(dY0, R, d, d, Gd("mel_channel_encoder.bias"), 0, ones);
     colsum(Tm, R, d, d, Gd("mel_norm.weight"), 0, ones);
@@ -858,8 +937,9 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     colsum(dE0, B, d, d, Gd("emotion_encoder.bias"), 0, ones);
     RUN(pg.end_phase(st));
     // ================= P13: sum the per-window partials of the channel encoder weight =================
-    reduce(dWce_part, (int)B, d * KT, d * KT, Gd("mel_channel_encoder.weight"), 0);
+    if (parts > 1) reduce(dWce_part, parts, d * KT, d * KT, Gd("mel_channel_encoder.weight"), 0);
     RUN(pg.end_phase(st));
+    RUN(pg.end_phase(st));            // (partials of a split product of P13: there is none today)
     return KM_OK;
 }
 

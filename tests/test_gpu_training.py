@@ -322,3 +322,36 @@ def test_train_step_from_audio_leaves_clean_window_maxima():
         res.append((loss, tr.flat_grad.clone()))
     assert res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1])
+
+
+def test_split_k_gradient_products_agree_with_the_unsplit_step():
+    """64 windows: the gradient products over all rows of the batch (K = 80 B, 28 B, 24 B > 1024) are cut along K into partial
+    products summed by the next phase (km_trainp.hip, Program::gemm).  Same gradients as the unsplit program (option
+    train_no_split) up to summation order, bit-reproducible from run to run, and the 8-window step is not affected."""
+    params = synth.make_core_params(5, style="trained")
+    B = 64
+    mel, short, emo = synth.make_core_inputs(77, B, 257, style="mel01")
+    target = synth.uniform(78, (B, 52), 0.0, 1.0)
+    c = dict(d=256, H=8, T=256, B=B)
+    e, tr = make(params, c, l1_weight=0.1)
+    shapes = {k: v.shape for k, v in params.items()}
+    l1 = float(tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target)).item())
+    g1 = tr.grads(shapes)
+    l1b = float(tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target)).item())
+    assert l1b == l1 and all(np.array_equal(v, tr.grads(shapes)[k]) for k, v in g1.items())
+    e.set_option("train_no_split", 1)
+    l0 = float(tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target)).item())
+    g0 = tr.grads(shapes)
+    e.set_option("train_no_split", 0)
+    assert abs(l1 - l0) < 1e-6 * max(1.0, abs(l0))
+    for k in g0:
+        np.testing.assert_allclose(g1[k], g0[k], atol=1e-8 + 2e-5 * np.abs(g0[k]).max(), rtol=2e-4, err_msg=k)
+    # and against autograd on the oracle for a sample of the tensors whose products are split
+    from oracle import core as ocore
+    _, gref, _ = ocore.core_loss_and_grads(params, mel[:B], short[:B], emo[:B], target)
+    e2, tr2 = make(params, c)
+    tr2.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target))
+    g2 = tr2.grads(shapes)
+    for k in ("mel_attention.in_proj_weight", "mel_attention.out_proj.weight", "mel_output_proj.weight", "blendshape_decoder.0.weight",
+              "blendshape_decoder.3.weight", "mel_channel_encoder.weight", "mel_norm.weight", "mel_attention.in_proj_bias"):
+        np.testing.assert_allclose(g2[k], gref[k], atol=1e-8 + 2e-4 * np.abs(gref[k]).max(), rtol=2e-4, err_msg=k)
