@@ -918,8 +918,8 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     // ================= P12: channel encoder gradients (per-window partials); LayerNorm parameters; emotion encoder =================
     // dWce = sum_b dY0_b^T X_b: `parts` partial sums over groups of B / parts consecutive windows (contraction batch), summed
     // by P13; parts == 1 writes the gradient itself and P13 has nothing to do
-    int parts = 1;
-    for (int q = 1; q <= 16 && q <= B; ++q) if (B % q == 0) parts = q;
+    int parts = 1;                                       // contraction chains of about 640 rows (8 windows): 8 windows -> 1 (0.2282 ms
+    for (int q = 1; q <= 16 && q <= B / 8; ++q) if (B % q == 0) parts = q;     // against 0.2313 with 8 partial sums and a summing phase)
     if (c->opt.train_dwce_parts > 0 && B % c->opt.train_dwce_parts == 0) parts = c->opt.train_dwce_parts;
     {
         const int64_t gsz = B / parts;
