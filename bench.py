@@ -374,6 +374,16 @@ def run_c2(args, rk: Ranks):
                 "traffic": (pmc.get("mel_power_rp_kernel") or pmc.get("mel_power_kernel") or {}).get("hbm_bytes_per_launch"),
                 "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, NOT this run)",
                 "launch_ms": round(t_mel * 1e3, 4), "algorithmic_bytes_per_launch": BYTES_PER_FRAME_AUDIO * B}
+    sqm = (load_json("profiles", "pmc_sq.json").get("mel_power_rp_kernel") or {}).get("derived") or {}
+    if sqm:      # the kernel is not bandwidth-limited: its honest roofs are instruction issue on the vector pipe and the LDS
+        wc = sqm.get("wave_cycle_split") or {}
+        roof_mel["issue"] = {"valu_active_frac_of_cu_busy": sqm.get("valu_active_frac_of_cu_busy"),
+                             "lds_active_frac_of_cu_busy": sqm.get("lds_active_frac_of_cu_busy"),
+                             "lds_bank_conflict_frac_of_cu_busy": sqm.get("lds_bank_conflict_frac_of_cu_busy"),
+                             "simd_issue_occupancy": None if "issuing" not in wc else round(4 * wc["issuing"], 3),
+                             "wave_cycle_split": wc,
+                             "note": "4 waves per SIMD x the fraction of its cycles a wave is issuing: ~1 = the SIMD's issue port is saturated",
+                             "source": "profiles/pmc_sq.json (separate rocprofv3 --pmc passes, NOT this run)"}
     roofline, other = (roof_core, roof_mel) if t_core >= t_mel else (roof_mel, roof_core)
     # whole step against both roofs: executed MFMA FLOPs and algorithmic HBM bytes (audio in + power-mel out and in) / step time
     step_roof = {"ms": round(ms_per_step, 4),
