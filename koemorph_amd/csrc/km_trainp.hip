@@ -609,12 +609,13 @@ struct Program {
     std::vector<PendingReduce> pend_prev, pend_cur;
     bool allow_split = true;
     // S for a product of K rows with `tiles` output tiles, or 1
-    static int split_factor(int64_t K, int tiles) {
-        if (K <= kSplitMinK || tiles >= 128) return 1;
-        const int want = (int)((K + 639) / 640);
+    int min_k = kSplitMinK, chain = 640;
+    int split_factor(int64_t K, int tiles) const {
+        if (K <= min_k || tiles >= 128) return 1;
+        const int want = (int)((K + chain - 1) / chain);
         int best = 1;
         for (int S = 2; S <= 16; ++S)
-            if (K % S == 0 && K / S >= 224 && tiles * S <= 512 && std::abs(S - want) < std::abs(best - want)) best = S;
+            if (K % S == 0 && K / S >= 128 && tiles * S <= 512 && std::abs(S - want) < std::abs(best - want)) best = S;
         return best;
     }
     void add(const Op& op, int nblocks) {
@@ -859,6 +860,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     Program pg;
     pg.scratch = c->trp_split; pg.scratch_left = c->trp_split_floats;
     pg.allow_split = !c->opt.train_no_split;
+    if (c->opt.train_split_min_k > 0) { pg.min_k = c->opt.train_split_min_k; pg.chain = c->opt.train_split_min_k; }
     auto blocks4 = [](int64_t rows) { return (rows + 3) / 4; };            // one wave per row, 4 rows per block
     auto blocks256 = [](int64_t n) { return (n + 255) / 256; };
     // column sums as products with a vector: out (1 x n) (+)= w^T (1 x rows) M (rows x n); w = ones, or per-row loss gradients
