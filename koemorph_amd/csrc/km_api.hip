@@ -58,6 +58,8 @@ int km_finalize(km_handle h, void* stream) {
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     for (MelPlan* p : c->mel_plans)
         if (int rc = upload_mel_plan(p)) return rc;
+    if (c->kind != 2)                                   // the front end's chunk counters exist before any launch could be captured
+        if (int rc = ensure_chunk_counters(c, 4096, stream)) return rc;
     c->dev_finalized = true;
     return KM_OK;
 }
