@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libkoemorph_hip.so")
-SOURCES = ["km_host.cpp", "km_wire.cpp", "km_core.hip", "km_mel.hip", "km_generic.hip", "km_koemorph.hip", "km_train.hip", "km_trainp.hip", "km_egemaps.hip", "km_data.hip", "km_api.hip"]
+SOURCES = ["km_host.cpp", "km_wire.cpp", "km_core.hip", "km_mel.hip", "km_generic.hip", "km_koemorph.hip", "km_kmmf.hip", "km_train.hip", "km_trainp.hip", "km_egemaps.hip", "km_data.hip", "km_api.hip"]
 HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(ROOT, "include", "koemorph.h")]
 
 

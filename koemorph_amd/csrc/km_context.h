@@ -70,6 +70,7 @@ struct Options {
     int mel_two_frame = 0;         // 1: two-frames-per-wave front end (A/B baseline)
     int emotion_separate = 0;      // 1: emotion logits in their own kernel
     int no_ln_fusion = 0, no_db_fusion = 0, no_score_fusion = 0, no_out_fusion = 0, no_v_fusion = 0;   // generic chain A/B
+    int kmm_no_fuse = 0;           // 1: KoeMorphModel as the launch-per-step chain even at the fused kernels' width (A/B, tests)
     int train_chain = 0;           // 1: training step as the round-1 launch-per-op chain (A/B reference; no dropout)
     int train_no_split = 0;        // 1: no split-K of the long gradient products of the phased training step (A/B)
     int train_dwce_parts = 0;      // > 0: partial sums of the channel-encoder gradient per step (a divisor of the batch; A/B)
@@ -98,6 +99,7 @@ struct Context {
     int legacy_hidden = 128;
     km_koemorph_config kmm{};                    // kind 2
     int64_t kmm_batch = 0, kmm_frames = 0;       // kind 2: reserved workspace (ws_generic)
+    bool kmm_fused = false;                      // kind 2: the model has the width of the fused kernels (km_kmmf.hip) and their blobs exist
     int d = 0, H = 0, hd = 0, T = 0, KT = 0, ED = 0, DH = 0, NB = 0, NK = 0;
     std::map<std::string, HostParam> params;     // reference state-dict tensors (fp32 masters)
     std::vector<std::string> param_order;

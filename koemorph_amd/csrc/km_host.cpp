@@ -20,6 +20,7 @@
 #include <cstring>
 
 #include "km_context.h"
+#include "km_kmmf.h"
 
 namespace km {
 
@@ -146,6 +147,82 @@ int finalize_host_legacy(Context* c) {
     return KM_OK;
 }
 
+// Weight blobs of the fused KoeMorphModel kernels (km_kmmf.hip; layout and the fragment packing: km_kmmf.h).  Built when the
+// model has the width those kernels are written for (the reference's defaults); anything else runs the launch-per-step chain.
+static void pack_frag(const std::vector<float>& W, int N, int K, int Kpad, float* dst) {
+    const int KB = Kpad / 16;
+    for (int t = 0; t < N / 16; ++t)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int n = 16 * t + (lane & 15), k = 16 * kb + 4 * (lane >> 4) + e;
+                    dst[(((size_t)t * KB + kb) * 64 + lane) * 4 + e] = k < K ? W[(size_t)n * K + k] : 0.f;
+                }
+}
+
+static bool build_kmmf_blobs(Context* c) {
+    using namespace kmmf;
+    const km_koemorph_config& k = c->kmm;
+    if (c->d != D || c->H != HEADS || c->NB != NQ || k.decoder_hidden_dim != HID || k.mel_dim % 16 || k.emotion_dim % 16 ||
+        k.mel_dim > D || k.emotion_dim > D || k.mel_dim <= 0 || k.emotion_dim <= 0 || k.num_attention_layers < 1)
+        return false;
+    auto Pv = [&](const std::string& n) -> const std::vector<float>& { return c->params.at(n).data; };
+    auto copy = [](const std::vector<float>& v, float* dst) { std::copy(v.begin(), v.end(), dst); };
+    const int LE = k.num_encoder_layers, LC = k.num_attention_layers, LD = k.decoder_layers;
+    std::vector<float> enc((size_t)2 * enc_stream_floats(LE), 0.f);
+    for (int s = 0; s < 2; ++s) {
+        float* b = enc.data() + (size_t)s * enc_stream_floats(LE);
+        const std::string st = s ? "emotion" : "mel";
+        const std::string e = "audio_encoder." + st + "_encoder.";
+        pack_frag(Pv(e + "0.weight"), D, s ? k.emotion_dim : k.mel_dim, D, b + ENC_W0);
+        copy(Pv(e + "0.bias"), b + ENC_B0);
+        copy(Pv(e + "3.weight"), b + ENC_LNG);
+        copy(Pv(e + "3.bias"), b + ENC_LNB);
+        for (int i = 0; i < LE; ++i) {
+            float* l = b + ENC_HEAD + (size_t)i * ENC_LAYER;
+            const std::string p = "audio_encoder." + st + "_transformer.layers." + std::to_string(i) + ".";
+            pack_frag(Pv(p + "self_attn.in_proj_weight"), 3 * D, D, D, l + EL_WIN);
+            copy(Pv(p + "self_attn.in_proj_bias"), l + EL_BIN);
+            pack_frag(Pv(p + "self_attn.out_proj.weight"), D, D, D, l + EL_WO);
+            copy(Pv(p + "self_attn.out_proj.bias"), l + EL_BO);
+            copy(Pv(p + "norm1.weight"), l + EL_N1G);
+            copy(Pv(p + "norm1.bias"), l + EL_N1B);
+            pack_frag(Pv(p + "linear1.weight"), FF, D, D, l + EL_W1);
+            copy(Pv(p + "linear1.bias"), l + EL_B1);
+            pack_frag(Pv(p + "linear2.weight"), D, FF, FF, l + EL_W2);
+            copy(Pv(p + "linear2.bias"), l + EL_B2);
+            copy(Pv(p + "norm2.weight"), l + EL_N2G);
+            copy(Pv(p + "norm2.bias"), l + EL_N2B);
+        }
+    }
+    std::vector<float> cross((size_t)LC * CROSS_LAYER, 0.f);
+    for (int i = 0; i < LC; ++i) {
+        float* l = cross.data() + (size_t)i * CROSS_LAYER;
+        const std::string p = "cross_attention_layers." + std::to_string(i) + ".";
+        pack_frag(Pv(p + "q_proj.weight"), D, D, D, l + CL_WQ);  copy(Pv(p + "q_proj.bias"), l + CL_BQ);
+        pack_frag(Pv(p + "k_proj.weight"), D, D, D, l + CL_WK);  copy(Pv(p + "k_proj.bias"), l + CL_BK);
+        pack_frag(Pv(p + "v_proj.weight"), D, D, D, l + CL_WV);  copy(Pv(p + "v_proj.bias"), l + CL_BV);
+        pack_frag(Pv(p + "out_proj.weight"), D, D, D, l + CL_WO);  copy(Pv(p + "out_proj.bias"), l + CL_BO);
+        copy(Pv("attention_layer_norms." + std::to_string(i) + ".weight"), l + CL_LNG);
+        copy(Pv("attention_layer_norms." + std::to_string(i) + ".bias"), l + CL_LNB);
+    }
+    std::vector<float> dec((size_t)DC_HEAD + (size_t)LD * DEC_LAYER, 0.f);
+    pack_frag(Pv("decoder.input_proj.weight"), HID, D, D, dec.data() + DC_WI);
+    copy(Pv("decoder.input_proj.bias"), dec.data() + DC_BI);
+    for (int i = 0; i < LD; ++i) {
+        float* l = dec.data() + DC_HEAD + (size_t)i * DEC_LAYER;
+        const std::string n = std::to_string(i);
+        pack_frag(Pv("decoder.hidden_layers." + n + ".weight"), HID, HID, HID, l + DL_W);
+        copy(Pv("decoder.hidden_layers." + n + ".bias"), l + DL_B);
+        copy(Pv("decoder.layer_norms." + n + ".weight"), l + DL_LNG);
+        copy(Pv("decoder.layer_norms." + n + ".bias"), l + DL_LNB);
+    }
+    put(c, "kmf_enc", std::move(enc));
+    put(c, "kmf_cross", std::move(cross));
+    put(c, "kmf_dec", std::move(dec));
+    return true;
+}
+
 // KoeMorphModel (gaussian_face.py:29-173): every tensor keeps the reference's layout (nn.Linear weights are (out, in) =
 // the B^T operand of the NT GEMM); the key / value projections of ALL cross-attention layers read the same encoded
 // audio, so they are stacked into one (2 L d, d) weight: one GEMM instead of 2 L.
@@ -163,6 +240,7 @@ int finalize_host_koemorph(Context* c) {
         }
     put(c, "kmm_kv_w", std::move(w));
     put(c, "kmm_kv_b", std::move(b));
+    c->kmm_fused = build_kmmf_blobs(c);
     c->fused_ok = false;
     c->host_finalized = true;
     return KM_OK;
@@ -540,7 +618,7 @@ const OptName kOptNames[] = {
     {"generic_staged", &Options::generic_staged}, {"mel_two_frame", &Options::mel_two_frame},
     {"emotion_separate", &Options::emotion_separate}, {"no_ln_fusion", &Options::no_ln_fusion},
     {"no_db_fusion", &Options::no_db_fusion}, {"no_score_fusion", &Options::no_score_fusion},
-    {"no_out_fusion", &Options::no_out_fusion}, {"no_v_fusion", &Options::no_v_fusion}, {"train_chain", &Options::train_chain},
+    {"no_out_fusion", &Options::no_out_fusion}, {"no_v_fusion", &Options::no_v_fusion}, {"train_chain", &Options::train_chain}, {"kmm_no_fuse", &Options::kmm_no_fuse},
     {"train_no_split", &Options::train_no_split}, {"train_dwce_parts", &Options::train_dwce_parts},
     {"train_tail_groups", &Options::train_tail_groups}, {"train_split_min_k", &Options::train_split_min_k},
 };

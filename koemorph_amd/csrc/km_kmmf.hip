@@ -1,0 +1,434 @@
+// Fused kernels of the legacy KoeMorphModel forward (src/model/gaussian_face.py:175-268) at the reference's default width
+// (d_model 256, 8 heads, 52 queries, decoder 128, windows of <= 32 frames).  Two launches replace the ~75 of the
+// launch-per-step chain in km_koemorph.hip:
+//
+//   kmmf_encoder_kernel   DualStreamEncoder (dual_stream_attention.py:369-388): one workgroup = TWO windows of ONE stream
+//                         (64 rows = 4 MFMA row tiles, window w on rows 32 w .. 32 w + T - 1), input projection + ReLU +
+//                         LayerNorm and every post-norm transformer layer with the rows resident in LDS.
+//   kmmf_decode_kernel    (km_kmmf_decode.h) the cross-attention stack + BlendshapeDecoder + output tail, one workgroup per window.
+//
+// All products are exact-fp32 v_mfma_f32_16x16x4_f32.  Activations are the A operand out of an LDS image [row][264] (one
+// ds_read_b128 = the operand of four MFMAs, stride 264 = 8 mod 64 dwords: conflict-free for the instruction's lane groups);
+// weights are the B operand straight from L2 in the fragment-packed images of km_kmmf.h (one k block prefetched), never
+// staged: a workgroup owns all 64 rows, so every weight fragment is used by 4 row tiles x 4 MFMAs and nobody else in the
+// workgroup needs it.  Attention never leaves the registers: Q_h^T and K_h^T are produced TRANSPOSED (W x^T: weight
+// fragments as the A operand), so a C-layout tile holds 4 consecutive head dimensions per lane = the operand of the four
+// MFMAs that contract them; S^T = K_h Q_h^T, the softmax runs over the rows of S^T (4 in-lane values x 2 tiles, then lanes
+// l ^ 16, l ^ 32), P^T is the B operand of O^T = V_h^T P^T as it stands, and O^T leaves as 16-byte LDS stores.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <string>
+
+#include "km_context.h"
+#include "km_gemm.h"
+#include "km_kmmf.h"
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return km::fail(KM_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace km {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define KM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+namespace kf {
+using namespace kmmf;
+constexpr int NTH = 512;             // threads per workgroup (8 waves: wave = head in the attention phases, = 32 columns elsewhere)
+constexpr int NW = 8;
+constexpr int XS = 264;              // row stride of the LDS images (floats)
+constexpr int IMG = 64 * XS;         // one 64-row image
+constexpr int KBD = D / 16;          // k blocks of a 256-wide contraction
+constexpr int RED = 2 * 64 * NW + 2 * 64;   // LayerNorm partials [pass][row][wave] + totals [pass][row]
+constexpr int ENC_LDS_FLOATS = 2 * IMG + RED;
+
+__device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes of a DPP row, in every lane
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+// acc[mt][nt] += X[16 mt + ..][16 kb ..] . W[16 (t0 + nt) + ..][16 (kb0 + kb) ..]^T over nkb k blocks.
+// X: LDS image (k block 0 of the contraction at column 0); wp: fragment-packed weight of kbs k blocks per tile.
+template <int MT, int NTW>
+__device__ __forceinline__ void mm_cols(f32x4 (&acc)[MT][NTW], const float* X, const float* wp, int t0, int kbs, int kb0, int nkb, int lane) {
+    const int g = lane >> 4, j = lane & 15;
+    const float* xp = X + j * XS + 4 * g;
+    const f32x4* w = reinterpret_cast<const f32x4*>(wp) + ((size_t)t0 * kbs + kb0) * 64 + lane;
+    f32x4 b[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) b[nt] = w[(size_t)nt * kbs * 64];
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int kn = kb + 1 < nkb ? kb + 1 : kb;
+        f32x4 bn[NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) bn[nt] = w[((size_t)nt * kbs + kn) * 64];
+        f32x4 a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(xp + 16 * mt * XS + 16 * kb);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = KM_MFMA(a[mt][s], b[nt][s], acc[mt][nt]);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) b[nt] = bn[nt];
+    }
+}
+
+// LayerNorm (two-pass, eps 1e-5) over rows whose DCOLS columns are spread over the 8 waves (NTW column tiles each, C layout),
+// then dst[row][col0 + 16 nt + j] = the normalised value for rows < row_limit.  Two barriers per pass (partials -> totals).
+// The caller fences dst against its readers.
+template <int NTW, int DCOLS>
+__device__ __forceinline__ void ln_store(f32x4 (&v)[4][NTW], float* red, const float* gam, const float* bet, float* dst, int col0,
+                                         int row_limit, int wave, int lane, int tid) {
+    const int g = lane >> 4, j = lane & 15;
+    float mean[4][4], rstd[4][4];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float* P = red + pass * (64 * NW);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    if (pass == 0) s += v[mt][nt][r];
+                    else { const float dlt = v[mt][nt][r] - mean[mt][r]; s += dlt * dlt; }
+                }
+                s = row16_sum(s);
+                if (j == 0) P[(16 * mt + 4 * g + r) * NW + wave] = s;
+            }
+        __syncthreads();
+        float* Tt = red + 2 * 64 * NW + pass * 64;
+        if (tid < 64) {
+            const f32x4* pr = reinterpret_cast<const f32x4*>(P + tid * NW);
+            const f32x4 lo = pr[0], hi = pr[1];
+            float s = 0.f;
+            s += lo[0]; s += lo[1]; s += lo[2]; s += lo[3];
+            s += hi[0]; s += hi[1]; s += hi[2]; s += hi[3];
+            Tt[tid] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(Tt + 16 * mt + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (pass == 0) mean[mt][r] = t4[r] * (1.0f / DCOLS);
+                else rstd[mt][r] = 1.0f / sqrtf(t4[r] * (1.0f / DCOLS) + 1e-5f);
+            }
+        }
+    }
+    float gm[NTW], bt[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) { gm[nt] = gam[col0 + 16 * nt + j]; bt[nt] = bet[col0 + 16 * nt + j]; }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + 4 * g + r;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                v[mt][nt][r] = (v[mt][nt][r] - mean[mt][r]) * rstd[mt][r] * gm[nt] + bt[nt];
+                if (row < row_limit) dst[row * XS + col0 + 16 * nt + j] = v[mt][nt][r];
+            }
+        }
+}
+
+// One head (= this wave) of an attention layer with everything in registers.
+//   Xq: LDS image of the query rows (QT row tiles), Xk: image of the key / value rows (KTT row tiles); NWIN windows share the
+//   images: window w owns query tiles [w QT / NWIN, ...) and key tiles [2 w, 2 w + 2) (a window's keys are two tiles = 32 rows).
+//   wq / wk / wv: fragment-packed (256-wide) projections already offset to this head's first tile (16 k blocks per tile),
+//   bq / bk / bv: their biases offset to this head's first column.  scale multiplies q (after its bias), as torch does.
+//   mask(w, key, q) -> true when key `key` of window w may be attended by query q (row index inside the window).
+//   O^T -> Yo[query row][32 h + dim] for query rows < q_limit.  attn (or null): P -> attn[(w) ...] through store_p(w, q, key, p).
+template <int QT, int KTT, int NWIN, bool SELF, class Mask, class StoreP>
+__device__ __forceinline__ void attention_head(const float* Xq, const float* Xk, const float* wq, const float* wk, const float* wv,
+                                               const float* bq, const float* bk, const float* bv, float scale, float* Yo, int head,
+                                               int q_limit, int lane, Mask mask, StoreP store_p) {
+    constexpr int QW = QT / NWIN;
+    static_assert(KTT == 2 * NWIN, "a window's keys are two row tiles");
+    const int g = lane >> 4, j = lane & 15;
+    f32x4 qT[2][QT], kT[2][KTT], vv[KTT][2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) qT[dt][t] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < KTT; ++t) { kT[dt][t] = f32x4{0, 0, 0, 0}; vv[t][dt] = f32x4{0, 0, 0, 0}; }
+    }
+    {
+        const f32x4* pq = reinterpret_cast<const f32x4*>(wq) + lane;
+        const f32x4* pk = reinterpret_cast<const f32x4*>(wk) + lane;
+        const f32x4* pv = reinterpret_cast<const f32x4*>(wv) + lane;
+        const float* xq = Xq + j * XS + 4 * g;
+        const float* xk = Xk + j * XS + 4 * g;
+        f32x4 fq[2], fk[2], fv[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) { fq[dt] = pq[dt * KBD * 64]; fk[dt] = pk[dt * KBD * 64]; fv[dt] = pv[dt * KBD * 64]; }
+        for (int kb = 0; kb < KBD; ++kb) {
+            const int kn = kb + 1 < KBD ? kb + 1 : kb;
+            f32x4 nq[2], nk[2], nv[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                nq[dt] = pq[(dt * KBD + kn) * 64]; nk[dt] = pk[(dt * KBD + kn) * 64]; nv[dt] = pv[(dt * KBD + kn) * 64];
+            }
+            f32x4 aq[QT], ak[KTT];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) aq[t] = *reinterpret_cast<const f32x4*>(xq + 16 * t * XS + 16 * kb);
+#pragma unroll
+            for (int t = 0; t < KTT; ++t) {
+                if constexpr (SELF) ak[t] = aq[t];
+                else ak[t] = *reinterpret_cast<const f32x4*>(xk + 16 * t * XS + 16 * kb);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) qT[dt][t] = KM_MFMA(fq[dt][s], aq[t][s], qT[dt][t]);       // Q^T = Wq x^T
+#pragma unroll
+                    for (int t = 0; t < KTT; ++t) kT[dt][t] = KM_MFMA(fk[dt][s], ak[t][s], kT[dt][t]);     // K^T = Wk x^T
+#pragma unroll
+                    for (int t = 0; t < KTT; ++t) vv[t][dt] = KM_MFMA(ak[t][s], fv[dt][s], vv[t][dt]);     // V = x Wv^T
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) { fq[dt] = nq[dt]; fk[dt] = nk[dt]; fv[dt] = nv[dt]; }
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const f32x4 b4q = *reinterpret_cast<const f32x4*>(bq + 16 * dt + 4 * g);
+        const f32x4 b4k = *reinterpret_cast<const f32x4*>(bk + 16 * dt + 4 * g);
+        const float bvj = bv[16 * dt + j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) qT[dt][t][r] = (qT[dt][t][r] + b4q[r]) * scale;
+#pragma unroll
+            for (int t = 0; t < KTT; ++t) { kT[dt][t][r] += b4k[r]; vv[t][dt][r] += bvj; }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < NWIN; ++w) {
+        f32x4 S[2][QW];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < QW; ++qt) {
+                f32x4 c = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) c = KM_MFMA(kT[dt][2 * w + kt][s], qT[dt][QW * w + qt][s], c);   // S^T[key][query]
+                S[kt][qt] = c;
+            }
+        // masked softmax over the keys (the rows of S^T) of each query column
+#pragma unroll
+        for (int qt = 0; qt < QW; ++qt) {
+            const int q = 16 * qt + j;
+            float m = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (!mask(w, 16 * kt + 4 * g + r, q)) S[kt][qt][r] = -INFINITY;
+                    m = fmaxf(m, S[kt][qt][r]);
+                }
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { S[kt][qt][r] = expf(S[kt][qt][r] - m); sum += S[kt][qt][r]; }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    S[kt][qt][r] *= inv;
+                    store_p(w, q, 16 * kt + 4 * g + r, S[kt][qt][r]);
+                }
+        }
+        // O^T[dim][query] = sum over keys V[key][dim] P^T[key][query]
+#pragma unroll
+        for (int qt = 0; qt < QW; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                f32x4 o = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) o = KM_MFMA(vv[2 * w + kt][dt][s], S[kt][qt][s], o);
+                const int row = 16 * (QW * w + qt) + j;
+                if (row < q_limit) *reinterpret_cast<f32x4*>(Yo + row * XS + 32 * head + 16 * dt + 4 * g) = o;
+            }
+    }
+}
+
+struct EncArgs {
+    const float* in0; const float* in1;       // (B, T, in_dim) of the mel / emotion stream
+    int in_dim0, in_dim1;
+    const float* blob; int64_t stream_floats; int layers;
+    const unsigned char* kvalid;              // (B, T), 1 = attend, or null (src_key_padding_mask)
+    float* out0; float* out1;                 // (B, T, 256)
+    int B, T;
+};
+
+__global__ __launch_bounds__(512) void kmmf_encoder_kernel(EncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;
+    float* Y = smem + IMG;
+    float* red = smem + 2 * IMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int stream = blockIdx.y, w0 = 2 * blockIdx.x, T = a.T;
+    const float* in = stream ? a.in1 : a.in0;
+    const int in_dim = stream ? a.in_dim1 : a.in_dim0;
+    float* out = stream ? a.out1 : a.out0;
+    const float* blob = a.blob + stream * a.stream_floats;
+    const int col0 = 32 * wave;
+
+    // key padding masks of the two windows as bit masks (bit t = key t may be attended); a window past the batch has none
+    unsigned kmask[2];
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const int b = w0 + w;
+        const bool ok = b < a.B && lane < T && (!a.kvalid || a.kvalid[(int64_t)b * T + lane]);
+        kmask[w] = (unsigned)__ballot(ok);
+    }
+    // ---- input rows -> X (columns >= in_dim and rows without a frame are zero) ----
+    for (int i = tid; i < 64 * 64; i += NTH) {
+        const int r = i >> 6, c4 = i & 63, b = w0 + (r >> 5), t = r & 31;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < a.B && t < T && 4 * c4 < in_dim) v = *reinterpret_cast<const float4*>(in + ((int64_t)b * T + t) * in_dim + 4 * c4);
+        *reinterpret_cast<float4*>(X + r * XS + 4 * c4) = v;
+    }
+    __syncthreads();
+    // ---- x = LayerNorm(ReLU(in W0^T + b0))   (dual_stream_attention.py:369-388) -> Y ----
+    {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = f32x4{0, 0, 0, 0}; acc[mt][1] = f32x4{0, 0, 0, 0}; }
+        mm_cols<4, 2>(acc, X, blob + ENC_W0, 2 * wave, KBD, 0, in_dim / 16, lane);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float bb = blob[ENC_B0 + col0 + 16 * nt + j];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float v = acc[mt][nt][r] + bb; acc[mt][nt][r] = v < 0.f ? 0.f : v; }
+        }
+        ln_store<2, D>(acc, red, blob + ENC_LNG, blob + ENC_LNB, Y, col0, 64, wave, lane, tid);
+    }
+    __syncthreads();
+    float* xc = Y;      // the rows
+    float* xo = X;      // attention output / feed-forward hidden chunk
+    const float scale = 1.0f / sqrtf((float)HD);
+    for (int layer = 0; layer < a.layers; ++layer) {
+        const float* L = blob + ENC_HEAD + (int64_t)layer * ENC_LAYER;
+        // ---- self-attention, wave = head ----
+        attention_head<4, 4, 2, true>(
+            xc, xc, L + EL_WIN + (int64_t)(2 * wave) * KBD * 256, L + EL_WIN + (int64_t)(16 + 2 * wave) * KBD * 256,
+            L + EL_WIN + (int64_t)(32 + 2 * wave) * KBD * 256, L + EL_BIN + 32 * wave, L + EL_BIN + D + 32 * wave,
+            L + EL_BIN + 2 * D + 32 * wave, scale, xo, wave, 64, lane,
+            [&](int w, int key, int) { return ((kmask[w] >> key) & 1u) != 0; }, [](int, int, int, float) {});
+        __syncthreads();
+        // ---- x = LN1(x + out_proj(O)) ----
+        {
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = f32x4{0, 0, 0, 0}; acc[mt][1] = f32x4{0, 0, 0, 0}; }
+            mm_cols<4, 2>(acc, xo, L + EL_WO, 2 * wave, KBD, 0, KBD, lane);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float bb = L[EL_BO + col0 + 16 * nt + j];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mt][nt][r] += bb + xc[(16 * mt + 4 * g + r) * XS + col0 + 16 * nt + j];
+            }
+            ln_store<2, D>(acc, red, L + EL_N1G, L + EL_N1B, xc, col0, 64, wave, lane, tid);
+        }
+        __syncthreads();
+        // ---- x = LN2(x + W2 gelu(W1 x + b1) + b2), the hidden layer in four chunks of 256 through xo ----
+        {
+            f32x4 y2[4][2];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) { y2[mt][0] = f32x4{0, 0, 0, 0}; y2[mt][1] = f32x4{0, 0, 0, 0}; }
+            for (int c = 0; c < FF / D; ++c) {
+                f32x4 h[4][2];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) { h[mt][0] = f32x4{0, 0, 0, 0}; h[mt][1] = f32x4{0, 0, 0, 0}; }
+                mm_cols<4, 2>(h, xc, L + EL_W1, 16 * c + 2 * wave, KBD, 0, KBD, lane);
+                if (c > 0) __syncthreads();          // the previous chunk's readers of xo
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float bb = L[EL_B1 + D * c + col0 + 16 * nt + j];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            xo[(16 * mt + 4 * g + r) * XS + col0 + 16 * nt + j] = gemm_act(h[mt][nt][r] + bb, 2);
+                }
+                __syncthreads();
+                mm_cols<4, 2>(y2, xo, L + EL_W2, 2 * wave, FF / 16, KBD * c, KBD, lane);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float bb = L[EL_B2 + col0 + 16 * nt + j];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y2[mt][nt][r] += bb + xc[(16 * mt + 4 * g + r) * XS + col0 + 16 * nt + j];
+            }
+            ln_store<2, D>(y2, red, L + EL_N2G, L + EL_N2B, xc, col0, 64, wave, lane, tid);
+        }
+        __syncthreads();
+    }
+    // ---- rows -> (B, T, 256) ----
+    for (int i = tid; i < 64 * 64; i += NTH) {
+        const int r = i >> 6, c4 = i & 63, b = w0 + (r >> 5), t = r & 31;
+        if (b < a.B && t < T) *reinterpret_cast<float4*>(out + ((int64_t)b * T + t) * D + 4 * c4) = *reinterpret_cast<const float4*>(xc + r * XS + 4 * c4);
+    }
+}
+
+}  // namespace kf
+
+static const float* dvp(Context* c, const char* name) { return c->packed.at(name).dev; }
+
+bool koemorph_fused_ok(Context* c, int64_t B, int64_t T, const float* mel, const float* emo) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return c->kmm_fused && !c->opt.kmm_no_fuse && T >= 1 && T <= kmmf::TMAX && B >= 1 && al(mel) && al(emo);
+}
+
+// both streams of DualStreamEncoder: xm, xe (B, T, 256)
+int launch_kmmf_encoder(Context* c, const float* mel, const float* emo, int64_t B, int64_t T, const unsigned char* kvalid, float* xm,
+                        float* xe, void* stream) {
+    static PerDeviceOnce once;
+    if (once.first(c->device))
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kf::kmmf_encoder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kf::ENC_LDS_FLOATS * 4));
+    kf::EncArgs a{};
+    a.in0 = mel; a.in1 = emo; a.in_dim0 = c->kmm.mel_dim; a.in_dim1 = c->kmm.emotion_dim;
+    a.blob = dvp(c, "kmf_enc"); a.stream_floats = kmmf::enc_stream_floats(c->kmm.num_encoder_layers); a.layers = c->kmm.num_encoder_layers;
+    a.kvalid = kvalid; a.out0 = xm; a.out1 = xe; a.B = (int)B; a.T = (int)T;
+    hipLaunchKernelGGL(kf::kmmf_encoder_kernel, dim3((unsigned)((B + 1) / 2), 2), dim3(kf::NTH), kf::ENC_LDS_FLOATS * 4, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+}  // namespace km

@@ -21,6 +21,11 @@ namespace km {
 
 static const float* dv(Context* c, const std::string& name) { return c->packed.at(name).dev; }
 
+// km_kmmf.hip: the fused kernels for the reference's default width
+bool koemorph_fused_ok(Context* c, int64_t B, int64_t T, const float* mel, const float* emo);
+int launch_kmmf_encoder(Context* c, const float* mel, const float* emo, int64_t B, int64_t T, const unsigned char* kvalid, float* xm,
+                        float* xe, void* stream);
+
 // LayerNorm over the last dimension, in place, one wave per row (two-pass, eps 1e-5)
 __global__ __launch_bounds__(256) void kmm_ln_rows_kernel(float* __restrict__ x, int64_t rows, int d,
                                                           const float* __restrict__ gam, const float* __restrict__ bet) {
@@ -287,8 +292,13 @@ int launch_koemorph(Context* c, const float* mel, const float* emo, int64_t B, i
     float* cond = dB + RQ * hid;
     float* cond1 = cond + B * d;
     // ---- DualStreamEncoder on both streams, then the average (gaussian_face.py:203-209) ----
-    if (int rc = encode_stream(c, "mel", mel, k.mel_dim, B, T, kvalid, xm, qkv, S, O, ffn, st)) return rc;
-    if (int rc = encode_stream(c, "emotion", emo, k.emotion_dim, B, T, kvalid, xe, qkv, S, O, ffn, st)) return rc;
+    const bool fused = koemorph_fused_ok(c, B, T, mel, emo);
+    if (fused) {
+        if (int rc = launch_kmmf_encoder(c, mel, emo, B, T, kvalid, xm, xe, stream)) return rc;
+    } else {
+        if (int rc = encode_stream(c, "mel", mel, k.mel_dim, B, T, kvalid, xm, qkv, S, O, ffn, st)) return rc;
+        if (int rc = encode_stream(c, "emotion", emo, k.emotion_dim, B, T, kvalid, xe, qkv, S, O, ffn, st)) return rc;
+    }
     hipLaunchKernelGGL(kmm_avg_kernel, dim3((unsigned)((R * d + 255) / 256)), dim3(256), 0, st, xm, xe, xm, R * d);
     // ---- queries (attention.py:481-514) ----
     if (prev) {

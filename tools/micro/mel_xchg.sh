@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../.."
 mkdir -p tools/micro/bin/obj
 CS=koemorph_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$CS -Wno-unused-function"
-OTHERS="km_host.cpp km_wire.cpp km_core.hip km_generic.hip km_koemorph.hip km_train.hip km_trainp.hip km_egemaps.hip km_data.hip km_api.hip"
+OTHERS="km_host.cpp km_wire.cpp km_core.hip km_generic.hip km_koemorph.hip km_kmmf.hip km_train.hip km_trainp.hip km_egemaps.hip km_data.hip km_api.hip"
 for f in $OTHERS; do
     o=tools/micro/bin/obj/${f%.*}.o
     newest=$(ls -t $CS/$f $CS/*.h include/*.h | head -1)
