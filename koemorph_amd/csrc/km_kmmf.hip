@@ -5,7 +5,8 @@
 //   kmmf_encoder_kernel   DualStreamEncoder (dual_stream_attention.py:369-388): one workgroup = TWO windows of ONE stream
 //                         (64 rows = 4 MFMA row tiles, window w on rows 32 w .. 32 w + T - 1), input projection + ReLU +
 //                         LayerNorm and every post-norm transformer layer with the rows resident in LDS.
-//   kmmf_decode_kernel    (km_kmmf_decode.h) the cross-attention stack + BlendshapeDecoder + output tail, one workgroup per window.
+//   kmmf_decode_kernel    average of the two encodings, query embeddings (+ conditioning net), every cross-attention layer,
+//                         BlendshapeDecoder and the output tail: one workgroup per window, the 52 query rows resident in LDS.
 //
 // All products are exact-fp32 v_mfma_f32_16x16x4_f32.  Activations are the A operand out of an LDS image [row][264] (one
 // ds_read_b128 = the operand of four MFMAs, stride 264 = 8 mod 64 dwords: conflict-free for the instruction's lane groups);
@@ -32,6 +33,8 @@
     } while (0)
 
 namespace km {
+
+#include "km_kmm_tail.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define KM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -84,9 +87,10 @@ __device__ __forceinline__ void mm_cols(f32x4 (&acc)[MT][NTW], const float* X, c
 }
 
 // LayerNorm (two-pass, eps 1e-5) over rows whose DCOLS columns are spread over the 8 waves (NTW column tiles each, C layout),
-// then dst[row][col0 + 16 nt + j] = the normalised value for rows < row_limit.  Two barriers per pass (partials -> totals).
+// then (STORE) dst[row][col0 + 16 nt + j] = the normalised value (which v holds afterwards) for rows < row_limit.  Two barriers
+// per pass (partials -> totals).
 // The caller fences dst against its readers.
-template <int NTW, int DCOLS>
+template <int NTW, int DCOLS, bool STORE = true>
 __device__ __forceinline__ void ln_store(f32x4 (&v)[4][NTW], float* red, const float* gam, const float* bet, float* dst, int col0,
                                          int row_limit, int wave, int lane, int tid) {
     const int g = lane >> 4, j = lane & 15;
@@ -139,7 +143,7 @@ __device__ __forceinline__ void ln_store(f32x4 (&v)[4][NTW], float* red, const f
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 v[mt][nt][r] = (v[mt][nt][r] - mean[mt][r]) * rstd[mt][r] * gm[nt] + bt[nt];
-                if (row < row_limit) dst[row * XS + col0 + 16 * nt + j] = v[mt][nt][r];
+                if (STORE && row < row_limit) dst[row * XS + col0 + 16 * nt + j] = v[mt][nt][r];
             }
         }
 }
@@ -406,6 +410,187 @@ __global__ __launch_bounds__(512) void kmmf_encoder_kernel(EncArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// kmmf_decode_kernel: gaussian_face.py:209-268 for one window per workgroup.
+// LDS: X = the 52 query rows [52][264], Y = attention output / decoder ping-pong [52][264], A = the averaged encoding
+// [32][264] (keys and values of every layer), LayerNorm partials.  MFMA row tiles 3's rows 52..63 read whatever follows the
+// image (rows are independent in every product, and nothing is stored for them).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int QIMG = NQ * XS;
+constexpr int DEC_LDS_FLOATS = 2 * QIMG + TMAX * XS + RED + 64;
+
+struct DecArgs {
+    const float* xm; const float* xe;          // (B, T, 256) the two encodings
+    const float* emb;                          // query_embeddings (52, 256)
+    const float* cw0; const float* cb0; const float* cw3; const float* cb3;    // conditioning_net (attention.py:481-514)
+    const float* prev;                         // (B, 52) or null
+    const float* cross; int cross_layers;
+    const float* dec; int dec_layers; int act; // gemm_act code of the decoder
+    const unsigned char* kvalid; int causal, window;
+    float* attn;                               // (L, B, 8, 52, T) or null
+    int B, T;
+    KmmTail tail;
+};
+
+__global__ __launch_bounds__(512) void kmmf_decode_kernel(DecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;
+    float* Y = smem + QIMG;
+    float* A = smem + 2 * QIMG;
+    float* red = A + TMAX * XS;
+    float* ys = red + RED;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int b = blockIdx.x, T = a.T;
+    const int col0 = 32 * wave;
+
+    const unsigned kmask = (unsigned)__ballot(lane < T && (!a.kvalid || a.kvalid[(int64_t)b * T + lane]));
+    // ---- conditioning (attention.py:500-512): cond = W3 relu(W0 prev + b0) + b3, through `red` ----
+    if (a.prev) {
+        if (tid < 128) {
+            const float* w = a.cw0 + tid * NQ;
+            const float* p = a.prev + (int64_t)b * NQ;
+            float s = 0.f;
+            for (int k = 0; k < NQ; ++k) s = fmaf(w[k], p[k], s);
+            s += a.cb0[tid];
+            red[tid] = s < 0.f ? 0.f : s;
+        }
+        __syncthreads();
+        if (tid < D) {
+            const float4* w = reinterpret_cast<const float4*>(a.cw3 + tid * 128);
+            float s = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+                const float4 wv = w[k];
+                const float4 hv = *reinterpret_cast<const float4*>(red + 4 * k);
+                s = fmaf(wv.x, hv.x, s); s = fmaf(wv.y, hv.y, s); s = fmaf(wv.z, hv.z, s); s = fmaf(wv.w, hv.w, s);
+            }
+            red[128 + tid] = s + a.cb3[tid];
+        }
+        __syncthreads();
+    }
+    // ---- x = embeddings (+ cond); A = (xm + xe) / 2, rows >= T zero ----
+    for (int i = tid; i < NQ * 64; i += NTH) {
+        const int q = i >> 6, c4 = i & 63;
+        float4 v = *reinterpret_cast<const float4*>(a.emb + q * D + 4 * c4);
+        if (a.prev) {
+            const float4 cv = *reinterpret_cast<const float4*>(red + 128 + 4 * c4);
+            v.x += cv.x; v.y += cv.y; v.z += cv.z; v.w += cv.w;
+        }
+        *reinterpret_cast<float4*>(X + q * XS + 4 * c4) = v;
+    }
+    for (int i = tid; i < TMAX * 64; i += NTH) {
+        const int t = i >> 6, c4 = i & 63;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < T) {
+            const float4 m = *reinterpret_cast<const float4*>(a.xm + ((int64_t)b * T + t) * D + 4 * c4);
+            const float4 e = *reinterpret_cast<const float4*>(a.xe + ((int64_t)b * T + t) * D + 4 * c4);
+            v = make_float4((m.x + e.x) / 2.0f, (m.y + e.y) / 2.0f, (m.z + e.z) / 2.0f, (m.w + e.w) / 2.0f);
+        }
+        *reinterpret_cast<float4*>(A + t * XS + 4 * c4) = v;
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)HD);                       // (head_dim * temperature)^-0.5, temperature 1
+    for (int layer = 0; layer < a.cross_layers; ++layer) {
+        const float* L = a.cross + (int64_t)layer * CROSS_LAYER;
+        float* ap = a.attn ? a.attn + ((((int64_t)layer * a.B + b) * HEADS + wave) * NQ) * T : nullptr;
+        attention_head<4, 2, 1, false>(
+            X, A, L + CL_WQ + (int64_t)(2 * wave) * KBD * 256, L + CL_WK + (int64_t)(2 * wave) * KBD * 256,
+            L + CL_WV + (int64_t)(2 * wave) * KBD * 256, L + CL_BQ + 32 * wave, L + CL_BK + 32 * wave, L + CL_BV + 32 * wave, scale, Y,
+            wave, NQ, lane,
+            [&](int, int key, int q) {          // attention.py:208-246: causal and local-window masks, key padding
+                int lo = 0, hi = T;
+                if (a.window >= 0) {
+                    const int kp = (q * T) / NQ;
+                    lo = kp - a.window / 2 > 0 ? kp - a.window / 2 : 0;
+                    hi = kp + a.window / 2 + 1 < T ? kp + a.window / 2 + 1 : T;
+                }
+                if (a.causal && q + 1 < hi) hi = q + 1;
+                return key >= lo && key < hi && ((kmask >> key) & 1u) != 0;
+            },
+            [&](int, int q, int key, float p) { if (ap && q < NQ && key < T) ap[q * T + key] = p; });
+        __syncthreads();
+        // ---- x = LN(out_proj(O) + x)   (gaussian_face.py:230-231) ----
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = f32x4{0, 0, 0, 0}; acc[mt][1] = f32x4{0, 0, 0, 0}; }
+        mm_cols<4, 2>(acc, Y, L + CL_WO, 2 * wave, KBD, 0, KBD, lane);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float bb = L[CL_BO + col0 + 16 * nt + j];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mt][nt][r] += bb + X[(16 * mt + 4 * g + r) * XS + col0 + 16 * nt + j];
+        }
+        ln_store<2, D>(acc, red, L + CL_LNG, L + CL_LNB, X, col0, NQ, wave, lane, tid);
+        __syncthreads();
+    }
+    // ---- BlendshapeDecoder (decoder.py:131-177): wave = 16 hidden units ----
+    float* cur = Y;
+    float* nxt = X;
+    {
+        f32x4 acc[4][1];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][0] = f32x4{0, 0, 0, 0};
+        mm_cols<4, 1>(acc, X, a.dec + DC_WI, wave, KBD, 0, KBD, lane);
+        const float bb = a.dec[DC_BI + 16 * wave + j];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * mt + 4 * g + r;
+                if (row < NQ) cur[row * XS + 16 * wave + j] = gemm_act(acc[mt][0][r] + bb, a.act);
+            }
+    }
+    __syncthreads();
+    for (int layer = 0; layer < a.dec_layers; ++layer) {
+        const float* L = a.dec + DC_HEAD + (int64_t)layer * DEC_LAYER;
+        f32x4 acc[4][1];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][0] = f32x4{0, 0, 0, 0};
+        mm_cols<4, 1>(acc, cur, L + DL_W, wave, HID / 16, 0, HID / 16, lane);
+        const float bb = L[DL_B + 16 * wave + j];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][0][r] += bb;
+        ln_store<1, HID, false>(acc, red, L + DL_LNG, L + DL_LNB, nullptr, 16 * wave, NQ, wave, lane, tid);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                       // x = act(LN(.)) + x   (decoder.py:147-152)
+                const int row = 16 * mt + 4 * g + r;
+                if (row < NQ) nxt[row * XS + 16 * wave + j] = gemm_act(acc[mt][0][r], a.act) + cur[row * XS + 16 * wave + j];
+            }
+        __syncthreads();
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    // ---- output_proj (row q of the weight for query q), eight lanes per query, then the tail ----
+    {
+        const int q = tid >> 3, part = tid & 7;
+        float s = 0.f;
+        if (q < NQ) {
+            const float4* hr = reinterpret_cast<const float4*>(cur + q * XS + 16 * part);
+            const float4* wr = reinterpret_cast<const float4*>(a.tail.wout + q * HID + 16 * part);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 hv = hr[k], wv = wr[k];
+                s = fmaf(hv.x, wv.x, s); s = fmaf(hv.y, wv.y, s); s = fmaf(hv.z, wv.z, s); s = fmaf(hv.w, wv.w, s);
+            }
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (q < NQ && part == 0) ys[q] = s + a.tail.bout[q];
+    }
+    __syncthreads();
+    const float z = tid < NQ ? ys[tid] : 0.f;
+    __syncthreads();
+    kmm_tail_dev(a.tail, b, tid, z, ys);
+}
+
 }  // namespace kf
 
 static const float* dvp(Context* c, const char* name) { return c->packed.at(name).dev; }
@@ -427,6 +612,29 @@ int launch_kmmf_encoder(Context* c, const float* mel, const float* emo, int64_t 
     a.blob = dvp(c, "kmf_enc"); a.stream_floats = kmmf::enc_stream_floats(c->kmm.num_encoder_layers); a.layers = c->kmm.num_encoder_layers;
     a.kvalid = kvalid; a.out0 = xm; a.out1 = xe; a.B = (int)B; a.T = (int)T;
     hipLaunchKernelGGL(kf::kmmf_encoder_kernel, dim3((unsigned)((B + 1) / 2), 2), dim3(kf::NTH), kf::ENC_LDS_FLOATS * 4, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+
+// everything after the encoders: average, queries, cross-attention layers, decoder, tail
+int launch_kmmf_decode(Context* c, const float* xm, const float* xe, int64_t B, int64_t T, const unsigned char* kvalid, const float* prev,
+                       float* attn, const KmmTail& tail, void* stream) {
+    static PerDeviceOnce once;
+    if (once.first(c->device))
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kf::kmmf_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kf::DEC_LDS_FLOATS * 4));
+    const km_koemorph_config& k = c->kmm;
+    kf::DecArgs a{};
+    a.xm = xm; a.xe = xe; a.emb = dvp(c, "query_embeddings.query_embeddings");
+    a.cw0 = dvp(c, "query_embeddings.conditioning_net.0.weight"); a.cb0 = dvp(c, "query_embeddings.conditioning_net.0.bias");
+    a.cw3 = dvp(c, "query_embeddings.conditioning_net.3.weight"); a.cb3 = dvp(c, "query_embeddings.conditioning_net.3.bias");
+    a.prev = prev; a.cross = dvp(c, "kmf_cross"); a.cross_layers = k.num_attention_layers;
+    a.dec = dvp(c, "kmf_dec"); a.dec_layers = k.decoder_layers;
+    a.act = k.decoder_activation == 0 ? 1 : (k.decoder_activation == 1 ? 2 : (k.decoder_activation == 2 ? 3 : 4));
+    a.kvalid = kvalid; a.causal = k.causal; a.window = k.window_size; a.attn = attn; a.B = (int)B; a.T = (int)T;
+    a.tail = tail;
+    hipLaunchKernelGGL(kf::kmmf_decode_kernel, dim3((unsigned)B), dim3(kf::NTH), kf::DEC_LDS_FLOATS * 4, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }

@@ -19,12 +19,16 @@
 
 namespace km {
 
+#include "km_kmm_tail.h"
+
 static const float* dv(Context* c, const std::string& name) { return c->packed.at(name).dev; }
 
 // km_kmmf.hip: the fused kernels for the reference's default width
 bool koemorph_fused_ok(Context* c, int64_t B, int64_t T, const float* mel, const float* emo);
 int launch_kmmf_encoder(Context* c, const float* mel, const float* emo, int64_t B, int64_t T, const unsigned char* kvalid, float* xm,
                         float* xe, void* stream);
+int launch_kmmf_decode(Context* c, const float* xm, const float* xe, int64_t B, int64_t T, const unsigned char* kvalid, const float* prev,
+                       float* attn, const KmmTail& tail, void* stream);
 
 // LayerNorm over the last dimension, in place, one wave per row (two-pass, eps 1e-5)
 __global__ __launch_bounds__(256) void kmm_ln_rows_kernel(float* __restrict__ x, int64_t rows, int d,
@@ -126,86 +130,20 @@ __global__ void kmm_act_residual_kernel(float* __restrict__ x, const float* __re
     x[i] = gemm_act(v, act) + res[i];
 }
 
-// decoder output (diagonal of output_proj: row q only needs Wout[q]), output activation, mix with the previous frame,
-// temporal smoothing with the caller's state, constraints.  One workgroup of 64 threads per batch element (NB <= 64).
-struct KmmTail {
-    const float* h; int hid, NB;
-    const float* wout; const float* bout; const float* prev;
-    int out_act;                 // 0 sigmoid, 1 tanh, 2 none (decoder.py:162-167)
-    int smooth;                  // -1 off, 0 exponential, 1 gaussian, 2 median (decoder.py:260-331)
-    int window;                  // ring slots of methods 1 and 2
-    const float* sm_param;       // alpha (method 0) or gaussian_weights (window) (method 1)
-    float* state;                // method 0: (B, NB); 1, 2: (B, window * NB + 1) = ring (window, NB) + slot pointer
-    int constraints;
-    float* out; float* raw;
-};
-
+// decoder output (diagonal of output_proj: row q only needs Wout[q]) and the output tail (km_kmm_tail.h).  One workgroup of
+// 64 threads per batch element (NB <= 64).
 __global__ __launch_bounds__(64) void kmm_tail_kernel(KmmTail a) {
     __shared__ float ys[64];
     const int64_t b = blockIdx.x;
     const int q = threadIdx.x, NB = a.NB;
-    float y = 0.f;
+    float z = 0.f;
     if (q < NB) {
         const float* hr = a.h + (b * NB + q) * a.hid;
         const float* wr = a.wout + (int64_t)q * a.hid;
-        float z = 0.f;
         for (int k = 0; k < a.hid; ++k) z = fmaf(hr[k], wr[k], z);
         z += a.bout[q];
-        y = a.out_act == 0 ? 1.0f / (1.0f + expf(-z)) : (a.out_act == 1 ? tanhf(z) : z);
-        if (a.prev) y = (1.0f - 0.1f) * y + 0.1f * a.prev[b * NB + q];      // decoder.py:172-175
-        if (a.raw) a.raw[b * NB + q] = y;
-        if (a.smooth == 0) {                                                   // decoder.py:278-292
-            const float alpha = 1.0f / (1.0f + expf(-a.sm_param[0]));
-            y = alpha * a.state[b * NB + q] + (1.0f - alpha) * y;
-            a.state[b * NB + q] = y;
-        } else if (a.smooth > 0) {                                             // decoder.py:294-340: history ring, one slot per call
-            float* ring = a.state + b * ((int64_t)a.window * NB + 1);
-            const int ptr = (int)ring[(int64_t)a.window * NB];                  // every thread reads it before thread 0 moves it
-            float v[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = k < a.window ? (k == ptr ? y : ring[k * NB + q]) : 0.f;
-            ring[ptr * NB + q] = y;
-            if (a.smooth == 1) {          // softmax of the learnable weights over the SLOTS (:307-317)
-                float m = -INFINITY, s = 0.f, acc = 0.f;
-                for (int k = 0; k < a.window; ++k) m = fmaxf(m, a.sm_param[k]);
-                for (int k = 0; k < a.window; ++k) s += expf(a.sm_param[k] - m);
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (k < a.window) acc += (expf(a.sm_param[k] - m) / s) * v[k];
-                y = acc;
-            } else {                      // torch.median(dim=0): the lower middle of the sorted slots; NaN if any slot is NaN
-                bool nan = false;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) nan = nan || (k < a.window && v[k] != v[k]);
-#pragma unroll
-                for (int i = 1; i < 16; ++i)          // insertion sort of the first `window` entries (fully unrolled: registers)
-#pragma unroll
-                    for (int j = i; j > 0; --j)
-                        if (i < a.window && v[j] < v[j - 1]) { const float t = v[j]; v[j] = v[j - 1]; v[j - 1] = t; }
-                float med = v[0];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) med = k == (a.window - 1) / 2 ? v[k] : med;
-                y = nan ? NAN : med;
-            }
-        }
-        if (a.constraints) y = y < 0.f ? 0.f : (y > 1.f ? 1.f : y);          // decoder.py:434-438; NaN stays NaN, as torch.clamp
     }
-    ys[q] = y;
-    __syncthreads();
-    if (a.smooth > 0 && q == 0) {       // after every thread of the element has read the pointer
-        float* pp = a.state + b * ((int64_t)a.window * NB + 1) + (int64_t)a.window * NB;
-        const int ptr = (int)pp[0];
-        pp[0] = (float)((ptr + 1) % a.window);
-    }
-    if (q < NB) {
-        if (a.constraints) {
-            const int pa[2] = {25, 20}, pb[2] = {26, 21};                     // decoder.py:384-387, :451-456
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                if (q == pa[i] || q == pb[i]) y = ys[q] / ((ys[pa[i]] + ys[pb[i]]) + 1e-8f);
-        }
-        a.out[b * NB + q] = y;
-    }
+    kmm_tail_dev(a, b, q, z, ys);
 }
 
 static GemmArgs lin(const float* A, int64_t a_rs, const float* W, int K, float* C, int64_t c_rs, int64_t rows, int N,
@@ -299,6 +237,14 @@ int launch_koemorph(Context* c, const float* mel, const float* emo, int64_t B, i
         if (int rc = encode_stream(c, "mel", mel, k.mel_dim, B, T, kvalid, xm, qkv, S, O, ffn, st)) return rc;
         if (int rc = encode_stream(c, "emotion", emo, k.emotion_dim, B, T, kvalid, xe, qkv, S, O, ffn, st)) return rc;
     }
+    const bool smooth = state != nullptr && k.use_temporal_smoothing;
+    KmmTail ta{};
+    ta.hid = hid; ta.NB = NB; ta.wout = dv(c, "decoder.output_proj.weight"); ta.bout = dv(c, "decoder.output_proj.bias");
+    ta.prev = prev; ta.out_act = k.output_activation; ta.smooth = smooth ? k.smoothing_method : -1; ta.window = k.smoothing_window;
+    ta.sm_param = !smooth ? nullptr : (k.smoothing_method == 0 ? dv(c, "temporal_smoother.alpha")
+                                       : (k.smoothing_method == 1 ? dv(c, "temporal_smoother.gaussian_weights") : nullptr));
+    ta.state = smooth ? state : nullptr; ta.constraints = (apply_constraints && k.use_constraints) ? 1 : 0; ta.out = out; ta.raw = raw;
+    if (fused) return launch_kmmf_decode(c, xm, xe, B, T, kvalid, prev, attn, ta, stream);
     hipLaunchKernelGGL(kmm_avg_kernel, dim3((unsigned)((R * d + 255) / 256)), dim3(256), 0, st, xm, xe, xm, R * d);
     // ---- queries (attention.py:481-514) ----
     if (prev) {
@@ -354,13 +300,7 @@ int launch_koemorph(Context* c, const float* mel, const float* emo, int64_t B, i
         HIP_TRY(hipGetLastError());
         float* t = cur; cur = nxt; nxt = t;
     }
-    const bool smooth = state != nullptr && k.use_temporal_smoothing;
-    KmmTail ta{};
-    ta.h = cur; ta.hid = hid; ta.NB = NB; ta.wout = dv(c, "decoder.output_proj.weight"); ta.bout = dv(c, "decoder.output_proj.bias");
-    ta.prev = prev; ta.out_act = k.output_activation; ta.smooth = smooth ? k.smoothing_method : -1; ta.window = k.smoothing_window;
-    ta.sm_param = !smooth ? nullptr : (k.smoothing_method == 0 ? dv(c, "temporal_smoother.alpha")
-                                       : (k.smoothing_method == 1 ? dv(c, "temporal_smoother.gaussian_weights") : nullptr));
-    ta.state = smooth ? state : nullptr; ta.constraints = (apply_constraints && k.use_constraints) ? 1 : 0; ta.out = out; ta.raw = raw;
+    ta.h = cur;
     hipLaunchKernelGGL(kmm_tail_kernel, dim3((unsigned)B), dim3(64), 0, st, ta);
     HIP_TRY(hipGetLastError());
     return KM_OK;

@@ -206,3 +206,55 @@ def test_padding_is_invisible():
         for i, n in enumerate(lens):
             alone = m(torch.from_numpy(mel[i:i + 1, :n]).cuda(), torch.from_numpy(emo[i:i + 1, :n]).cuda(), apply_smoothing=False)["blendshapes"].cpu().numpy()
             np.testing.assert_allclose(padded[i:i + 1], alone, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,T,masked,causal,window,act,prev", [
+    (2, 30, False, True, 30, "gelu", True),       # the reference's defaults (the d256 golden's shape)
+    (5, 30, True, True, 30, "gelu", True),        # odd batch: the last encoder workgroup holds one window; key padding mask
+    (3, 32, True, False, None, "swish", False),   # full tiles, no causal / local-window mask, no conditioning
+    (4, 17, False, True, 8, "leaky_relu", True),  # narrow window: the last queries see few keys
+    (7, 1, False, True, 30, "relu", True),        # the per-tick form scripts/rt.py feeds
+    (3, 9, True, False, 4, "gelu", False),
+])
+def test_fused_kernels_match_the_chain_and_the_oracle(B, T, masked, causal, window, act, prev):
+    """The default width runs two fused kernels (km_kmmf.hip); option kmm_no_fuse runs the launch-per-step chain on the same
+    handle.  Both against the oracle (pinned by the reference goldens), two chained frames, attention weights included."""
+    from koemorph_amd import synth
+    cfg = okm.KoeMorphConfig(causal=causal, window_size=window, decoder_activation=act)
+    params = okm.make_koemorph_params(17 + B, cfg)
+    m = build(cfg, params)
+    lib, h, _ = m._handle()
+    am = None
+    if masked:                                        # ragged tails, and leading padding on element 0
+        am = np.ones((B, T), dtype=bool)
+        for b in range(B):
+            if b % 3:
+                am[b, T - (b % 3):] = False
+        am[0, : T // 3] = False
+    res = {}
+    for mode in ("fused", "chain"):
+        _lib.check(lib.km_set_option(h, b"kmm_no_fuse", 0 if mode == "fused" else 1))
+        m.reset_temporal_state()
+        outs, pb = [], None
+        for f in range(2):
+            mel, emo = synth.normal(300 + f, (B, T, 80)), synth.normal(400 + f, (B, T, 256))
+            with torch.no_grad():
+                o = m(torch.from_numpy(mel).cuda(), torch.from_numpy(emo).cuda(), audio_mask=None if am is None else torch.from_numpy(am).cuda(),
+                      prev_blendshapes=pb if prev else None, return_attention=True)
+            pb = o["blendshapes"]
+            outs.append({"b": o["blendshapes"].cpu().numpy(), "r": o["raw_blendshapes"].cpu().numpy(),
+                         "a": [w.cpu().numpy() for w in o["attention_weights"]]})
+        res[mode] = outs
+    _lib.check(lib.km_set_option(h, b"kmm_no_fuse", 0))
+    state, pb = None, None
+    for f in range(2):
+        mel, emo = synth.normal(300 + f, (B, T, 80)), synth.normal(400 + f, (B, T, 256))
+        g = okm.koemorph_forward(params, cfg, mel, emo, audio_mask=am, prev_blendshapes=pb if prev else None, smoother_state=state)
+        g = {k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in g.items()}
+        state, pb = g["smoother_state"], g["blendshapes"]
+        for mode in ("fused", "chain"):
+            o = res[mode][f]
+            assert_same(o["b"], g["blendshapes"], TOL)
+            assert_same(o["r"], g["raw_blendshapes"], TOL)
+            for li in range(cfg.num_attention_layers):
+                assert_same(o["a"][li], np.asarray(g["attention_weights"][li]), TOL)
