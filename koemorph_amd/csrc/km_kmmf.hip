@@ -2,9 +2,10 @@
 // (d_model 256, 8 heads, 52 queries, decoder 128, windows of <= 32 frames).  Two launches replace the ~75 of the
 // launch-per-step chain in km_koemorph.hip:
 //
-//   kmmf_encoder_kernel   DualStreamEncoder (dual_stream_attention.py:369-388): one workgroup = TWO windows of ONE stream
-//                         (64 rows = 4 MFMA row tiles, window w on rows 32 w .. 32 w + T - 1), input projection + ReLU +
-//                         LayerNorm and every post-norm transformer layer with the rows resident in LDS.
+//   kmmf_encoder_kernel   DualStreamEncoder (dual_stream_attention.py:369-388): one workgroup = 64 rows (4 MFMA row tiles) of ONE
+//                         stream = two windows of 17 - 32 frames (window w on rows 32 w ..), or 4 .. 64 windows of fewer frames
+//                         (slots of the power of two >= T); input projection + ReLU + LayerNorm and every post-norm
+//                         transformer layer with the rows resident in LDS.
 //   kmmf_decode_kernel    average of the two encodings, query embeddings (+ conditioning net), every cross-attention layer,
 //                         BlendshapeDecoder and the output tail: one workgroup per window, the 52 query rows resident in LDS.
 //
@@ -148,21 +149,17 @@ __device__ __forceinline__ void ln_store(f32x4 (&v)[4][NTW], float* red, const f
         }
 }
 
-// One head (= this wave) of an attention layer with everything in registers.
-//   Xq: LDS image of the query rows (QT row tiles), Xk: image of the key / value rows (KTT row tiles); NWIN windows share the
-//   images: window w owns query tiles [w QT / NWIN, ...) and key tiles [2 w, 2 w + 2) (a window's keys are two tiles = 32 rows).
+// One head (= this wave) of an attention layer with everything in registers, in two steps.
+//
+// project_qkv: Q_h^T (scaled, as torch scales q after its bias), K_h^T and V_h of this head.
+//   Xq: LDS image of the query rows (QT row tiles), Xk: image of the key / value rows (KTT row tiles; SELF: the same rows).
 //   wq / wk / wv: fragment-packed (256-wide) projections already offset to this head's first tile (16 k blocks per tile),
-//   bq / bk / bv: their biases offset to this head's first column.  scale multiplies q (after its bias), as torch does.
-//   mask(w, key, q) -> true when key `key` of window w may be attended by query q (row index inside the window).
-//   O^T -> Yo[query row][32 h + dim] for query rows < q_limit.  attn (or null): P -> attn[(w) ...] through store_p(w, q, key, p).
-template <int QT, int KTT, int NWIN, bool SELF, class Mask, class StoreP>
-__device__ __forceinline__ void attention_head(const float* Xq, const float* Xk, const float* wq, const float* wk, const float* wv,
-                                               const float* bq, const float* bk, const float* bv, float scale, float* Yo, int head,
-                                               int q_limit, int lane, Mask mask, StoreP store_p) {
-    constexpr int QW = QT / NWIN;
-    static_assert(KTT == 2 * NWIN, "a window's keys are two row tiles");
+//   bq / bk / bv: their biases offset to this head's first column.
+template <int QT, int KTT, bool SELF>
+__device__ __forceinline__ void project_qkv(f32x4 (&qT)[2][QT], f32x4 (&kT)[2][KTT], f32x4 (&vv)[KTT][2], const float* Xq, const float* Xk,
+                                            const float* wq, const float* wk, const float* wv, const float* bq, const float* bk,
+                                            const float* bv, float scale, int lane) {
     const int g = lane >> 4, j = lane & 15;
-    f32x4 qT[2][QT], kT[2][KTT], vv[KTT][2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
@@ -223,48 +220,61 @@ __device__ __forceinline__ void attention_head(const float* Xq, const float* Xk,
             for (int t = 0; t < KTT; ++t) { kT[dt][t][r] += b4k[r]; vv[t][dt][r] += bvj; }
         }
     }
+}
+
+// attend: masked softmax and P V for groups of KW key tiles x QW query tiles: group w owns key tiles [KW w, KW w + KW) and
+// query tiles [QW w, QW w + QW) (encoder, windows of 17 - 32 frames: two groups of 2 x 2 tiles; windows of <= 16 frames: four
+// groups of 1 x 1, several windows inside a tile told apart by the mask; cross-attention: one group of 2 x 4).
+//   mask(key_row, query_row) -> true when that key may be attended by that query (row indices in the images).
+//   O^T -> Yo[query row][32 head + dim] for query rows < q_limit;  store_p(query_row, key_row, p) sees every probability.
+template <int QT, int KTT, int KW, int QW, class Mask, class StoreP>
+__device__ __forceinline__ void attend(const f32x4 (&qT)[2][QT], const f32x4 (&kT)[2][KTT], const f32x4 (&vv)[KTT][2], float* Yo, int head,
+                                       int q_limit, int lane, Mask mask, StoreP store_p) {
+    constexpr int NG = KTT / KW;
+    static_assert(NG * QW == QT && NG * KW == KTT, "groups tile the images");
+    const int g = lane >> 4, j = lane & 15;
 #pragma unroll
-    for (int w = 0; w < NWIN; ++w) {
-        f32x4 S[2][QW];
+    for (int w = 0; w < NG; ++w) {
+        f32x4 S[KW][QW];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < KW; ++kt)
 #pragma unroll
             for (int qt = 0; qt < QW; ++qt) {
                 f32x4 c = f32x4{0, 0, 0, 0};
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) c = KM_MFMA(kT[dt][2 * w + kt][s], qT[dt][QW * w + qt][s], c);   // S^T[key][query]
+                    for (int s = 0; s < 4; ++s) c = KM_MFMA(kT[dt][KW * w + kt][s], qT[dt][QW * w + qt][s], c);   // S^T[key][query]
                 S[kt][qt] = c;
             }
         // masked softmax over the keys (the rows of S^T) of each query column
 #pragma unroll
         for (int qt = 0; qt < QW; ++qt) {
-            const int q = 16 * qt + j;
+            const int q = 16 * (QW * w + qt) + j;
             float m = -INFINITY;
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < KW; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (!mask(w, 16 * kt + 4 * g + r, q)) S[kt][qt][r] = -INFINITY;
+                    if (!mask(16 * (KW * w + kt) + 4 * g + r, q)) S[kt][qt][r] = -INFINITY;
                     m = fmaxf(m, S[kt][qt][r]);
                 }
             m = fmaxf(m, __shfl_xor(m, 16));
             m = fmaxf(m, __shfl_xor(m, 32));
             float sum = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < KW; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { S[kt][qt][r] = expf(S[kt][qt][r] - m); sum += S[kt][qt][r]; }
             sum += __shfl_xor(sum, 16);
             sum += __shfl_xor(sum, 32);
             const float inv = 1.0f / sum;
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < KW; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     S[kt][qt][r] *= inv;
-                    store_p(w, q, 16 * kt + 4 * g + r, S[kt][qt][r]);
+                    store_p(q, 16 * (KW * w + kt) + 4 * g + r, S[kt][qt][r]);
                 }
         }
         // O^T[dim][query] = sum over keys V[key][dim] P^T[key][query]
@@ -274,9 +284,9 @@ __device__ __forceinline__ void attention_head(const float* Xq, const float* Xk,
             for (int dt = 0; dt < 2; ++dt) {
                 f32x4 o = f32x4{0, 0, 0, 0};
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < KW; ++kt)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) o = KM_MFMA(vv[2 * w + kt][dt][s], S[kt][qt][s], o);
+                    for (int s = 0; s < 4; ++s) o = KM_MFMA(vv[KW * w + kt][dt][s], S[kt][qt][s], o);
                 const int row = 16 * (QW * w + qt) + j;
                 if (row < q_limit) *reinterpret_cast<f32x4*>(Yo + row * XS + 32 * head + 16 * dt + 4 * g) = o;
             }
@@ -290,8 +300,10 @@ struct EncArgs {
     const unsigned char* kvalid;              // (B, T), 1 = attend, or null (src_key_padding_mask)
     float* out0; float* out1;                 // (B, T, 256)
     int B, T;
+    int slot_log2;                            // a window owns 1 << slot_log2 rows of the 64 (the power of two >= T): 2 .. 64 windows per workgroup
 };
 
+template <bool SMALL>     // SMALL: windows of <= 16 frames (slots of 1 .. 16 rows), else two windows of 17 - 32 frames
 __global__ __launch_bounds__(512) void kmmf_encoder_kernel(EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;
@@ -299,24 +311,24 @@ __global__ __launch_bounds__(512) void kmmf_encoder_kernel(EncArgs a) {
     float* red = smem + 2 * IMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, j = lane & 15;
-    const int stream = blockIdx.y, w0 = 2 * blockIdx.x, T = a.T;
+    const int stream = blockIdx.y, T = a.T, lg = a.slot_log2;
+    const int w0 = blockIdx.x * (64 >> lg);             // first window of this workgroup
     const float* in = stream ? a.in1 : a.in0;
     const int in_dim = stream ? a.in_dim1 : a.in_dim0;
     float* out = stream ? a.out1 : a.out0;
     const float* blob = a.blob + stream * a.stream_floats;
     const int col0 = 32 * wave;
 
-    // key padding masks of the two windows as bit masks (bit t = key t may be attended); a window past the batch has none
-    unsigned kmask[2];
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {
-        const int b = w0 + w;
-        const bool ok = b < a.B && lane < T && (!a.kvalid || a.kvalid[(int64_t)b * T + lane]);
-        kmask[w] = (unsigned)__ballot(ok);
+    // row r = frame (r & (slot - 1)) of window w0 + (r >> lg).  Bit r of rowmask: row r holds a frame that may be attended
+    // (inside the batch, inside the window, not padding: src_key_padding_mask)
+    unsigned long long rowmask;
+    {
+        const int b = w0 + (lane >> lg), t = lane & ((1 << lg) - 1);
+        rowmask = __ballot(b < a.B && t < T && (!a.kvalid || a.kvalid[(int64_t)b * T + t]));
     }
     // ---- input rows -> X (columns >= in_dim and rows without a frame are zero) ----
     for (int i = tid; i < 64 * 64; i += NTH) {
-        const int r = i >> 6, c4 = i & 63, b = w0 + (r >> 5), t = r & 31;
+        const int r = i >> 6, c4 = i & 63, b = w0 + (r >> lg), t = r & ((1 << lg) - 1);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (b < a.B && t < T && 4 * c4 < in_dim) v = *reinterpret_cast<const float4*>(in + ((int64_t)b * T + t) * in_dim + 4 * c4);
         *reinterpret_cast<float4*>(X + r * XS + 4 * c4) = v;
@@ -345,11 +357,28 @@ __global__ __launch_bounds__(512) void kmmf_encoder_kernel(EncArgs a) {
     for (int layer = 0; layer < a.layers; ++layer) {
         const float* L = blob + ENC_HEAD + (int64_t)layer * ENC_LAYER;
         // ---- self-attention, wave = head ----
-        attention_head<4, 4, 2, true>(
-            xc, xc, L + EL_WIN + (int64_t)(2 * wave) * KBD * 256, L + EL_WIN + (int64_t)(16 + 2 * wave) * KBD * 256,
-            L + EL_WIN + (int64_t)(32 + 2 * wave) * KBD * 256, L + EL_BIN + 32 * wave, L + EL_BIN + D + 32 * wave,
-            L + EL_BIN + 2 * D + 32 * wave, scale, xo, wave, 64, lane,
-            [&](int w, int key, int) { return ((kmask[w] >> key) & 1u) != 0; }, [](int, int, int, float) {});
+        {
+            f32x4 qT[2][4], kT[2][4], vv[4][2];
+            project_qkv<4, 4, true>(qT, kT, vv, xc, xc, L + EL_WIN + (int64_t)(2 * wave) * KBD * 256,
+                                    L + EL_WIN + (int64_t)(16 + 2 * wave) * KBD * 256, L + EL_WIN + (int64_t)(32 + 2 * wave) * KBD * 256,
+                                    L + EL_BIN + 32 * wave, L + EL_BIN + D + 32 * wave, L + EL_BIN + 2 * D + 32 * wave, scale, lane);
+            auto nostore = [](int, int, float) {};
+            if constexpr (!SMALL)       // a window = two row tiles
+                attend<4, 4, 2, 2>(qT, kT, vv, xo, wave, 64, lane, [&](int key, int) { return ((rowmask >> key) & 1ull) != 0; }, nostore);
+            else {             // 1 .. 16 windows inside each row tile
+                // A tile's P V product runs over the keys of ALL its windows with P = 0 for the foreign ones: the value rows of
+                // frames nobody may attend (padding, windows past the batch -- NaN from the second layer on, when a window
+                // has no key at all) are cleared, or 0 x NaN would leak into the tile's other windows.  (A non-finite
+                // activation of an ATTENDED frame -- non-finite input features -- still spreads inside its row tile.)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (!((rowmask >> (16 * t + 4 * g + r)) & 1ull)) { vv[t][0][r] = 0.f; vv[t][1][r] = 0.f; }
+                attend<4, 4, 1, 1>(qT, kT, vv, xo, wave, 64, lane,
+                                   [&](int key, int q) { return ((rowmask >> key) & 1ull) != 0 && (key >> lg) == (q >> lg); }, nostore);
+            }
+        }
         __syncthreads();
         // ---- x = LN1(x + out_proj(O)) ----
         {
@@ -405,7 +434,7 @@ __global__ __launch_bounds__(512) void kmmf_encoder_kernel(EncArgs a) {
     }
     // ---- rows -> (B, T, 256) ----
     for (int i = tid; i < 64 * 64; i += NTH) {
-        const int r = i >> 6, c4 = i & 63, b = w0 + (r >> 5), t = r & 31;
+        const int r = i >> 6, c4 = i & 63, b = w0 + (r >> lg), t = r & ((1 << lg) - 1);
         if (b < a.B && t < T) *reinterpret_cast<float4*>(out + ((int64_t)b * T + t) * D + 4 * c4) = *reinterpret_cast<const float4*>(xc + r * XS + 4 * c4);
     }
 }
@@ -495,21 +524,25 @@ __global__ __launch_bounds__(512) void kmmf_decode_kernel(DecArgs a) {
     for (int layer = 0; layer < a.cross_layers; ++layer) {
         const float* L = a.cross + (int64_t)layer * CROSS_LAYER;
         float* ap = a.attn ? a.attn + ((((int64_t)layer * a.B + b) * HEADS + wave) * NQ) * T : nullptr;
-        attention_head<4, 2, 1, false>(
-            X, A, L + CL_WQ + (int64_t)(2 * wave) * KBD * 256, L + CL_WK + (int64_t)(2 * wave) * KBD * 256,
-            L + CL_WV + (int64_t)(2 * wave) * KBD * 256, L + CL_BQ + 32 * wave, L + CL_BK + 32 * wave, L + CL_BV + 32 * wave, scale, Y,
-            wave, NQ, lane,
-            [&](int, int key, int q) {          // attention.py:208-246: causal and local-window masks, key padding
-                int lo = 0, hi = T;
-                if (a.window >= 0) {
-                    const int kp = (q * T) / NQ;
-                    lo = kp - a.window / 2 > 0 ? kp - a.window / 2 : 0;
-                    hi = kp + a.window / 2 + 1 < T ? kp + a.window / 2 + 1 : T;
-                }
-                if (a.causal && q + 1 < hi) hi = q + 1;
-                return key >= lo && key < hi && ((kmask >> key) & 1u) != 0;
-            },
-            [&](int, int q, int key, float p) { if (ap && q < NQ && key < T) ap[q * T + key] = p; });
+        {
+            f32x4 qT[2][4], kT[2][2], vv[2][2];
+            project_qkv<4, 2, false>(qT, kT, vv, X, A, L + CL_WQ + (int64_t)(2 * wave) * KBD * 256, L + CL_WK + (int64_t)(2 * wave) * KBD * 256,
+                                     L + CL_WV + (int64_t)(2 * wave) * KBD * 256, L + CL_BQ + 32 * wave, L + CL_BK + 32 * wave,
+                                     L + CL_BV + 32 * wave, scale, lane);
+            attend<4, 2, 2, 4>(
+                qT, kT, vv, Y, wave, NQ, lane,
+                [&](int key, int q) {          // attention.py:208-246: causal and local-window masks, key padding
+                    int lo = 0, hi = T;
+                    if (a.window >= 0) {
+                        const int kp = (q * T) / NQ;
+                        lo = kp - a.window / 2 > 0 ? kp - a.window / 2 : 0;
+                        hi = kp + a.window / 2 + 1 < T ? kp + a.window / 2 + 1 : T;
+                    }
+                    if (a.causal && q + 1 < hi) hi = q + 1;
+                    return key >= lo && key < hi && ((kmask >> key) & 1u) != 0;
+                },
+                [&](int q, int key, float p) { if (ap && q < NQ && key < T) ap[q * T + key] = p; });
+        }
         __syncthreads();
         // ---- x = LN(out_proj(O) + x)   (gaussian_face.py:230-231) ----
         f32x4 acc[4][2];
@@ -604,14 +637,21 @@ bool koemorph_fused_ok(Context* c, int64_t B, int64_t T, const float* mel, const
 int launch_kmmf_encoder(Context* c, const float* mel, const float* emo, int64_t B, int64_t T, const unsigned char* kvalid, float* xm,
                         float* xe, void* stream) {
     static PerDeviceOnce once;
-    if (once.first(c->device))
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kf::kmmf_encoder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (once.first(c->device)) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kf::kmmf_encoder_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     kf::ENC_LDS_FLOATS * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kf::kmmf_encoder_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kf::ENC_LDS_FLOATS * 4));
+    }
     kf::EncArgs a{};
     a.in0 = mel; a.in1 = emo; a.in_dim0 = c->kmm.mel_dim; a.in_dim1 = c->kmm.emotion_dim;
     a.blob = dvp(c, "kmf_enc"); a.stream_floats = kmmf::enc_stream_floats(c->kmm.num_encoder_layers); a.layers = c->kmm.num_encoder_layers;
     a.kvalid = kvalid; a.out0 = xm; a.out1 = xe; a.B = (int)B; a.T = (int)T;
-    hipLaunchKernelGGL(kf::kmmf_encoder_kernel, dim3((unsigned)((B + 1) / 2), 2), dim3(kf::NTH), kf::ENC_LDS_FLOATS * 4, (hipStream_t)stream, a);
+    while ((1 << a.slot_log2) < T) ++a.slot_log2;
+    const int wpw = 64 >> a.slot_log2;
+    const dim3 grid((unsigned)((B + wpw - 1) / wpw), 2);
+    if (a.slot_log2 < 5) hipLaunchKernelGGL(kf::kmmf_encoder_kernel<true>, grid, dim3(kf::NTH), kf::ENC_LDS_FLOATS * 4, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(kf::kmmf_encoder_kernel<false>, grid, dim3(kf::NTH), kf::ENC_LDS_FLOATS * 4, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }

@@ -214,7 +214,9 @@ def test_padding_is_invisible():
     (3, 32, True, False, None, "swish", False),   # full tiles, no causal / local-window mask, no conditioning
     (4, 17, False, True, 8, "leaky_relu", True),  # narrow window: the last queries see few keys
     (7, 1, False, True, 30, "relu", True),        # the per-tick form scripts/rt.py feeds
-    (3, 9, True, False, 4, "gelu", False),
+    (3, 9, True, False, 4, "gelu", False),        # slots of 16 rows: one window per row tile
+    (70, 3, True, True, 30, "gelu", True),        # slots of 4 rows: 16 windows per encoder workgroup, 5 workgroups per stream
+    (9, 16, True, False, None, "relu", True),
 ])
 def test_fused_kernels_match_the_chain_and_the_oracle(B, T, masked, causal, window, act, prev):
     """The default width runs two fused kernels (km_kmmf.hip); option kmm_no_fuse runs the launch-per-step chain on the same
