@@ -28,10 +28,36 @@ struct GemmArgs {
 };
 
 #if defined(__HIPCC__)
+// erf(a) in fp32, branch-free, 24 vector instructions: both minimax polynomials of N. Juffa's single-precision erff
+// (x + x P(x^2) below 0.9277, 1 - exp(Q(|x|)) above: each < 1 ulp from erf with an exact exp) and a select; exp through v_exp_f32
+// (Q <= -1.06, so exp(Q) <= 0.35 and its few-ulp error is a fraction of an ulp of the result): <= 1.5 ulp over all, checked
+// against math.erf in tests/test_erf_poly.py.  The device library's erff is 36 instructions plus a divergent branch; fp32 VALU
+// work comes straight out of the fp32 matrix pipe's time, and GELU is 32 values per lane and hidden chunk in the
+// fused KoeMorphModel encoder.  NaN stays NaN.
+__device__ __forceinline__ float km_erff(float a) {
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    const float big = copysignf(1.0f - __builtin_amdgcn_exp2f(r * 1.4426950408889634f), a);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    const float small = fmaf(q, a, a);
+    return t > 0.927734375f ? big : small;
+}
+
 // GemmArgs::relu.  NaN stays NaN in every branch, as in torch.
 __device__ __forceinline__ float gemm_act(float v, int code) {
     if (code == 1) return v < 0.f ? 0.f : v;                                          // nn.ReLU
-    if (code == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));         // nn.GELU (exact erf)
+    if (code == 2) return 0.5f * v * (1.0f + km_erff(v * 0.70710678118654752f));      // nn.GELU (exact erf)
     if (code == 3) return v / (1.0f + expf(-v));                                      // nn.SiLU: x sigmoid(x)
     if (code == 4) return v < 0.f ? 0.1f * v : v;                                     // nn.LeakyReLU(0.1)
     return v;

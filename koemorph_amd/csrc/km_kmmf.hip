@@ -42,13 +42,39 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace kf {
 using namespace kmmf;
-constexpr int NTH = 512;             // threads per workgroup (8 waves: wave = head in the attention phases, = 32 columns elsewhere)
+constexpr int NTH = 512;             // decode kernel: threads per workgroup (8 waves: wave = head in the attention phase, = 32 columns elsewhere)
 constexpr int NW = 8;
 constexpr int XS = 264;              // row stride of the LDS images (floats)
-constexpr int IMG = 64 * XS;         // one 64-row image
 constexpr int KBD = D / 16;          // k blocks of a 256-wide contraction
-constexpr int RED = 2 * 64 * NW + 2 * 64;   // LayerNorm partials [pass][row][wave] + totals [pass][row]
-constexpr int ENC_LDS_FLOATS = 2 * IMG + RED;
+constexpr int RED = 2 * 64 * NW + 2 * 64;   // LayerNorm partials [pass][row][wave] + totals [pass][row] of 64 rows x 8 waves
+// encoder kernel: 256 threads (4 waves: wave = heads w and w + 4 in the attention phase, = 64 columns elsewhere) on 32 rows,
+// 70 KB of LDS: TWO workgroups per CU, whose barrier-separated phases drift apart -- one's LayerNorm / GELU / softmax / weight
+// round trips under the other's MFMAs (one 512-thread workgroup on 64 rows kept both waves of a SIMD in the same phase:
+// matrix pipe 0.76 busy)
+constexpr int ENTH = 256;
+constexpr int ENW = 4;
+constexpr int EROWS = 32;
+constexpr int EIMG = EROWS * XS;
+constexpr int ERED = 2 * EROWS * ENW + 2 * EROWS;
+constexpr int ENC_LDS_FLOATS = 2 * EIMG + ERED;
+
+// timing experiments (tools/micro/lib_variant.sh; results are wrong): 1 GELU -> ReLU, 2 no LayerNorm arithmetic
+#ifndef KM_KMMF_SKIP
+#define KM_KMMF_SKIP 0
+#endif
+// KM_KMMF_STAMP (timing builds, tools/micro/kmmf_stamp.py): every encoder wave sums the shader-clock cycles it spends in each part
+// of the kernel (s_memtime at the part boundaries) into km_kmmf_stamps[(workgroup, wave)][part]
+#ifdef KM_KMMF_STAMP
+__device__ unsigned long long km_kmmf_stamps[2048 * 4 * 16 + 1024 * 8 * 16];    // encoder, then decode
+#define KF_STAMP(i)                                                   \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        st_acc[i] += (unsigned)(now_ - st_last);                      \
+        st_last = now_;                                               \
+    } while (0)
+#else
+#define KF_STAMP(i) do {} while (0)
+#endif
 
 __device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes of a DPP row, in every lane
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
@@ -60,11 +86,26 @@ __device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 la
 
 // acc[mt][nt] += X[16 mt + ..][16 kb ..] . W[16 (t0 + nt) + ..][16 (kb0 + kb) ..]^T over nkb k blocks.
 // X: LDS image (k block 0 of the contraction at column 0); wp: fragment-packed weight of kbs k blocks per tile.
-template <int MT, int NTW>
+// PIN 0: the k loop as the compiler schedules it (the next block's weight loads sink into the step and are waited for with
+// vmcnt(0) a few MFMAs later).  PIN 1: the next k block's weight fragments are requested at the top of a step and held there
+// by scheduling barriers, two register sets alternating.  PIN 2: the rows' LDS fragments as well.  Measured, 256 x 30 frames:
+// the encoder (4 waves per workgroup, two workgroups per CU) gains 4 % from PIN 1 (PIN 2: 3 %); the 8-wave decode kernel LOSES
+// 11 % to it (its two waves per SIMD run in lockstep: the sunk loads stagger them).
+#ifndef KM_KMMF_ENC_PIN
+#define KM_KMMF_ENC_PIN 1
+#endif
+#ifndef KM_KMMF_ENC_QKV_PIN
+#define KM_KMMF_ENC_QKV_PIN 0
+#endif
+#ifndef KM_KMMF_DEC_PIN
+#define KM_KMMF_DEC_PIN 0
+#endif
+template <int MT, int NTW, int PIN>
 __device__ __forceinline__ void mm_cols(f32x4 (&acc)[MT][NTW], const float* X, const float* wp, int t0, int kbs, int kb0, int nkb, int lane) {
     const int g = lane >> 4, j = lane & 15;
     const float* xp = X + j * XS + 4 * g;
     const f32x4* w = reinterpret_cast<const f32x4*>(wp) + ((size_t)t0 * kbs + kb0) * 64 + lane;
+    if constexpr (PIN == 0) {
     f32x4 b[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) b[nt] = w[(size_t)nt * kbs * 64];
@@ -85,22 +126,58 @@ __device__ __forceinline__ void mm_cols(f32x4 (&acc)[MT][NTW], const float* X, c
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) b[nt] = bn[nt];
     }
+    } else {
+    f32x4 b0[NTW], b1[NTW], a0[MT], a1[MT];
+    auto fetch = [&](f32x4 (&b)[NTW], f32x4 (&a)[MT], int kb) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) b[nt] = w[((size_t)nt * kbs + kb) * 64];
+        if constexpr (PIN == 2) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(xp + 16 * mt * XS + 16 * kb);
+        }
+    };
+    auto step = [&](const f32x4 (&b)[NTW], f32x4 (&a)[MT], int kb) {
+        if constexpr (PIN == 1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(xp + 16 * mt * XS + 16 * kb);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = KM_MFMA(a[mt][s], b[nt][s], acc[mt][nt]);
+    };
+    fetch(b0, a0, 0);
+    for (int kb = 0; kb < nkb; kb += 2) {
+        fetch(b1, a1, kb + 1 < nkb ? kb + 1 : kb);
+        __builtin_amdgcn_sched_barrier(0);
+        step(b0, a0, kb);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(b0, a0, kb + 2 < nkb ? kb + 2 : kb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 1 < nkb) step(b1, a1, kb + 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    }
 }
 
-// LayerNorm (two-pass, eps 1e-5) over rows whose DCOLS columns are spread over the 8 waves (NTW column tiles each, C layout),
+// LayerNorm (two-pass, eps 1e-5) over 16 MT rows whose DCOLS columns are spread over the NWV waves (NTW column tiles each, C layout),
 // then (STORE) dst[row][col0 + 16 nt + j] = the normalised value (which v holds afterwards) for rows < row_limit.  Two barriers
-// per pass (partials -> totals).
-// The caller fences dst against its readers.
-template <int NTW, int DCOLS, bool STORE = true>
-__device__ __forceinline__ void ln_store(f32x4 (&v)[4][NTW], float* red, const float* gam, const float* bet, float* dst, int col0,
+// per pass (partials -> totals).  red: 2 (16 MT) NWV + 2 (16 MT) floats.  The caller fences dst against its readers.
+template <int MT, int NTW, int DCOLS, int NWV, bool STORE = true>
+__device__ __forceinline__ void ln_store(f32x4 (&v)[MT][NTW], float* red, const float* gam, const float* bet, float* dst, int col0,
                                          int row_limit, int wave, int lane, int tid) {
+    constexpr int ROWS = 16 * MT;
+    static_assert(NWV == 4 || NWV == 8, "partials of a row are one or two 16-byte reads");
     const int g = lane >> 4, j = lane & 15;
-    float mean[4][4], rstd[4][4];
+    float mean[MT][4], rstd[MT][4];
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        float* P = red + pass * (64 * NW);
+    for (int pass = (KM_KMMF_SKIP & 2) ? 2 : 0; pass < 2; ++pass) {
+        float* P = red + pass * (ROWS * NWV);
+        float part[MT][4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float s = 0.f;
@@ -109,22 +186,26 @@ __device__ __forceinline__ void ln_store(f32x4 (&v)[4][NTW], float* red, const f
                     if (pass == 0) s += v[mt][nt][r];
                     else { const float dlt = v[mt][nt][r] - mean[mt][r]; s += dlt * dlt; }
                 }
-                s = row16_sum(s);
-                if (j == 0) P[(16 * mt + 4 * g + r) * NW + wave] = s;
+                part[mt][r] = row16_sum(s);
             }
+        if (j == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) P[(16 * mt + 4 * g + r) * NWV + wave] = part[mt][r];
+        }
         __syncthreads();
-        float* Tt = red + 2 * 64 * NW + pass * 64;
-        if (tid < 64) {
-            const f32x4* pr = reinterpret_cast<const f32x4*>(P + tid * NW);
-            const f32x4 lo = pr[0], hi = pr[1];
+        float* Tt = red + 2 * ROWS * NWV + pass * ROWS;
+        if (tid < ROWS) {
+            const f32x4* pr = reinterpret_cast<const f32x4*>(P + tid * NWV);
             float s = 0.f;
-            s += lo[0]; s += lo[1]; s += lo[2]; s += lo[3];
-            s += hi[0]; s += hi[1]; s += hi[2]; s += hi[3];
+#pragma unroll
+            for (int q = 0; q < NWV / 4; ++q) { const f32x4 p4 = pr[q]; s += p4[0]; s += p4[1]; s += p4[2]; s += p4[3]; }
             Tt[tid] = s;
         }
         __syncthreads();
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             const f32x4 t4 = *reinterpret_cast<const f32x4*>(Tt + 16 * mt + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -137,13 +218,13 @@ __device__ __forceinline__ void ln_store(f32x4 (&v)[4][NTW], float* red, const f
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) { gm[nt] = gam[col0 + 16 * nt + j]; bt[nt] = bet[col0 + 16 * nt + j]; }
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * mt + 4 * g + r;
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
-                v[mt][nt][r] = (v[mt][nt][r] - mean[mt][r]) * rstd[mt][r] * gm[nt] + bt[nt];
+                if (!(KM_KMMF_SKIP & 2)) v[mt][nt][r] = (v[mt][nt][r] - mean[mt][r]) * rstd[mt][r] * gm[nt] + bt[nt];
                 if (STORE && row < row_limit) dst[row * XS + col0 + 16 * nt + j] = v[mt][nt][r];
             }
         }
@@ -155,7 +236,7 @@ __device__ __forceinline__ void ln_store(f32x4 (&v)[4][NTW], float* red, const f
 //   Xq: LDS image of the query rows (QT row tiles), Xk: image of the key / value rows (KTT row tiles; SELF: the same rows).
 //   wq / wk / wv: fragment-packed (256-wide) projections already offset to this head's first tile (16 k blocks per tile),
 //   bq / bk / bv: their biases offset to this head's first column.
-template <int QT, int KTT, bool SELF>
+template <int QT, int KTT, bool SELF, int PIN>
 __device__ __forceinline__ void project_qkv(f32x4 (&qT)[2][QT], f32x4 (&kT)[2][KTT], f32x4 (&vv)[KTT][2], const float* Xq, const float* Xk,
                                             const float* wq, const float* wk, const float* wv, const float* bq, const float* bk,
                                             const float* bv, float scale, int lane) {
@@ -173,6 +254,7 @@ __device__ __forceinline__ void project_qkv(f32x4 (&qT)[2][QT], f32x4 (&kT)[2][K
         const f32x4* pv = reinterpret_cast<const f32x4*>(wv) + lane;
         const float* xq = Xq + j * XS + 4 * g;
         const float* xk = Xk + j * XS + 4 * g;
+        if constexpr (PIN == 0) {
         f32x4 fq[2], fk[2], fv[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) { fq[dt] = pq[dt * KBD * 64]; fk[dt] = pk[dt * KBD * 64]; fv[dt] = pv[dt * KBD * 64]; }
@@ -205,6 +287,47 @@ __device__ __forceinline__ void project_qkv(f32x4 (&qT)[2][QT], f32x4 (&kT)[2][K
             }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) { fq[dt] = nq[dt]; fk[dt] = nk[dt]; fv[dt] = nv[dt]; }
+        }
+        } else {       // see mm_cols
+            f32x4 f0[3][2], f1[3][2];            // [q, k, v][head dimension tile]
+            auto fetch = [&](f32x4 (&f)[3][2], int kb) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) { f[0][dt] = pq[(dt * KBD + kb) * 64]; f[1][dt] = pk[(dt * KBD + kb) * 64]; f[2][dt] = pv[(dt * KBD + kb) * 64]; }
+            };
+            auto step = [&](const f32x4 (&f)[3][2], int kb) {
+                f32x4 aq[QT], ak[KTT];
+#pragma unroll
+                for (int t = 0; t < QT; ++t) aq[t] = *reinterpret_cast<const f32x4*>(xq + 16 * t * XS + 16 * kb);
+#pragma unroll
+                for (int t = 0; t < KTT; ++t) {
+                    if constexpr (SELF) ak[t] = aq[t];
+                    else ak[t] = *reinterpret_cast<const f32x4*>(xk + 16 * t * XS + 16 * kb);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) qT[dt][t] = KM_MFMA(f[0][dt][s], aq[t][s], qT[dt][t]);
+#pragma unroll
+                        for (int t = 0; t < KTT; ++t) kT[dt][t] = KM_MFMA(f[1][dt][s], ak[t][s], kT[dt][t]);
+#pragma unroll
+                        for (int t = 0; t < KTT; ++t) vv[t][dt] = KM_MFMA(ak[t][s], f[2][dt][s], vv[t][dt]);
+                    }
+                }
+            };
+            static_assert(KBD % 2 == 0, "two k blocks per turn");
+            fetch(f0, 0);
+            for (int kb = 0; kb < KBD; kb += 2) {
+                fetch(f1, kb + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                step(f0, kb);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(f0, kb + 2 < KBD ? kb + 2 : kb);
+                __builtin_amdgcn_sched_barrier(0);
+                step(f1, kb + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 #pragma unroll
@@ -300,145 +423,180 @@ struct EncArgs {
     const unsigned char* kvalid;              // (B, T), 1 = attend, or null (src_key_padding_mask)
     float* out0; float* out1;                 // (B, T, 256)
     int B, T;
-    int slot_log2;                            // a window owns 1 << slot_log2 rows of the 64 (the power of two >= T): 2 .. 64 windows per workgroup
+    int groups;                               // workgroups per stream
+    int slot_log2;                            // a window owns 1 << slot_log2 rows of the 32 (the power of two >= T): 1 .. 32 windows per workgroup
 };
 
-template <bool SMALL>     // SMALL: windows of <= 16 frames (slots of 1 .. 16 rows), else two windows of 17 - 32 frames
-__global__ __launch_bounds__(512) void kmmf_encoder_kernel(EncArgs a) {
+template <bool SMALL>     // SMALL: windows of <= 16 frames (slots of 1 .. 16 rows), else one window of 17 - 32 frames
+__global__ __launch_bounds__(256) void kmmf_encoder_kernel(EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;
-    float* Y = smem + IMG;
-    float* red = smem + 2 * IMG;
+    float* Y = smem + EIMG;
+    float* red = smem + 2 * EIMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, j = lane & 15;
-    const int stream = blockIdx.y, T = a.T, lg = a.slot_log2;
-    const int w0 = blockIdx.x * (64 >> lg);             // first window of this workgroup
+    const int T = a.T, lg = a.slot_log2;
+    const int stream = blockIdx.x & 1, widx = blockIdx.x >> 1;
+    const int w0 = widx * (EROWS >> lg);                // first window of this workgroup
     const float* in = stream ? a.in1 : a.in0;
     const int in_dim = stream ? a.in_dim1 : a.in_dim0;
     float* out = stream ? a.out1 : a.out0;
     const float* blob = a.blob + stream * a.stream_floats;
-    const int col0 = 32 * wave;
+    const int col0 = 64 * wave;
+#ifdef KM_KMMF_STAMP
+    unsigned st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_readcyclecounter();
+#endif
 
     // row r = frame (r & (slot - 1)) of window w0 + (r >> lg).  Bit r of rowmask: row r holds a frame that may be attended
     // (inside the batch, inside the window, not padding: src_key_padding_mask)
-    unsigned long long rowmask;
+    unsigned rowmask;
     {
         const int b = w0 + (lane >> lg), t = lane & ((1 << lg) - 1);
-        rowmask = __ballot(b < a.B && t < T && (!a.kvalid || a.kvalid[(int64_t)b * T + t]));
+        rowmask = (unsigned)__ballot(lane < EROWS && b < a.B && t < T && (!a.kvalid || a.kvalid[(int64_t)b * T + t]));
     }
     // ---- input rows -> X (columns >= in_dim and rows without a frame are zero) ----
-    for (int i = tid; i < 64 * 64; i += NTH) {
+    for (int i = tid; i < EROWS * 64; i += ENTH) {
         const int r = i >> 6, c4 = i & 63, b = w0 + (r >> lg), t = r & ((1 << lg) - 1);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (b < a.B && t < T && 4 * c4 < in_dim) v = *reinterpret_cast<const float4*>(in + ((int64_t)b * T + t) * in_dim + 4 * c4);
         *reinterpret_cast<float4*>(X + r * XS + 4 * c4) = v;
     }
     __syncthreads();
+    KF_STAMP(0);
     // ---- x = LayerNorm(ReLU(in W0^T + b0))   (dual_stream_attention.py:369-388) -> Y ----
     {
-        f32x4 acc[4][2];
+        f32x4 acc[2][4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = f32x4{0, 0, 0, 0}; acc[mt][1] = f32x4{0, 0, 0, 0}; }
-        mm_cols<4, 2>(acc, X, blob + ENC_W0, 2 * wave, KBD, 0, in_dim / 16, lane);
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0, 0, 0, 0};
+        mm_cols<2, 4, KM_KMMF_ENC_PIN>(acc, X, blob + ENC_W0, 4 * wave, KBD, 0, in_dim / 16, lane);
+        KF_STAMP(1);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
             const float bb = blob[ENC_B0 + col0 + 16 * nt + j];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float v = acc[mt][nt][r] + bb; acc[mt][nt][r] = v < 0.f ? 0.f : v; }
         }
-        ln_store<2, D>(acc, red, blob + ENC_LNG, blob + ENC_LNB, Y, col0, 64, wave, lane, tid);
+        ln_store<2, 4, D, ENW>(acc, red, blob + ENC_LNG, blob + ENC_LNB, Y, col0, EROWS, wave, lane, tid);
     }
     __syncthreads();
+    KF_STAMP(2);
     float* xc = Y;      // the rows
     float* xo = X;      // attention output / feed-forward hidden chunk
     const float scale = 1.0f / sqrtf((float)HD);
     for (int layer = 0; layer < a.layers; ++layer) {
         const float* L = blob + ENC_HEAD + (int64_t)layer * ENC_LAYER;
-        // ---- self-attention, wave = head ----
-        {
-            f32x4 qT[2][4], kT[2][4], vv[4][2];
-            project_qkv<4, 4, true>(qT, kT, vv, xc, xc, L + EL_WIN + (int64_t)(2 * wave) * KBD * 256,
-                                    L + EL_WIN + (int64_t)(16 + 2 * wave) * KBD * 256, L + EL_WIN + (int64_t)(32 + 2 * wave) * KBD * 256,
-                                    L + EL_BIN + 32 * wave, L + EL_BIN + D + 32 * wave, L + EL_BIN + 2 * D + 32 * wave, scale, lane);
+        // ---- self-attention: heads wave and wave + 4 ----
+#pragma unroll 1
+        for (int hh = 0; hh < 2; ++hh) {
+            const int head = wave + 4 * hh;
+            f32x4 qT[2][2], kT[2][2], vv[2][2];
+            project_qkv<2, 2, true, KM_KMMF_ENC_QKV_PIN>(qT, kT, vv, xc, xc, L + EL_WIN + (int64_t)(2 * head) * KBD * 256,
+                                    L + EL_WIN + (int64_t)(16 + 2 * head) * KBD * 256, L + EL_WIN + (int64_t)(32 + 2 * head) * KBD * 256,
+                                    L + EL_BIN + 32 * head, L + EL_BIN + D + 32 * head, L + EL_BIN + 2 * D + 32 * head, scale, lane);
+            KF_STAMP(3);
             auto nostore = [](int, int, float) {};
-            if constexpr (!SMALL)       // a window = two row tiles
-                attend<4, 4, 2, 2>(qT, kT, vv, xo, wave, 64, lane, [&](int key, int) { return ((rowmask >> key) & 1ull) != 0; }, nostore);
-            else {             // 1 .. 16 windows inside each row tile
+            if constexpr (!SMALL) {     // the window = both row tiles
+                attend<2, 2, 2, 2>(qT, kT, vv, xo, head, EROWS, lane, [&](int key, int) { return ((rowmask >> key) & 1u) != 0; }, nostore);
+            } else {                    // 1 .. 16 windows inside each row tile
                 // A tile's P V product runs over the keys of ALL its windows with P = 0 for the foreign ones: the value rows of
                 // frames nobody may attend (padding, windows past the batch -- NaN from the second layer on, when a window
                 // has no key at all) are cleared, or 0 x NaN would leak into the tile's other windows.  (A non-finite
                 // activation of an ATTENDED frame -- non-finite input features -- still spreads inside its row tile.)
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (!((rowmask >> (16 * t + 4 * g + r)) & 1ull)) { vv[t][0][r] = 0.f; vv[t][1][r] = 0.f; }
-                attend<4, 4, 1, 1>(qT, kT, vv, xo, wave, 64, lane,
-                                   [&](int key, int q) { return ((rowmask >> key) & 1ull) != 0 && (key >> lg) == (q >> lg); }, nostore);
+                        if (!((rowmask >> (16 * t + 4 * g + r)) & 1u)) { vv[t][0][r] = 0.f; vv[t][1][r] = 0.f; }
+                attend<2, 2, 1, 1>(qT, kT, vv, xo, head, EROWS, lane,
+                                   [&](int key, int q) { return ((rowmask >> key) & 1u) != 0 && (key >> lg) == (q >> lg); }, nostore);
             }
+            KF_STAMP(4);
         }
         __syncthreads();
+        KF_STAMP(5);
         // ---- x = LN1(x + out_proj(O)) ----
         {
-            f32x4 acc[4][2];
+            f32x4 acc[2][4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = f32x4{0, 0, 0, 0}; acc[mt][1] = f32x4{0, 0, 0, 0}; }
-            mm_cols<4, 2>(acc, xo, L + EL_WO, 2 * wave, KBD, 0, KBD, lane);
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0, 0, 0, 0};
+            mm_cols<2, 4, KM_KMMF_ENC_PIN>(acc, xo, L + EL_WO, 4 * wave, KBD, 0, KBD, lane);
+            KF_STAMP(6);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
                 const float bb = L[EL_BO + col0 + 16 * nt + j];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[mt][nt][r] += bb + xc[(16 * mt + 4 * g + r) * XS + col0 + 16 * nt + j];
             }
-            ln_store<2, D>(acc, red, L + EL_N1G, L + EL_N1B, xc, col0, 64, wave, lane, tid);
+            ln_store<2, 4, D, ENW>(acc, red, L + EL_N1G, L + EL_N1B, xc, col0, EROWS, wave, lane, tid);
         }
         __syncthreads();
+        KF_STAMP(7);
         // ---- x = LN2(x + W2 gelu(W1 x + b1) + b2), the hidden layer in four chunks of 256 through xo ----
         {
-            f32x4 y2[4][2];
+            f32x4 y2[2][4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) { y2[mt][0] = f32x4{0, 0, 0, 0}; y2[mt][1] = f32x4{0, 0, 0, 0}; }
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) y2[mt][nt] = f32x4{0, 0, 0, 0};
             for (int c = 0; c < FF / D; ++c) {
-                f32x4 h[4][2];
+                f32x4 h[2][4];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) { h[mt][0] = f32x4{0, 0, 0, 0}; h[mt][1] = f32x4{0, 0, 0, 0}; }
-                mm_cols<4, 2>(h, xc, L + EL_W1, 16 * c + 2 * wave, KBD, 0, KBD, lane);
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) h[mt][nt] = f32x4{0, 0, 0, 0};
+                mm_cols<2, 4, KM_KMMF_ENC_PIN>(h, xc, L + EL_W1, 16 * c + 4 * wave, KBD, 0, KBD, lane);
+                KF_STAMP(8);
                 if (c > 0) __syncthreads();          // the previous chunk's readers of xo
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
+                for (int nt = 0; nt < 4; ++nt) {
                     const float bb = L[EL_B1 + D * c + col0 + 16 * nt + j];
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
+                    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            xo[(16 * mt + 4 * g + r) * XS + col0 + 16 * nt + j] = gemm_act(h[mt][nt][r] + bb, 2);
+                            xo[(16 * mt + 4 * g + r) * XS + col0 + 16 * nt + j] = gemm_act(h[mt][nt][r] + bb, (KM_KMMF_SKIP & 1) ? 1 : 2);
                 }
                 __syncthreads();
-                mm_cols<4, 2>(y2, xo, L + EL_W2, 2 * wave, FF / 16, KBD * c, KBD, lane);
+                KF_STAMP(9);
+                mm_cols<2, 4, KM_KMMF_ENC_PIN>(y2, xo, L + EL_W2, 4 * wave, FF / 16, KBD * c, KBD, lane);
+                KF_STAMP(10);
             }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < 4; ++nt) {
                 const float bb = L[EL_B2 + col0 + 16 * nt + j];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y2[mt][nt][r] += bb + xc[(16 * mt + 4 * g + r) * XS + col0 + 16 * nt + j];
             }
-            ln_store<2, D>(y2, red, L + EL_N2G, L + EL_N2B, xc, col0, 64, wave, lane, tid);
+            ln_store<2, 4, D, ENW>(y2, red, L + EL_N2G, L + EL_N2B, xc, col0, EROWS, wave, lane, tid);
         }
         __syncthreads();
+        KF_STAMP(11);
     }
     // ---- rows -> (B, T, 256) ----
-    for (int i = tid; i < 64 * 64; i += NTH) {
+    for (int i = tid; i < EROWS * 64; i += ENTH) {
         const int r = i >> 6, c4 = i & 63, b = w0 + (r >> lg), t = r & ((1 << lg) - 1);
         if (b < a.B && t < T) *reinterpret_cast<float4*>(out + ((int64_t)b * T + t) * D + 4 * c4) = *reinterpret_cast<const float4*>(xc + r * XS + 4 * c4);
     }
+#ifdef KM_KMMF_STAMP
+    KF_STAMP(12);
+    if (lane == 0 && blockIdx.x < 2048) {
+        unsigned long long* o = km_kmmf_stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = st_acc[i];
+    }
+#endif
 }
-
 
 // ---------------------------------------------------------------------------------------------------------
 // kmmf_decode_kernel: gaussian_face.py:209-268 for one window per workgroup.
@@ -475,40 +633,11 @@ __global__ __launch_bounds__(512) void kmmf_decode_kernel(DecArgs a) {
     const int col0 = 32 * wave;
 
     const unsigned kmask = (unsigned)__ballot(lane < T && (!a.kvalid || a.kvalid[(int64_t)b * T + lane]));
-    // ---- conditioning (attention.py:500-512): cond = W3 relu(W0 prev + b0) + b3, through `red` ----
-    if (a.prev) {
-        if (tid < 128) {
-            const float* w = a.cw0 + tid * NQ;
-            const float* p = a.prev + (int64_t)b * NQ;
-            float s = 0.f;
-            for (int k = 0; k < NQ; ++k) s = fmaf(w[k], p[k], s);
-            s += a.cb0[tid];
-            red[tid] = s < 0.f ? 0.f : s;
-        }
-        __syncthreads();
-        if (tid < D) {
-            const float4* w = reinterpret_cast<const float4*>(a.cw3 + tid * 128);
-            float s = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < 32; ++k) {
-                const float4 wv = w[k];
-                const float4 hv = *reinterpret_cast<const float4*>(red + 4 * k);
-                s = fmaf(wv.x, hv.x, s); s = fmaf(wv.y, hv.y, s); s = fmaf(wv.z, hv.z, s); s = fmaf(wv.w, hv.w, s);
-            }
-            red[128 + tid] = s + a.cb3[tid];
-        }
-        __syncthreads();
-    }
-    // ---- x = embeddings (+ cond); A = (xm + xe) / 2, rows >= T zero ----
-    for (int i = tid; i < NQ * 64; i += NTH) {
-        const int q = i >> 6, c4 = i & 63;
-        float4 v = *reinterpret_cast<const float4*>(a.emb + q * D + 4 * c4);
-        if (a.prev) {
-            const float4 cv = *reinterpret_cast<const float4*>(red + 128 + 4 * c4);
-            v.x += cv.x; v.y += cv.y; v.z += cv.z; v.w += cv.w;
-        }
-        *reinterpret_cast<float4*>(X + q * XS + 4 * c4) = v;
-    }
+#ifdef KM_KMMF_STAMP
+    unsigned st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_readcyclecounter();
+#endif
+    // ---- A = (xm + xe) / 2, rows >= T zero (requested first: the conditioning net below waits on its own loads) ----
     for (int i = tid; i < TMAX * 64; i += NTH) {
         const int t = i >> 6, c4 = i & 63;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -519,36 +648,92 @@ __global__ __launch_bounds__(512) void kmmf_decode_kernel(DecArgs a) {
         }
         *reinterpret_cast<float4*>(A + t * XS + 4 * c4) = v;
     }
+    // ---- conditioning (attention.py:500-512): cond = W3 relu(W0 prev + b0) + b3, through `red`; four lanes per hidden
+    //      unit (13 of the 52 inputs each), then two lanes per output (64 of the 128 hidden units each) ----
+    if (a.prev) {
+        {
+            const int o = tid >> 2, part = tid & 3;
+            const float* w = a.cw0 + o * NQ + 13 * part;
+            const float* p = a.prev + (int64_t)b * NQ + 13 * part;
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 13; ++k) s = fmaf(w[k], p[k], s);
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += a.cb0[o];
+            if (part == 0) red[o] = s < 0.f ? 0.f : s;
+        }
+        __syncthreads();
+        {
+            const int o = tid >> 1, part = tid & 1;
+            const float4* w = reinterpret_cast<const float4*>(a.cw3 + o * 128 + 64 * part);
+            const float4* hp = reinterpret_cast<const float4*>(red + 64 * part);
+            float4 wv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) wv[k] = w[k];
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float4 hv = hp[k];
+                s = fmaf(wv[k].x, hv.x, s); s = fmaf(wv[k].y, hv.y, s); s = fmaf(wv[k].z, hv.z, s); s = fmaf(wv[k].w, hv.w, s);
+            }
+            s += __shfl_xor(s, 1);
+            if (part == 0) red[128 + o] = s + a.cb3[o];
+        }
+        __syncthreads();
+    }
+    // ---- x = embeddings (+ cond) ----
+    for (int i = tid; i < NQ * 64; i += NTH) {
+        const int q = i >> 6, c4 = i & 63;
+        float4 v = *reinterpret_cast<const float4*>(a.emb + q * D + 4 * c4);
+        if (a.prev) {
+            const float4 cv = *reinterpret_cast<const float4*>(red + 128 + 4 * c4);
+            v.x += cv.x; v.y += cv.y; v.z += cv.z; v.w += cv.w;
+        }
+        *reinterpret_cast<float4*>(X + q * XS + 4 * c4) = v;
+    }
     __syncthreads();
+    KF_STAMP(0);
     const float scale = 1.0f / sqrtf((float)HD);                       // (head_dim * temperature)^-0.5, temperature 1
+    int qlo[4], qhi[4];               // keys [lo, hi) of this lane's query in each of the four query tiles
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        const int q = 16 * qt + j;
+        int lo = 0, hi = T;
+        if (a.window >= 0) {
+            const int kp = (q * T) / NQ;
+            lo = kp - a.window / 2 > 0 ? kp - a.window / 2 : 0;
+            hi = kp + a.window / 2 + 1 < T ? kp + a.window / 2 + 1 : T;
+        }
+        if (a.causal && q + 1 < hi) hi = q + 1;
+        qlo[qt] = lo; qhi[qt] = hi;
+    }
     for (int layer = 0; layer < a.cross_layers; ++layer) {
         const float* L = a.cross + (int64_t)layer * CROSS_LAYER;
         float* ap = a.attn ? a.attn + ((((int64_t)layer * a.B + b) * HEADS + wave) * NQ) * T : nullptr;
         {
             f32x4 qT[2][4], kT[2][2], vv[2][2];
-            project_qkv<4, 2, false>(qT, kT, vv, X, A, L + CL_WQ + (int64_t)(2 * wave) * KBD * 256, L + CL_WK + (int64_t)(2 * wave) * KBD * 256,
+            project_qkv<4, 2, false, KM_KMMF_DEC_PIN>(qT, kT, vv, X, A, L + CL_WQ + (int64_t)(2 * wave) * KBD * 256, L + CL_WK + (int64_t)(2 * wave) * KBD * 256,
                                      L + CL_WV + (int64_t)(2 * wave) * KBD * 256, L + CL_BQ + 32 * wave, L + CL_BK + 32 * wave,
                                      L + CL_BV + 32 * wave, scale, lane);
+            KF_STAMP(1);
             attend<4, 2, 2, 4>(
                 qT, kT, vv, Y, wave, NQ, lane,
                 [&](int key, int q) {          // attention.py:208-246: causal and local-window masks, key padding
-                    int lo = 0, hi = T;
-                    if (a.window >= 0) {
-                        const int kp = (q * T) / NQ;
-                        lo = kp - a.window / 2 > 0 ? kp - a.window / 2 : 0;
-                        hi = kp + a.window / 2 + 1 < T ? kp + a.window / 2 + 1 : T;
-                    }
-                    if (a.causal && q + 1 < hi) hi = q + 1;
-                    return key >= lo && key < hi && ((kmask >> key) & 1u) != 0;
+                    const int qt = q >> 4;      // compile-time in the unrolled caller: bounds computed once per query tile
+                    return key >= qlo[qt] && key < qhi[qt] && ((kmask >> key) & 1u) != 0;
                 },
                 [&](int q, int key, float p) { if (ap && q < NQ && key < T) ap[q * T + key] = p; });
+            KF_STAMP(2);
         }
         __syncthreads();
+        KF_STAMP(3);
         // ---- x = LN(out_proj(O) + x)   (gaussian_face.py:230-231) ----
         f32x4 acc[4][2];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = f32x4{0, 0, 0, 0}; acc[mt][1] = f32x4{0, 0, 0, 0}; }
-        mm_cols<4, 2>(acc, Y, L + CL_WO, 2 * wave, KBD, 0, KBD, lane);
+        mm_cols<4, 2, KM_KMMF_DEC_PIN>(acc, Y, L + CL_WO, 2 * wave, KBD, 0, KBD, lane);
+        KF_STAMP(4);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const float bb = L[CL_BO + col0 + 16 * nt + j];
@@ -557,8 +742,9 @@ __global__ __launch_bounds__(512) void kmmf_decode_kernel(DecArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[mt][nt][r] += bb + X[(16 * mt + 4 * g + r) * XS + col0 + 16 * nt + j];
         }
-        ln_store<2, D>(acc, red, L + CL_LNG, L + CL_LNB, X, col0, NQ, wave, lane, tid);
+        ln_store<4, 2, D, NW>(acc, red, L + CL_LNG, L + CL_LNB, X, col0, NQ, wave, lane, tid);
         __syncthreads();
+        KF_STAMP(5);
     }
     // ---- BlendshapeDecoder (decoder.py:131-177): wave = 16 hidden units ----
     float* cur = Y;
@@ -567,7 +753,7 @@ __global__ __launch_bounds__(512) void kmmf_decode_kernel(DecArgs a) {
         f32x4 acc[4][1];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt][0] = f32x4{0, 0, 0, 0};
-        mm_cols<4, 1>(acc, X, a.dec + DC_WI, wave, KBD, 0, KBD, lane);
+        mm_cols<4, 1, KM_KMMF_DEC_PIN>(acc, X, a.dec + DC_WI, wave, KBD, 0, KBD, lane);
         const float bb = a.dec[DC_BI + 16 * wave + j];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -583,13 +769,13 @@ __global__ __launch_bounds__(512) void kmmf_decode_kernel(DecArgs a) {
         f32x4 acc[4][1];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt][0] = f32x4{0, 0, 0, 0};
-        mm_cols<4, 1>(acc, cur, L + DL_W, wave, HID / 16, 0, HID / 16, lane);
+        mm_cols<4, 1, KM_KMMF_DEC_PIN>(acc, cur, L + DL_W, wave, HID / 16, 0, HID / 16, lane);
         const float bb = L[DL_B + 16 * wave + j];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[mt][0][r] += bb;
-        ln_store<1, HID, false>(acc, red, L + DL_LNG, L + DL_LNB, nullptr, 16 * wave, NQ, wave, lane, tid);
+        ln_store<4, 1, HID, NW, false>(acc, red, L + DL_LNG, L + DL_LNB, nullptr, 16 * wave, NQ, wave, lane, tid);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -600,6 +786,7 @@ __global__ __launch_bounds__(512) void kmmf_decode_kernel(DecArgs a) {
         __syncthreads();
         float* t = cur; cur = nxt; nxt = t;
     }
+    KF_STAMP(6);
     // ---- output_proj (row q of the weight for query q), eight lanes per query, then the tail ----
     {
         const int q = tid >> 3, part = tid & 7;
@@ -622,6 +809,14 @@ __global__ __launch_bounds__(512) void kmmf_decode_kernel(DecArgs a) {
     const float z = tid < NQ ? ys[tid] : 0.f;
     __syncthreads();
     kmm_tail_dev(a.tail, b, tid, z, ys);
+#ifdef KM_KMMF_STAMP
+    KF_STAMP(7);
+    if (lane == 0 && blockIdx.x < 1024) {
+        unsigned long long* o = km_kmmf_stamps + 2048 * 4 * 16 + ((size_t)blockIdx.x * 8 + wave) * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = st_acc[i];
+    }
+#endif
 }
 
 }  // namespace kf
@@ -648,10 +843,11 @@ int launch_kmmf_encoder(Context* c, const float* mel, const float* emo, int64_t 
     a.blob = dvp(c, "kmf_enc"); a.stream_floats = kmmf::enc_stream_floats(c->kmm.num_encoder_layers); a.layers = c->kmm.num_encoder_layers;
     a.kvalid = kvalid; a.out0 = xm; a.out1 = xe; a.B = (int)B; a.T = (int)T;
     while ((1 << a.slot_log2) < T) ++a.slot_log2;
-    const int wpw = 64 >> a.slot_log2;
-    const dim3 grid((unsigned)((B + wpw - 1) / wpw), 2);
-    if (a.slot_log2 < 5) hipLaunchKernelGGL(kf::kmmf_encoder_kernel<true>, grid, dim3(kf::NTH), kf::ENC_LDS_FLOATS * 4, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(kf::kmmf_encoder_kernel<false>, grid, dim3(kf::NTH), kf::ENC_LDS_FLOATS * 4, (hipStream_t)stream, a);
+    const int wpw = kf::EROWS >> a.slot_log2;
+    a.groups = (int)((B + wpw - 1) / wpw);
+    const dim3 grid((unsigned)(2 * a.groups));
+    if (a.slot_log2 < 5) hipLaunchKernelGGL(kf::kmmf_encoder_kernel<true>, grid, dim3(kf::ENTH), kf::ENC_LDS_FLOATS * 4, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(kf::kmmf_encoder_kernel<false>, grid, dim3(kf::ENTH), kf::ENC_LDS_FLOATS * 4, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }
@@ -680,3 +876,9 @@ int launch_kmmf_decode(Context* c, const float* xm, const float* xe, int64_t B, 
 }
 
 }  // namespace km
+
+#ifdef KM_KMMF_STAMP
+extern "C" __attribute__((visibility("default"))) int km_debug_kmmf_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(km::kf::km_kmmf_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif

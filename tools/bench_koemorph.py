@@ -33,9 +33,9 @@ for B, T in CASES:
     emo = torch.from_numpy(synth.normal(2, (B, T, 256))).cuda()
     prev = torch.from_numpy(synth.uniform(3, (B, 52), 0, 1)).cuda()
     with torch.no_grad():
-        for _ in range(3): m(mel, emo, prev_blendshapes=prev)
+        for _ in range(int(os.environ.get("WARM", 3))): m(mel, emo, prev_blendshapes=prev)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        n = 20
+        n = int(os.environ.get("ITERS", 20))
         for _ in range(n): m(mel, emo, prev_blendshapes=prev)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     print(json.dumps({"workload": f"KoeMorphModel d256, {B} windows x {T} frames", "ms_per_forward": round(dt * 1e3, 3),
