@@ -2,7 +2,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/kmm_pmc
-ONLY=0 timeout -k 5 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/kmm_pmc/a -- python3 tools/bench_koemorph.py > gpurun_out/kmm_pmc/a.log 2>&1
+ONLY=0 WARM=100 ITERS=100 timeout -k 5 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/kmm_pmc/a -- python3 tools/bench_koemorph.py > gpurun_out/kmm_pmc/a.log 2>&1
 echo pass A done
 python3 - <<'PY' > gpurun_out/kmm_pmc/summary.txt
 import collections, csv, glob
