@@ -260,3 +260,27 @@ def test_fused_kernels_match_the_chain_and_the_oracle(B, T, masked, causal, wind
             assert_same(o["r"], g["raw_blendshapes"], TOL)
             for li in range(cfg.num_attention_layers):
                 assert_same(o["a"][li], np.asarray(g["attention_weights"][li]), TOL)
+
+
+@pytest.mark.parametrize("B,T", [(6, 4), (5, 30), (40, 1)])
+def test_fused_fully_masked_window_stays_in_its_window(B, T):
+    """A window whose every frame is padding is NaN (softmax over no key, as torch) -- and only that window: with T <= 16 several
+    windows share an MFMA row tile in the fused encoder, where 0 x NaN of a neighbour's value rows would otherwise leak."""
+    from koemorph_amd import synth
+    cfg = okm.KoeMorphConfig()
+    params = okm.make_koemorph_params(23, cfg)
+    m = build(cfg, params)
+    am = np.ones((B, T), dtype=bool)
+    am[2, :] = False
+    am[B - 1, :] = False
+    mel, emo = synth.normal(310, (B, T, 80)), synth.normal(410, (B, T, 256))
+    with torch.no_grad():
+        o = m(torch.from_numpy(mel).cuda(), torch.from_numpy(emo).cuda(), audio_mask=torch.from_numpy(am).cuda(), return_attention=True)
+    g = okm.koemorph_forward(params, cfg, mel, emo, audio_mask=am)
+    got = o["blendshapes"].cpu().numpy()
+    want = np.asarray(g["blendshapes"])
+    dead = np.isnan(want).all(axis=1)
+    assert dead[2] and dead[B - 1] and dead.sum() == 2
+    assert_same(got, want, TOL)
+    for li in range(cfg.num_attention_layers):
+        assert_same(o["attention_weights"][li].cpu().numpy(), np.asarray(g["attention_weights"][li]), TOL)
