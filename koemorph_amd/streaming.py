@@ -58,10 +58,13 @@ class StreamEngine:
         self.ready.zero_()
 
     # ---- hipGraph replay ------------------------------------------------------------------------
-    def capture(self, n_per_stream: int = 533) -> None:
+    def capture(self, n_per_stream: int = 533, host_out: Optional[torch.Tensor] = None) -> None:
         """Record push + tick on static input buffers into a hipGraph (torch.cuda.CUDAGraph drives
-        hipStreamBeginCapture on the current stream; the kernels are launched by libkoemorph_hip)."""
+        hipStreamBeginCapture on the current stream; the kernels are launched by libkoemorph_hip).  ``host_out``: a pinned
+        (n_streams, 52) host tensor -- the tick's result readback becomes the graph's last node instead of a call per tick."""
         dev = self.engine.device
+        if host_out is not None and (not host_out.is_pinned() or tuple(host_out.shape) != tuple(self.out.shape)):
+            raise ValueError("host_out must be a pinned host tensor of the shape of the result")
         self._g_samples = torch.zeros(self.n_streams, n_per_stream, device=dev)
         self._g_emotion = torch.zeros(self.n_streams, self.engine.emotion_dim, device=dev)
         torch.cuda.synchronize(dev)
@@ -69,7 +72,10 @@ class StreamEngine:
         with torch.cuda.graph(g):
             self.push(self._g_samples)
             self.tick(self._g_emotion)
+            if host_out is not None:
+                host_out.copy_(self.out, non_blocking=True)
         self._graph = g
+        self._g_host_out = host_out
 
     def replay(self, samples: torch.Tensor, emotion: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         if self._graph is None:

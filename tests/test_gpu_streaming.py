@@ -36,9 +36,12 @@ def test_streams_match_oracle_and_graph_replay():
     for t in range(TICKS):
         frame = audio[:, t * 533:(t + 1) * 533]
         if t == use_graph_from:
-            se.capture(533)
+            host_out = torch.empty(S, 52).pin_memory()
+            se.capture(533, host_out=host_out)             # the readback is the graph's last node
         if t >= use_graph_from:
             out, ready = se.replay(dev(frame), dev(emo))
+            torch.cuda.synchronize()
+            assert np.array_equal(host_out.numpy(), out.cpu().numpy())
         else:
             se.push(dev(frame))
             out, ready = se.tick(dev(emo))
