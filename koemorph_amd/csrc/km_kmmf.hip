@@ -48,9 +48,9 @@ constexpr int XS = 264;              // row stride of the LDS images (floats)
 constexpr int KBD = D / 16;          // k blocks of a 256-wide contraction
 constexpr int RED = 2 * 64 * NW + 2 * 64;   // LayerNorm partials [pass][row][wave] + totals [pass][row] of 64 rows x 8 waves
 // encoder kernel: 256 threads (4 waves: wave = heads w and w + 4 in the attention phase, = 64 columns elsewhere) on 32 rows,
-// 70 KB of LDS: TWO workgroups per CU, whose barrier-separated phases drift apart -- one's LayerNorm / GELU / softmax / weight
-// round trips under the other's MFMAs (one 512-thread workgroup on 64 rows kept both waves of a SIMD in the same phase:
-// matrix pipe 0.76 busy)
+// 70 KB of LDS: TWO independent workgroups per CU instead of one 512-thread workgroup on 64 rows whose two waves per SIMD
+// sit in the same barrier-separated phase.  Measured: the split alone changes nothing (0.785 against 0.786 ms per forward),
+// but pinned weight prefetch (mm_cols PIN 1) gains 4 % in this form and loses in the other
 constexpr int ENTH = 256;
 constexpr int ENW = 4;
 constexpr int EROWS = 32;
