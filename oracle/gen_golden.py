@@ -179,6 +179,11 @@ KOEMORPH_CASES = [
                                                       decoder_hidden_dim=32, decoder_layers=1, emotion_dim=24,
                                                       decoder_activation="leaky_relu", output_activation="tanh", use_constraints=False),
          B=2, T=20, seed=67, frames=3),
+    # the default width (the two fused kernels of km_kmmf.hip) with a padded batch, and with windows of <= 16 frames that share
+    # MFMA row tiles in the fused encoder (ragged padding, no causal / local-window mask, swish decoder)
+    dict(name="koemorph_d256_T30_padded", cfg=dict(), B=3, T=30, seed=69, valid=[30, 19, 8]),
+    dict(name="koemorph_d256_T12_open", cfg=dict(causal=False, window_size=None, decoder_activation="swish"), B=5, T=12, seed=70,
+         valid=[12, 12, 7, 12, 3], frames=3),
     dict(name="koemorph_d64_T20_none", cfg=dict(d_model=64, num_heads=4, num_encoder_layers=1, num_attention_layers=1,
                                                 decoder_hidden_dim=32, decoder_layers=1, emotion_dim=24, output_activation="none"),
          B=2, T=20, seed=68, frames=3),

@@ -46,7 +46,7 @@ def assert_same(got, want, atol):
 
 
 def test_golden_files_present():
-    assert len(GOLDEN) == 8
+    assert len(GOLDEN) == 10
 
 
 @pytest.mark.parametrize("path", [p for p in GOLDEN if "swish" in p or "leaky" in p or "none" in p],
