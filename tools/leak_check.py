@@ -27,7 +27,10 @@ def cycle(i):
     m = KoeMorphModel(d_model=64, d_query=64, num_heads=4, num_encoder_layers=1, num_attention_layers=1, decoder_hidden_dim=32, emotion_dim=8).cuda().eval()
     with torch.no_grad():
         m(torch.randn(2, 12, 80, device="cuda"), torch.randn(2, 12, 8, device="cuda"))
-    del tr, eng, g, m, audio, emo
+    mf = KoeMorphModel(d_query=256).cuda().eval()       # default width: the two fused kernels and their weight blobs
+    with torch.no_grad():
+        mf(torch.randn(3, 30, 80, device="cuda"), torch.randn(3, 30, 256, device="cuda"))
+    del tr, eng, g, m, mf, audio, emo
     gc.collect(); torch.cuda.empty_cache()
 
 
