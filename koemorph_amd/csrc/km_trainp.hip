@@ -396,6 +396,7 @@ __device__ __forceinline__ void attn_bwd_mfma_dev(const ElemArgs& a, int vb, flo
     __syncthreads();
 }
 
+template <bool ATTN>
 __device__ __forceinline__ void op_elem(const Op& op, int vb, float* smem) {
     const ElemArgs& a = op.e;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -552,16 +553,34 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, float* smem) {
         break;
     }
     case OP_ATTN_FWD:
-        if (a.i1 == 32) attn_fwd_mfma_dev<32>(a, vb, smem); else if (a.i1 == 64) attn_fwd_mfma_dev<64>(a, vb, smem); else attn_fwd_mfma_dev<16>(a, vb, smem);
+        if constexpr (!ATTN) break;
+        else if (a.i1 == 32) attn_fwd_mfma_dev<32>(a, vb, smem); else if (a.i1 == 64) attn_fwd_mfma_dev<64>(a, vb, smem); else attn_fwd_mfma_dev<16>(a, vb, smem);
         break;
     case OP_ATTN_BWD:
-        if (a.i1 == 32) attn_bwd_mfma_dev<32>(a, vb, smem); else if (a.i1 == 64) attn_bwd_mfma_dev<64>(a, vb, smem); else attn_bwd_mfma_dev<16>(a, vb, smem);
+        if constexpr (!ATTN) break;
+        else if (a.i1 == 32) attn_bwd_mfma_dev<32>(a, vb, smem); else if (a.i1 == 64) attn_bwd_mfma_dev<64>(a, vb, smem); else attn_bwd_mfma_dev<16>(a, vb, smem);
         break;
     default: break;
     }
 }
 
-__global__ __launch_bounds__(256) void phase_kernel(Phase p) {
+// Occupancy is the lever of these phases: a workgroup is four waves (one per SIMD) that stop at a barrier every k-step, so what
+// hides a wave's LDS and L2 round trips is the number of OTHER workgroups on the CU.  Two instantiations: phases without an
+// attention block run with 2 k-tiles of operand loads in flight per thread (4 before) under a 96-register cap = 5 workgroups
+// per CU (the 160 KB of LDS allow exactly five 32 KB tile buffers); the two attention phases need more registers and LDS.
+// Measured at 8 / 64 windows per step: 3 waves per SIMD, depth 4 (round-3 start) 0.2122 / 0.444 ms; 4 waves (27 registers
+// spilled) 0.2057 / 0.428; 4 waves, depth 2 (no spills) 0.2022 / 0.4055; 5 waves, depth 2 0.1984 / 0.3998.
+#ifndef KM_TRAINP_D
+#define KM_TRAINP_D 2          /* k-tiles of operand loads in flight per thread (gemm_tile_dev) */
+#endif
+#ifndef KM_TRAINP_WAVES
+#define KM_TRAINP_WAVES 5      /* waves per SIMD the phases without attention blocks are compiled for */
+#endif
+#ifndef KM_TRAINP_WAVES_ATTN
+#define KM_TRAINP_WAVES_ATTN 4
+#endif
+template <bool ATTN>
+__global__ __launch_bounds__(256, ATTN ? KM_TRAINP_WAVES_ATTN : KM_TRAINP_WAVES) void phase_kernel(Phase p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // the host sizes it for the phase's largest operation
     const int vb = blockIdx.x;
     int i = 0;
@@ -574,16 +593,16 @@ __global__ __launch_bounds__(256) void phase_kernel(Phase p) {
         const int tx = t % op.gx, ty = t / op.gx;
         // operand B of the channel encoder (rows of 259 floats) is the one product without 16-byte rows
         if (op.bm == 32) {
-            if (op.va && op.vb) gemm_tile_dev<32, 4, true, true>(op.g, tx, ty, bz, smem);
-            else if (op.va) gemm_tile_dev<32, 4, true, false>(op.g, tx, ty, bz, smem);
-            else gemm_tile_dev<32, 4, false, false>(op.g, tx, ty, bz, smem);
+            if (op.va && op.vb) gemm_tile_dev<32, KM_TRAINP_D, true, true>(op.g, tx, ty, bz, smem);
+            else if (op.va) gemm_tile_dev<32, KM_TRAINP_D, true, false>(op.g, tx, ty, bz, smem);
+            else gemm_tile_dev<32, KM_TRAINP_D, false, false>(op.g, tx, ty, bz, smem);
         } else {
-            if (op.va && op.vb) gemm_tile_dev<64, 4, true, true>(op.g, tx, ty, bz, smem);
-            else if (op.va) gemm_tile_dev<64, 4, true, false>(op.g, tx, ty, bz, smem);
-            else gemm_tile_dev<64, 4, false, false>(op.g, tx, ty, bz, smem);
+            if (op.va && op.vb) gemm_tile_dev<64, KM_TRAINP_D, true, true>(op.g, tx, ty, bz, smem);
+            else if (op.va) gemm_tile_dev<64, KM_TRAINP_D, true, false>(op.g, tx, ty, bz, smem);
+            else gemm_tile_dev<64, KM_TRAINP_D, false, false>(op.g, tx, ty, bz, smem);
         }
     } else {
-        op_elem(op, local, smem);
+        op_elem<ATTN>(op, local, smem);
     }
 }
 
@@ -604,12 +623,14 @@ struct Program {
     int blocks = 0;
     int rc = KM_OK;
     size_t lds = 0;
+    bool has_attn = false;        // the phase holds an attention block: phase_kernel<true>
     float* scratch = nullptr;            // bump allocator for the partials of a step
     int64_t scratch_left = 0;
     std::vector<PendingReduce> pend_prev, pend_cur;
     bool allow_split = true;
     // S for a product of K rows with `tiles` output tiles, or 1
     int min_k = kSplitMinK, chain = 640;
+    int bm32_below = 192;                // products with fewer 64-row tiles than this run on 32-row tiles
     int split_factor(int64_t K, int tiles) const {
         if (K <= min_k || tiles >= 128) return 1;
         const int want = (int)((K + chain - 1) / chain);
@@ -651,7 +672,7 @@ struct Program {
         Op op{};
         op.kind = OP_GEMM; op.g = g;
         op.gx = (g.N + 63) / 64; op.gy = (g.M + 63) / 64; op.bm = 64;
-        if (g.M <= 32 || op.gx * op.gy * batch < 192) { op.bm = 32; op.gy = (g.M + 31) / 32; }   // finer tiles: more CUs, half the chain
+        if (g.M <= 32 || op.gx * op.gy * batch < bm32_below) { op.bm = 32; op.gy = (g.M + 31) / 32; }   // finer tiles: more CUs, half the chain
         need_lds((size_t)ggd::lds_floats(op.bm) * sizeof(float));
         if ((g.a_cs != 1 && g.a_rs != 1) || (g.b_rs != 1 && g.b_cs != 1)) {
             rc = fail(KM_ERR_UNSUPPORTED, "training program: an operand is contiguous neither along k nor along its rows");
@@ -670,6 +691,7 @@ struct Program {
     void need_lds(size_t bytes) { if (bytes > lds) lds = bytes; }
     void elem(int kind, const ElemArgs& e, int64_t nblocks) {
         Op op{};
+        if (kind == OP_ATTN_FWD || kind == OP_ATTN_BWD) has_attn = true;
         op.kind = kind; op.e = e;
         add(op, (int)nblocks);
     }
@@ -696,12 +718,14 @@ struct Program {
         pend_prev.swap(pend_cur);
         if (rc) return rc;
         if (cur.n_ops > 0) {
-            hipLaunchKernelGGL(phase_kernel, dim3((unsigned)blocks), dim3(256), lds, st, cur);
+            if (has_attn) hipLaunchKernelGGL(phase_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, cur);
+            else hipLaunchKernelGGL(phase_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, st, cur);
             HIP_TRY(hipGetLastError());
         }
         cur = Phase{};
         blocks = 0;
         lds = 0;
+        has_attn = false;
         return KM_OK;
     }
 };
@@ -852,7 +876,10 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
 
     static PerDeviceOnce once;
     if (once.first(c->device))
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&phase_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&phase_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&phase_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     const size_t attn_lds = (size_t)attn_mfma_lds_floats((int)hd, (int)NKk) * sizeof(float);
     if (attn_lds > 160 * 1024 || (hd != 16 && hd != 32 && hd != 64))
         return fail(KM_ERR_UNSUPPORTED, "the fused training attention blocks are built for heads of 16, 32 or 64 columns (got %lld)", (long long)hd);
@@ -860,6 +887,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     Program pg;
     pg.scratch = c->trp_split; pg.scratch_left = c->trp_split_floats;
     pg.allow_split = !c->opt.train_no_split;
+    if (c->opt.train_bm32_below > 0) pg.bm32_below = c->opt.train_bm32_below;
     if (c->opt.train_split_min_k > 0) { pg.min_k = c->opt.train_split_min_k; pg.chain = c->opt.train_split_min_k; }
     auto blocks4 = [](int64_t rows) { return (rows + 3) / 4; };            // one wave per row, 4 rows per block
     auto blocks256 = [](int64_t n) { return (n + 255) / 256; };
