@@ -631,6 +631,7 @@ struct Program {
     // S for a product of K rows with `tiles` output tiles, or 1
     int min_k = kSplitMinK, chain = 640;
     int bm32_below = 192;                // products with fewer 64-row tiles than this run on 32-row tiles
+    bool op_per_launch = false; hipStream_t dbg_stream = nullptr;
     int split_factor(int64_t K, int tiles) const {
         if (K <= min_k || tiles >= 128) return 1;
         const int want = (int)((K + chain - 1) / chain);
@@ -646,6 +647,11 @@ struct Program {
         blocks += nblocks;
         cur.block_end[cur.n_ops] = blocks;
         ++cur.n_ops;
+        if (op_per_launch) {      // timing aid (option train_op_per_launch): every operation is its own launch, in program order
+            if (has_attn) hipLaunchKernelGGL(phase_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, dbg_stream, cur);
+            else hipLaunchKernelGGL(phase_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, dbg_stream, cur);
+            cur = Phase{}; blocks = 0; lds = 0; has_attn = false;
+        }
     }
     void gemm(const GemmArgs& g_in, int batch) {
         GemmArgs g = g_in;
@@ -888,6 +894,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     pg.scratch = c->trp_split; pg.scratch_left = c->trp_split_floats;
     pg.allow_split = !c->opt.train_no_split;
     if (c->opt.train_bm32_below > 0) pg.bm32_below = c->opt.train_bm32_below;
+    pg.op_per_launch = c->opt.train_op_per_launch != 0; pg.dbg_stream = st;
     if (c->opt.train_split_min_k > 0) { pg.min_k = c->opt.train_split_min_k; pg.chain = c->opt.train_split_min_k; }
     auto blocks4 = [](int64_t rows) { return (rows + 3) / 4; };            // one wave per row, 4 rows per block
     auto blocks256 = [](int64_t n) { return (n + 255) / 256; };
@@ -1056,12 +1063,6 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     }
     pg.gemm(NN(dO2, d, Wmo, d, dO1, d, Rm, d, d), 1);
     pg.gemm(NN(dOe2, d, Weo, d, dOe1, d, Re, d, d), 1);
-    pg.gemm(TN(dO2, d, O1, d, Gd("mel_output_proj.weight"), d, d, d, Rm), 1);
-    pg.gemm(TN(dOe2, d, Oe1, d, Gd("emotion_output_proj.weight"), d, d, d, Re), 1);
-    colsum(dO2, Rm, d, d, Gd("mel_output_proj.bias"), 0, ones);
-    colsum(dOe2, Re, d, d, Gd("emotion_output_proj.bias"), 0, ones);
-    { GemmArgs g = TN(dHe, DH, Oe2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, Re); g.beta = 1.f; pg.gemm(g, 1); }
-    colsum(dHe, Re, DH, DH, Gd("blendshape_decoder.0.bias"), 1, ones);
     RUN(pg.end_phase(st));
     // ================= P10: dY; in_proj [K | V] gradients; dQ; out_proj gradients; emotion value projection backward =================
     pg.gemm(NN(dKV, 2 * d, inw + d * d, d, dY, d, R, d, 2 * d), 1);
@@ -1075,6 +1076,14 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     pg.gemm(TN(dVe, d, E, d, gein_w + 2 * d * d, d, d, d, B), 1);                                           // only the V third of in_proj
     colsum(dVe, B, d, d, gein_b + 2 * d, 0, ones);
     pg.gemm(NN(dVe, d, einw + 2 * d * d, d, dE, d, B, d, d), 1);
+    // (the parameter gradients of the output projections and of decoder[0]'s emotion rows need nothing of P9: they sit here (behind the products the next phase waits for), where
+    // a CU takes five tile workgroups -- the attention blocks' 64 KB of LDS leave room for two in P9)
+    pg.gemm(TN(dO2, d, O1, d, Gd("mel_output_proj.weight"), d, d, d, Rm), 1);
+    pg.gemm(TN(dOe2, d, Oe1, d, Gd("emotion_output_proj.weight"), d, d, d, Re), 1);
+    colsum(dO2, Rm, d, d, Gd("mel_output_proj.bias"), 0, ones);
+    colsum(dOe2, Re, d, d, Gd("emotion_output_proj.bias"), 0, ones);
+    { GemmArgs g = TN(dHe, DH, Oe2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, Re); g.beta = 1.f; pg.gemm(g, 1); }
+    colsum(dHe, Re, DH, DH, Gd("blendshape_decoder.0.bias"), 1, ones);
     RUN(pg.end_phase(st));
     // ================= P11: LayerNorm backward (both streams); query-side gradients (+ the partial sums of P10's products) =========
     {
