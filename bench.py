@@ -594,6 +594,36 @@ def _cpu_front_range_cfg(r):
     return [omel.mel_batch_window(_CPU_POOL_AUDIO[i], sample_rate=16000, n_fft=1024, hop=r[2]) for i in range(r[0], r[1])]
 
 
+def cpu_baseline_c5(args, params, frames_np, emo_np):
+    """The reference's per-tick loop for ONE stream on this host (scripts/rt.py:343-381 with the sliding-window extractor,
+    mel_sliding_window.py:252-324): ring push of one 533-sample frame, the full 8.5 s window's log-mel (n_fft 1024, hop 533),
+    the core at B = 1, the EMA.  One tick = one blendshape frame of that stream; bounded by --cpu-seconds."""
+    import numpy as np
+    import torch
+    from oracle import buffers, core as ocore, mel as omel, smoothing
+    n_all = usable_cpus()
+    torch.set_num_threads(n_all)
+    ring = buffers.MelAudioBufferOracle()
+    sm = smoothing.TemporalSmootherOracle(0.8)
+    t = 0
+    while not ring.is_full:
+        ring.add_audio_frame(frames_np[0, (t % 8) * 533:(t % 8 + 1) * 533])
+        t += 1
+    tick_no = [t]
+
+    def tick():
+        k = tick_no[0]
+        tick_no[0] += 1
+        ring.add_audio_frame(frames_np[0, (k % 8) * 533:(k % 8 + 1) * 533])
+        feats = omel.mel_sliding_window(ring.get_current_audio(), n_fft=1024, hop=533)
+        return sm(ocore.core_forward_np(params, feats[None], feats[None, -3:], emo_np[:1])["blendshapes"])
+    rate, done, secs = _cpu_rate(tick, 1, args.cpu_seconds, 400)
+    return {"value": round(rate, 2), "unit": "frames/s", "cores": n_all, "kind": "port",
+            "sample": f"{done} ticks of ONE stream in {secs:.1f} s of CPU work (ring push, numpy sliding-window log-mel of the 8.5 s window, "
+                      f"torch-CPU fp32 core at B = 1 on {n_all} threads, EMA): {rate / 30.0:.1f} streams in real time at 30 ticks/s",
+            "streams_in_real_time": round(rate / 30.0, 2)}
+
+
 def cpu_baseline_c3(args, params, audio_np, emo_np, target_np, dropout: float):
     """BASELINE.md section 3, training: ONE optimizer step of the restated path at B = 8 on all usable host cores -- numpy
     front end (one window per call, as the reference's extract_mel_features loops), torch-CPU core forward in training
@@ -800,6 +830,9 @@ def run_c5(args, rk: Ranks):
         lat.append(time.perf_counter() - t0)
 
     dt = timed(rk, tick, args.steps, args.warmup)
+    cpu = None
+    if rk.rank == 0 and rk.world == 1 and args.cpu_seconds > 0:
+        cpu = cpu_baseline_c5(args, synth.make_core_params(0), frames.cpu().numpy(), emo.cpu().numpy())
     lat_ms = np.array(lat[args.warmup:]) * 1e3
     ms = dt / args.steps * 1e3
     value = S * rk.world * args.steps / dt
@@ -817,7 +850,7 @@ def run_c5(args, rk: Ranks):
                      "achieved": round(EXECUTED_MFMA_FLOPS_PER_FRAME * S / (ms * 1e-3) / 1e12, 3), "peak": PEAK_F32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(EXECUTED_MFMA_FLOPS_PER_FRAME * S / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                      "traffic": None},
-        "cpu_baseline": None,
+        "cpu_baseline": cpu,
     }
 
 
