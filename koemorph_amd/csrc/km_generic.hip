@@ -282,7 +282,7 @@ int launch_gemm(const GemmArgs& g, int batch, void* stream) {
     const int64_t wgs4 = mt_wgs * ((g.N + 127) / 128), wgs2 = mt_wgs * ((g.N + 63) / 64), wgs22 = mt64_wgs * ((g.N + 63) / 64);
     static const bool mid = std::getenv("KM_GEMM_NO_NT2_MID") == nullptr;
     static const bool small = std::getenv("KM_GEMM_NO_64_TILE") == nullptr;
-    static const int64_t small_below = std::getenv("KM_GEMM_64_BELOW") ? atoll(std::getenv("KM_GEMM_64_BELOW")) : 1024;   // < 4 big tiles per CU
+    static const int64_t small_below = std::getenv("KM_GEMM_64_BELOW") ? atoll(std::getenv("KM_GEMM_64_BELOW")) : 4096;   // < 16 big tiles per CU (1024 until round 3: the legacy model's 1028-tile products run 12 % faster on 64 x 64 tiles, eight waves per SIMD against three)
     const bool use4 = g.N > 64 && wgs4 >= KM_NT_MIN_WGS;
     const bool use2 = !use4 && wgs2 >= KM_NT_MIN_WGS && (mid || g.N <= 64);
     const bool use22 = small && gemm_nt_ok(g) && ((!use4 && !use2 && wgs22 >= KM_NT_MIN_WGS) || ((use4 ? wgs4 : wgs2) < small_below && (use4 || use2)));
