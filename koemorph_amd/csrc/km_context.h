@@ -70,6 +70,7 @@ struct Options {
     int mel_two_frame = 0;         // 1: two-frames-per-wave front end (A/B baseline)
     int emotion_separate = 0;      // 1: emotion logits in their own kernel
     int no_ln_fusion = 0, no_db_fusion = 0, no_score_fusion = 0, no_out_fusion = 0, no_v_fusion = 0;   // generic chain A/B
+    int legacy_no_attn_fusion = 0; // 1: SimplifiedKoeMorphModel attention as two batched strided products + a row softmax (A/B, tests)
     int kmm_no_fuse = 0;           // 1: KoeMorphModel as the launch-per-step chain even at the fused kernels' width (A/B, tests)
     int train_chain = 0;           // 1: training step as the round-1 launch-per-op chain (A/B reference; no dropout)
     int train_no_split = 0;        // 1: no split-K of the long gradient products of the phased training step (A/B)

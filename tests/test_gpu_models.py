@@ -275,3 +275,16 @@ def test_legacy_simplified_koemorph_model():
     assert m.extract_mel_features(dev(audio)).shape == (2, 257, 80)
     with pytest.raises(ValueError):
         m(dev(audio)[0])
+    # the attention as one register-resident kernel (the default at 32-wide heads) against two batched products + a row softmax,
+    # at frame counts that fill the last key tile, leave one key in it, and fit in one tile
+    from koemorph_amd import _lib
+    lib, h, _ = m._handle()
+    for T in (257, 256, 250, 16, 5):
+        melT = synth.uniform(10 + T, (5, T, 80), 0, 1)
+        res = {}
+        for mode in (0, 1):
+            _lib.check(lib.km_set_option(h, b"legacy_no_attn_fusion", mode))
+            res[mode] = m.forward_mel(dev(melT)).cpu().numpy()
+        _lib.check(lib.km_set_option(h, b"legacy_no_attn_fusion", 0))
+        want = legacy.legacy_forward_mel(params, melT)
+        assert np.abs(res[0] - want).max() < 5e-6 and np.abs(res[1] - want).max() < 5e-6, T
