@@ -443,7 +443,7 @@ int km_linear(const float* x_dev, const float* w_dev, const float* b_dev, int64_
  * "seq_per_window", "generic_staged", "mel_two_frame", "emotion_separate", "no_ln_fusion", "no_db_fusion",
  * "no_score_fusion", "no_out_fusion", "no_v_fusion", "train_chain" (training step as the launch-per-op chain),
  * "kmm_no_fuse" (km_koemorph_forward as the launch-per-step GEMM chain even at the width of the two fused kernels),
- * "legacy_no_attn_fusion" (km_legacy_forward's attention as two batched products + a row softmax), "train_op_per_launch" (timing aid:
+ * "legacy_no_enc_fusion" / "legacy_no_attn_fusion" / "legacy_no_tail_fusion" (km_legacy_forward's three fused kernels back to GEMM-chain launches), "train_op_per_launch" (timing aid:
  * every operation of the training program as its own launch), "train_bm32_below", "train_tail_groups", "train_split_min_k".  A handle's switches start from the environment
  * variables KM_<NAME> read ONCE in km_create; no launch path reads the environment.  Unknown name: KM_ERR_INVALID_ARG. */
 int km_set_option(km_handle h, const char* name, int64_t value);

@@ -70,6 +70,8 @@ struct Options {
     int mel_two_frame = 0;         // 1: two-frames-per-wave front end (A/B baseline)
     int emotion_separate = 0;      // 1: emotion logits in their own kernel
     int no_ln_fusion = 0, no_db_fusion = 0, no_score_fusion = 0, no_out_fusion = 0, no_v_fusion = 0;   // generic chain A/B
+    int legacy_no_tail_fusion = 0; // 1: SimplifiedKoeMorphModel out_proj + decoder as four GEMM launches + a row kernel (A/B, tests)
+    int legacy_no_enc_fusion = 0;  // 1: SimplifiedKoeMorphModel audio encoder + key / value projections as four GEMM launches (A/B, tests)
     int legacy_no_attn_fusion = 0; // 1: SimplifiedKoeMorphModel attention as two batched strided products + a row softmax (A/B, tests)
     int kmm_no_fuse = 0;           // 1: KoeMorphModel as the launch-per-step chain even at the fused kernels' width (A/B, tests)
     int train_chain = 0;           // 1: training step as the round-1 launch-per-op chain (A/B reference; no dropout)
@@ -102,6 +104,8 @@ struct Context {
     int legacy_hidden = 128;
     km_koemorph_config kmm{};                    // kind 2
     int64_t kmm_batch = 0, kmm_frames = 0;       // kind 2: reserved workspace (ws_generic)
+    bool legacy_tail_fused = false;              // kind 1: the blob of legacy_tail_kernel exists as well (decoder 128 wide, 52 queries)
+    bool legacy_fused = false;                   // kind 1: the blob of legacy_encoder_kernel exists (d_model 256, 80 mel bins, 8 heads)
     bool kmm_fused = false;                      // kind 2: the model has the width of the fused kernels (km_kmmf.hip) and their blobs exist
     int d = 0, H = 0, hd = 0, T = 0, KT = 0, ED = 0, DH = 0, NB = 0, NK = 0;
     std::map<std::string, HostParam> params;     // reference state-dict tensors (fp32 masters)

@@ -859,6 +859,9 @@ __global__ __launch_bounds__(256) void legacy_attention_kernel(const float* __re
     }
 }
 
+int launch_legacy_encoder_fused(Context* c, const float* mel, int64_t rows, float* Kp, float* Vp, void* stream);      // km_kmmf.hip
+int launch_legacy_tail_fused(Context* c, const float* O, int64_t B, float* out, void* stream);
+
 int launch_legacy(Context* c, const float* mel, int64_t B, int64_t Tm, float* out, void* stream) {
     const int d = c->d, H = c->H, hd = c->hd, NQ = c->NB, hid = c->legacy_hidden, NKk = c->NK;
     float* E1 = c->ws_generic;
@@ -871,12 +874,17 @@ int launch_legacy(Context* c, const float* mel, int64_t B, int64_t Tm, float* ou
     float* D1 = A1 + B * NQ * d;
     float* D2 = D1 + B * NQ * hid;
     float* D3 = D2 + B * NQ * hid;
+    if (c->legacy_fused && !c->opt.legacy_no_enc_fusion && (reinterpret_cast<uintptr_t>(mel) & 15) == 0) {
+        // audio_encoder + key / value projections with the hidden activations resident in LDS (km_kmmf.hip)
+        if (int rc = launch_legacy_encoder_fused(c, mel, B * Tm, Kp, Vp, stream)) return rc;
+    } else {
     // audio_encoder: Linear(80,d) ReLU [Dropout] Linear(d,d) ReLU [Dropout]   (:44-51, :129)
     if (int rc = launch_gemm(lin(mel, NKk, dv(c, "l_w0"), NKk, E1, B * Tm, d, dv(c, "l_b0"), 1), 1, stream)) return rc;
     if (int rc = launch_gemm(lin(E1, d, dv(c, "l_w3"), d, E, B * Tm, d, dv(c, "l_b3"), 1), 1, stream)) return rc;
     // nn.MultiheadAttention(query = 52 learnable rows, key = value = encoded frames)   (:136-141)
     if (int rc = launch_gemm(lin(E, d, dv(c, "l_wk"), d, Kp, B * Tm, d, dv(c, "l_bk"), 0), 1, stream)) return rc;
     if (int rc = launch_gemm(lin(E, d, dv(c, "l_wv"), d, Vp, B * Tm, d, dv(c, "l_bv"), 0), 1, stream)) return rc;
+    }
     if (hd == 32 && NQ <= 64 && !c->opt.legacy_no_attn_fusion) {
         hipLaunchKernelGGL(legacy_attention_kernel, dim3((unsigned)((B * H + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dv(c, "l_q"), Kp, Vp, O,
                            B * H, (int)Tm, H, NQ);
@@ -899,6 +907,8 @@ int launch_legacy(Context* c, const float* mel, int64_t B, int64_t Tm, float* ou
     g.M = NQ; g.N = hd; g.K = (int)Tm; g.batch2 = H;
     if (int rc = launch_gemm(g, (int)(B * H), stream)) return rc;
     }
+    if (c->legacy_fused && c->legacy_tail_fused && !c->opt.legacy_no_tail_fusion)      // out_proj + decoder + mean with the 52 rows resident in LDS
+        return launch_legacy_tail_fused(c, O, B, out, stream);
     if (int rc = launch_gemm(lin(O, d, dv(c, "l_wo"), d, A1, B * NQ, d, dv(c, "l_bo"), 0), 1, stream)) return rc;
     // decoder: Linear(d,hid) ReLU Linear(hid,hid) ReLU Linear(hid,52) Sigmoid, then mean over the query rows (:63-72, :144-147)
     if (int rc = launch_gemm(lin(A1, d, dv(c, "l_d0w"), d, D1, B * NQ, hid, dv(c, "l_d0b"), 1), 1, stream)) return rc;

@@ -118,6 +118,8 @@ static void fold_chain(const dvec& bin, const dvec& Wa, const dvec& ba, const dv
     for (int i = 0; i < DH; ++i) f[i] += b1[i];
 }
 
+static void pack_frag(const std::vector<float>& W, int N, int K, int Kpad, float* dst);
+
 // SimplifiedKoeMorphModel (simplified_model.py:44-77): the queries are input independent, so
 // Q = (blendshape_queries Wq^T + bq) / sqrt(hd) is precomputed; everything else keeps the reference's layers.
 int finalize_host_legacy(Context* c) {
@@ -142,6 +144,41 @@ int finalize_host_legacy(Context* c) {
                             {"l_d3w", "decoder.3.weight"}, {"l_d3b", "decoder.3.bias"},
                             {"l_d6w", "decoder.6.weight"}, {"l_d6b", "decoder.6.bias"}};
     for (auto& r : raw) put(c, r[0], std::vector<float>(P(c, r[1])));
+    // the audio encoder and the key / value projections as ONE rows-resident kernel (km_kmmf.hip legacy_encoder_kernel): weights in
+    // MFMA fragment order (km_kmmf.h), at the reference's width
+    c->legacy_fused = false;
+    if (d == kmmf::D && c->NK == kmmf::LG_MEL && c->H == kmmf::HEADS) {
+        using namespace kmmf;
+        std::vector<float> blob((size_t)LG_FLOATS, 0.f);
+        pack_frag(P(c, "audio_encoder.0.weight"), D, LG_MEL, LG_MEL, blob.data() + LG_W0);
+        std::copy(P(c, "audio_encoder.0.bias").begin(), P(c, "audio_encoder.0.bias").end(), blob.begin() + LG_B0);
+        pack_frag(P(c, "audio_encoder.3.weight"), D, D, D, blob.data() + LG_W3);
+        std::copy(P(c, "audio_encoder.3.bias").begin(), P(c, "audio_encoder.3.bias").end(), blob.begin() + LG_B3);
+        const std::vector<float>& inw_f = P(c, "attention.in_proj_weight");
+        const std::vector<float>& inb_f = P(c, "attention.in_proj_bias");
+        pack_frag(std::vector<float>(inw_f.begin() + (size_t)D * D, inw_f.begin() + (size_t)2 * D * D), D, D, D, blob.data() + LG_WK);
+        std::copy(inb_f.begin() + D, inb_f.begin() + 2 * D, blob.begin() + LG_BK);
+        pack_frag(std::vector<float>(inw_f.begin() + (size_t)2 * D * D, inw_f.end()), D, D, D, blob.data() + LG_WV);
+        std::copy(inb_f.begin() + 2 * D, inb_f.end(), blob.begin() + LG_BV);
+        put(c, "lgf_enc", std::move(blob));
+        c->legacy_fused = true;
+        c->legacy_tail_fused = false;
+        if (c->legacy_hidden == HID && NQ == kmmf::NQ) {     // out_proj + decoder + sigmoid + mean over the query rows: legacy_tail_kernel
+            std::vector<float> t((size_t)LT_FLOATS, 0.f);
+            pack_frag(P(c, "attention.out_proj.weight"), D, D, D, t.data() + LT_WO);
+            std::copy(P(c, "attention.out_proj.bias").begin(), P(c, "attention.out_proj.bias").end(), t.begin() + LT_BO);
+            pack_frag(P(c, "decoder.0.weight"), HID, D, D, t.data() + LT_W0);
+            std::copy(P(c, "decoder.0.bias").begin(), P(c, "decoder.0.bias").end(), t.begin() + LT_B0);
+            pack_frag(P(c, "decoder.3.weight"), HID, HID, HID, t.data() + LT_W3);
+            std::copy(P(c, "decoder.3.bias").begin(), P(c, "decoder.3.bias").end(), t.begin() + LT_B3);
+            std::vector<float> w6((size_t)64 * HID, 0.f);
+            std::copy(P(c, "decoder.6.weight").begin(), P(c, "decoder.6.weight").end(), w6.begin());
+            pack_frag(w6, 64, HID, HID, t.data() + LT_W6);
+            std::copy(P(c, "decoder.6.bias").begin(), P(c, "decoder.6.bias").end(), t.begin() + LT_B6);
+            put(c, "lgf_tail", std::move(t));
+            c->legacy_tail_fused = true;
+        }
+    }
     c->fused_ok = false;
     c->host_finalized = true;
     return KM_OK;
@@ -618,7 +655,7 @@ const OptName kOptNames[] = {
     {"generic_staged", &Options::generic_staged}, {"mel_two_frame", &Options::mel_two_frame},
     {"emotion_separate", &Options::emotion_separate}, {"no_ln_fusion", &Options::no_ln_fusion},
     {"no_db_fusion", &Options::no_db_fusion}, {"no_score_fusion", &Options::no_score_fusion},
-    {"no_out_fusion", &Options::no_out_fusion}, {"no_v_fusion", &Options::no_v_fusion}, {"train_chain", &Options::train_chain}, {"kmm_no_fuse", &Options::kmm_no_fuse}, {"legacy_no_attn_fusion", &Options::legacy_no_attn_fusion},
+    {"no_out_fusion", &Options::no_out_fusion}, {"no_v_fusion", &Options::no_v_fusion}, {"train_chain", &Options::train_chain}, {"kmm_no_fuse", &Options::kmm_no_fuse}, {"legacy_no_attn_fusion", &Options::legacy_no_attn_fusion}, {"legacy_no_enc_fusion", &Options::legacy_no_enc_fusion}, {"legacy_no_tail_fusion", &Options::legacy_no_tail_fusion},
     {"train_no_split", &Options::train_no_split}, {"train_dwce_parts", &Options::train_dwce_parts},
     {"train_tail_groups", &Options::train_tail_groups}, {"train_bm32_below", &Options::train_bm32_below}, {"train_op_per_launch", &Options::train_op_per_launch}, {"train_split_min_k", &Options::train_split_min_k},
 };

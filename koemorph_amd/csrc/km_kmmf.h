@@ -64,4 +64,27 @@ constexpr int64_t DL_LNG = DL_B + HID;
 constexpr int64_t DL_LNB = DL_LNG + HID;
 constexpr int64_t DEC_LAYER = DL_LNB + HID;
 
+// ---- legacy SimplifiedKoeMorphModel blob "lgf_enc" (d_model 256, 80 mel bins): audio_encoder + key / value projections ----
+constexpr int LG_MEL = 80;
+constexpr int64_t LG_W0 = 0;                                // audio_encoder.0 (256 x 80), 5 k blocks per tile
+constexpr int64_t LG_B0 = LG_W0 + (int64_t)D * LG_MEL;
+constexpr int64_t LG_W3 = LG_B0 + D;                        // audio_encoder.3 (256 x 256)
+constexpr int64_t LG_B3 = LG_W3 + (int64_t)D * D;
+constexpr int64_t LG_WK = LG_B3 + D;                        // attention in_proj rows [d, 2 d)
+constexpr int64_t LG_BK = LG_WK + (int64_t)D * D;
+constexpr int64_t LG_WV = LG_BK + D;                        // attention in_proj rows [2 d, 3 d)
+constexpr int64_t LG_BV = LG_WV + (int64_t)D * D;
+constexpr int64_t LG_FLOATS = LG_BV + D;
+// blob "lgf_tail": attention out_proj and the decoder (Linear(256, 128) ReLU Linear(128, 128) ReLU Linear(128, 52) Sigmoid); the last
+// weight padded to 64 rows (rows 52 .. 63 zero)
+constexpr int64_t LT_WO = 0;
+constexpr int64_t LT_BO = LT_WO + (int64_t)D * D;
+constexpr int64_t LT_W0 = LT_BO + D;
+constexpr int64_t LT_B0 = LT_W0 + (int64_t)HID * D;
+constexpr int64_t LT_W3 = LT_B0 + HID;
+constexpr int64_t LT_B3 = LT_W3 + (int64_t)HID * HID;
+constexpr int64_t LT_W6 = LT_B3 + HID;
+constexpr int64_t LT_B6 = LT_W6 + (int64_t)64 * HID;
+constexpr int64_t LT_FLOATS = LT_B6 + 64;
+
 }  // namespace kmmf

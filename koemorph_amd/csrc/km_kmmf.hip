@@ -819,6 +819,149 @@ __global__ __launch_bounds__(512) void kmmf_decode_kernel(DecArgs a) {
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// legacy_encoder_kernel: SimplifiedKoeMorphModel's audio_encoder (Linear(80, 256) ReLU Linear(256, 256) ReLU,
+// simplified_model.py:44-51) and the key / value projections of its attention (:136-141) for 32 token rows per 256-thread
+// workgroup: the two hidden activations never leave LDS, the four weights are MFMA operands straight from L2 (blob lgf_enc).
+// Replaces four NT GEMM launches over (B Tm, 256) activations.  K, V (rows, 256) row-major for legacy_attention_kernel.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void legacy_encoder_kernel(const float* __restrict__ mel, const float* __restrict__ blob, int64_t rows,
+                                                            float* __restrict__ Kp, float* __restrict__ Vp) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* A = smem;
+    float* Bi = smem + EIMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int64_t r0 = (int64_t)blockIdx.x * EROWS;
+    const int col0 = 64 * wave;
+    for (int i = tid; i < EROWS * (LG_MEL / 4); i += ENTH) {
+        const int r = i / (LG_MEL / 4), c4 = i - r * (LG_MEL / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + r < rows) v = *reinterpret_cast<const float4*>(mel + (r0 + r) * LG_MEL + 4 * c4);
+        *reinterpret_cast<float4*>(A + r * XS + 4 * c4) = v;
+    }
+    __syncthreads();
+    auto layer = [&](const float* src, float* dst, int64_t w_off, int64_t b_off, int kbs) {     // dst = relu(src W^T + b)
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0, 0, 0, 0};
+        mm_cols<2, 4, KM_KMMF_ENC_PIN>(acc, src, blob + w_off, 4 * wave, kbs, 0, kbs, lane);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const float bb = blob[b_off + col0 + 16 * nt + j];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[mt][nt][r] + bb;
+                    dst[(16 * mt + 4 * g + r) * XS + col0 + 16 * nt + j] = v < 0.f ? 0.f : v;
+                }
+        }
+    };
+    layer(A, Bi, LG_W0, LG_B0, LG_MEL / 16);
+    __syncthreads();
+    layer(Bi, A, LG_W3, LG_B3, KBD);
+    __syncthreads();
+    auto project = [&](int64_t w_off, int64_t b_off, float* out) {                                // out rows = A W^T + b
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0, 0, 0, 0};
+        mm_cols<2, 4, KM_KMMF_ENC_PIN>(acc, A, blob + w_off, 4 * wave, KBD, 0, KBD, lane);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const float bb = blob[b_off + col0 + 16 * nt + j];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = r0 + 16 * mt + 4 * g + r;
+                    if (row < rows) out[row * D + col0 + 16 * nt + j] = acc[mt][nt][r] + bb;
+                }
+        }
+    };
+    project(LG_WK, LG_BK, Kp);
+    project(LG_WV, LG_BV, Vp);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// legacy_tail_kernel: SimplifiedKoeMorphModel after its attention, one 512-thread workgroup per window: out_proj, the decoder
+// (Linear ReLU Linear ReLU Linear Sigmoid, simplified_model.py:63-72) on the 52 query rows resident in LDS and the mean over those
+// rows (:144-147).  Replaces four NT GEMM launches + a row kernel.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void legacy_tail_kernel(const float* __restrict__ O, const float* __restrict__ blob, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* A = smem;                 // [64][264] images; rows 52 .. 63 hold whatever the stores below leave (rows are independent)
+    float* Bi = smem + 64 * XS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int64_t b = blockIdx.x;
+    for (int i = tid; i < 64 * 64; i += NTH) {
+        const int q = i >> 6, c4 = i & 63;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < NQ) v = *reinterpret_cast<const float4*>(O + (b * NQ + q) * D + 4 * c4);
+        *reinterpret_cast<float4*>(A + q * XS + 4 * c4) = v;
+    }
+    __syncthreads();
+    {   // A1 = O Wo^T + bo: wave = 32 columns
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = f32x4{0, 0, 0, 0}; acc[mt][1] = f32x4{0, 0, 0, 0}; }
+        mm_cols<4, 2, KM_KMMF_DEC_PIN>(acc, A, blob + LT_WO, 2 * wave, KBD, 0, KBD, lane);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float bb = blob[LT_BO + 32 * wave + 16 * nt + j];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Bi[(16 * mt + 4 * g + r) * XS + 32 * wave + 16 * nt + j] = acc[mt][nt][r] + bb;
+        }
+    }
+    __syncthreads();
+    auto hidden = [&](const float* src, float* dst, int64_t w_off, int64_t b_off, int kbs) {     // dst = relu(src W^T + b), 128 wide: wave = 16 columns
+        f32x4 acc[4][1];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][0] = f32x4{0, 0, 0, 0};
+        mm_cols<4, 1, KM_KMMF_DEC_PIN>(acc, src, blob + w_off, wave, kbs, 0, kbs, lane);
+        const float bb = blob[b_off + 16 * wave + j];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[mt][0][r] + bb;
+                dst[(16 * mt + 4 * g + r) * XS + 16 * wave + j] = v < 0.f ? 0.f : v;
+            }
+    };
+    hidden(Bi, A, LT_W0, LT_B0, KBD);
+    __syncthreads();
+    hidden(A, Bi, LT_W3, LT_B3, HID / 16);
+    __syncthreads();
+    if (wave < 4) {      // the 52 outputs (padded to 64 columns): waves 0 - 3 own 16 columns each; mean of sigmoid over the 52 query rows
+        f32x4 acc[4][1];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][0] = f32x4{0, 0, 0, 0};
+        mm_cols<4, 1, KM_KMMF_DEC_PIN>(acc, Bi, blob + LT_W6, wave, HID / 16, 0, HID / 16, lane);
+        const int col = 16 * wave + j;
+        const float bb = blob[LT_B6 + col];
+        float s = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = acc[mt][0][r] + bb;
+                if (16 * mt + 4 * g + r < NQ) s += 1.0f / (1.0f + expf(-z));
+            }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (g == 0 && col < NQ) out[b * NQ + col] = s / (float)NQ;
+    }
+}
+
 }  // namespace kf
 
 static const float* dvp(Context* c, const char* name) { return c->packed.at(name).dev; }
@@ -871,6 +1014,31 @@ int launch_kmmf_decode(Context* c, const float* xm, const float* xe, int64_t B, 
     a.kvalid = kvalid; a.causal = k.causal; a.window = k.window_size; a.attn = attn; a.B = (int)B; a.T = (int)T;
     a.tail = tail;
     hipLaunchKernelGGL(kf::kmmf_decode_kernel, dim3((unsigned)B), dim3(kf::NTH), kf::DEC_LDS_FLOATS * 4, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+
+// SimplifiedKoeMorphModel: K, V (rows, 256) of the attention from the mel rows (rows, 80), one launch
+int launch_legacy_encoder_fused(Context* c, const float* mel, int64_t rows, float* Kp, float* Vp, void* stream) {
+    static PerDeviceOnce once;
+    if (once.first(c->device))
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kf::legacy_encoder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * kf::EIMG * 4));
+    hipLaunchKernelGGL(kf::legacy_encoder_kernel, dim3((unsigned)((rows + kf::EROWS - 1) / kf::EROWS)), dim3(kf::ENTH), 2 * kf::EIMG * 4,
+                       (hipStream_t)stream, mel, dvp(c, "lgf_enc"), rows, Kp, Vp);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+
+// SimplifiedKoeMorphModel: attention output O (B, 52, 256) -> out (B, 52), one launch
+int launch_legacy_tail_fused(Context* c, const float* O, int64_t B, float* out, void* stream) {
+    static PerDeviceOnce once;
+    if (once.first(c->device))
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kf::legacy_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * 64 * kf::XS * 4));
+    hipLaunchKernelGGL(kf::legacy_tail_kernel, dim3((unsigned)B), dim3(kf::NTH), 2 * 64 * kf::XS * 4, (hipStream_t)stream, O, dvp(c, "lgf_tail"), out);
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }

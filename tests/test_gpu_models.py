@@ -282,9 +282,13 @@ def test_legacy_simplified_koemorph_model():
     for T in (257, 256, 250, 16, 5):
         melT = synth.uniform(10 + T, (5, T, 80), 0, 1)
         res = {}
-        for mode in (0, 1):
-            _lib.check(lib.km_set_option(h, b"legacy_no_attn_fusion", mode))
+        for mode in (0, 1, 2, 4, 7):   # bit 0: attention as batched products, 1: encoder + K / V projections, 2: out_proj + decoder as GEMM launches
+            _lib.check(lib.km_set_option(h, b"legacy_no_attn_fusion", mode & 1))
+            _lib.check(lib.km_set_option(h, b"legacy_no_enc_fusion", (mode >> 1) & 1))
+            _lib.check(lib.km_set_option(h, b"legacy_no_tail_fusion", mode >> 2))
             res[mode] = m.forward_mel(dev(melT)).cpu().numpy()
-        _lib.check(lib.km_set_option(h, b"legacy_no_attn_fusion", 0))
+        for name in (b"legacy_no_attn_fusion", b"legacy_no_enc_fusion", b"legacy_no_tail_fusion"):
+            _lib.check(lib.km_set_option(h, name, 0))
         want = legacy.legacy_forward_mel(params, melT)
-        assert np.abs(res[0] - want).max() < 5e-6 and np.abs(res[1] - want).max() < 5e-6, T
+        for mode in res:
+            assert np.abs(res[mode] - want).max() < 5e-6, (T, mode)
