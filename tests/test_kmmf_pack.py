@@ -108,3 +108,51 @@ def test_blobs_hold_every_weight_in_fragment_order():
         assert np.abs(acc - want).max() < 1e-9
     finally:
         lib.km_destroy(h)
+
+
+def test_legacy_blobs_hold_the_weights_in_fragment_order():
+    """SimplifiedKoeMorphModel's fused kernels read lgf_enc (audio encoder + key / value projections) and lgf_tail (out_proj +
+    decoder, the 52-row output weight padded to 64 rows)."""
+    from koemorph_amd.model import SimplifiedKoeMorphModel
+    from oracle import legacy
+    import torch
+    params = legacy.make_legacy_params(3)
+    m = SimplifiedKoeMorphModel()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    lib = _lib.load()
+    h = C.c_void_p()
+    from koemorph_amd._lib import KMLegacyConfig
+    from koemorph_amd.engine import MelConfig
+    mel = MelConfig.model_batch(m.sample_rate, m.target_fps, m.n_fft)
+    mel.hop_length = m.hop_length
+    cfg = KMLegacyConfig(_lib.KM_ABI_VERSION, m.d_model, m.num_heads, m.decoder_hidden, m.num_blendshapes, mel.to_c())
+    check(lib.km_legacy_create(C.byref(cfg), C.byref(h)))
+    try:
+        for k, v in m.state_dict().items():               # what SimplifiedKoeMorphModel._handle loads
+            a = np.ascontiguousarray(v.detach().cpu().numpy(), dtype=np.float32)
+            shape = (C.c_int64 * max(1, a.ndim))(*a.shape)
+            check(lib.km_load_param(h, k.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+        check(lib.km_finalize_host(h))
+
+        def buf(name):
+            n = C.c_int64(0)
+            check(lib.km_debug_buffer(h, name.encode(), None, C.byref(n)))
+            out = np.empty(n.value, dtype=np.float32)
+            check(lib.km_debug_buffer(h, name.encode(), out.ctypes.data_as(C.c_void_p), C.byref(n)))
+            return out
+        enc, tail = buf("lgf_enc"), buf("lgf_tail")
+        o = 0
+        assert np.array_equal(unpack(enc[o:o + D * 80], D, 80), params["audio_encoder.0.weight"]); o += D * 80
+        assert np.array_equal(enc[o:o + D], params["audio_encoder.0.bias"]); o += D
+        assert np.array_equal(unpack(enc[o:o + D * D], D, D), params["audio_encoder.3.weight"]); o += D * D + D
+        inw = params["attention.in_proj_weight"]
+        assert np.array_equal(unpack(enc[o:o + D * D], D, D), inw[D:2 * D]); o += D * D
+        assert np.array_equal(enc[o:o + D], params["attention.in_proj_bias"][D:2 * D]); o += D
+        assert np.array_equal(unpack(enc[o:o + D * D], D, D), inw[2 * D:]); o += D * D + D
+        assert o == enc.size
+        o = D * D + D + HID * D + HID + HID * HID + HID
+        w6 = unpack(tail[o:o + 64 * HID], 64, HID)
+        assert np.array_equal(w6[:52], params["decoder.6.weight"]) and not w6[52:].any()
+        assert np.array_equal(tail[o + 64 * HID:o + 64 * HID + 52], params["decoder.6.bias"]) and tail.size == o + 64 * HID + 64
+    finally:
+        lib.km_destroy(h)
