@@ -29,4 +29,23 @@ for _ in range(100):
     tr.forward_backward(audio[:8], emo[:8], tgt)
     bad_t += int(not torch.equal(tr.flat_grad, g0) or float(tr.loss.item()) != l0)
 print(f"train forward_backward (two streams): 100 repetitions, {bad_t} differ")
-sys.exit(1 if bad or bad_s or bad_t else 0)
+core_bad = bad or bad_s or bad_t
+
+# the fused legacy models: determinism of the multi-wave reductions (LayerNorm partials, online softmax)
+import numpy as np
+from koemorph_amd.model import KoeMorphModel, SimplifiedKoeMorphModel
+cfg = synth.KoeMorphConfig()
+m = KoeMorphModel(d_query=cfg.d_model)
+sd = m.state_dict(); sd.update({k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_koemorph_params(5, cfg).items()}); m.load_state_dict(sd)
+m = m.cuda().eval()
+mel = torch.from_numpy(synth.normal(1, (64, 30, 80))).cuda(); emf = torch.from_numpy(synth.normal(2, (64, 30, 256))).cuda()
+with torch.no_grad():
+    m.reset_temporal_state(); k0 = m(mel, emf, apply_smoothing=False)["blendshapes"].clone()
+    bad_k = sum(int(not torch.equal(m(mel, emf, apply_smoothing=False)["blendshapes"], k0)) for _ in range(100))
+print(f"KoeMorphModel (fused kernels): 100 repetitions, {bad_k} differ")
+lg = SimplifiedKoeMorphModel().cuda().eval()
+with torch.no_grad():
+    a0 = lg(audio[:32]).clone()
+    bad_l = sum(int(not torch.equal(lg(audio[:32]), a0)) for _ in range(100))
+print(f"SimplifiedKoeMorphModel (fused kernels): 100 repetitions, {bad_l} differ")
+sys.exit(1 if (core_bad or bad_k or bad_l) else 0)
