@@ -238,6 +238,19 @@ def timed(rk: Ranks, step, steps: int, warmup: int, flush=None, spin: bool = Tru
     return _timed_once(rk, step, steps, warmup, flush)
 
 
+INFINITY_CACHE_BYTES = 256 << 20      # /opt/skills/guides/MI355X_MICROARCH.md: a working set below this is served on-die from the 2nd pass on
+
+
+def rotating_inputs(torch, audio, min_buffers: int = 3):
+    """K >= 3 DISTINCT device copies of the step's audio batch whose total size exceeds the 256 MiB Infinity Cache, used
+    round-robin: every timed step then streams its samples from HBM, as a fresh batch of audio would (the reference feeds
+    fresh audio every call, src/model/simplified_dual_stream_model.py:184-229).  Copy k is the batch with its windows
+    rotated by k (same values, other addresses)."""
+    per = audio.numel() * audio.element_size()
+    k = max(min_buffers, -(-int(1.6 * INFINITY_CACHE_BYTES) // per))
+    return [audio] + [torch.roll(audio, shifts=i, dims=0).contiguous() for i in range(1, k)], k * per
+
+
 GRAD_BUCKET_FLOATS = 837744        # flat gradient bucket of the d_model 256 / window 256 model (km_train_num_params)
 
 
@@ -273,20 +286,47 @@ def measure_collective(args, rk: Ranks, steps: int = 50):
         for mode in ("ring", "direct"):
             os.environ["KM_ALLREDUCE"] = mode
             res = {}
+            # Probe: can this backend run the mode at all?  A mode the backend lacks (gloo has no all-to-all on some builds)
+            # raises on EVERY rank alike, before any rank has entered a collective, so the ranks can compare notes with one
+            # all-reduce (MAX) of the failure flag and skip the mode together.
+            probe_err = None
             try:
-              if tr is not None:
+                small = torch.full((max(rk.world, 1) * 4,), float(rk.rank + 1), device=bucket.device)
+                parallel.allreduce_gradients(small, average=False)
+            except Exception as exc:
+                probe_err = f"{type(exc).__name__}: {exc}"[:300]
+            if rk.dist is not None:
+                flag = torch.tensor([0.0 if probe_err is None else 1.0], device=rk.coll_device())
+                rk.dist.all_reduce(flag, op=rk.dist.ReduceOp.MAX)
+                if float(flag.item()) > 0 and probe_err is None:
+                    probe_err = "another rank cannot run this mode"
+            if probe_err is not None:
+                out[mode] = {"error": probe_err}
+                continue
+            # Past the probe every exception is FATAL: a failure on one rank only (a local out-of-memory, a HIP error in its
+            # step) would leave the others inside a barrier or an all-reduce this rank never joins -- the rank exits non-zero
+            # and the launcher (launch_ranks / torchrun) tears the job down instead of waiting for the driver's timeout.
+            if tr is not None:
                 dt = timed(rk, lambda: tr.step(audio, emo, target), steps, 5, spin=False)
-                res["ms_per_step"] = round(dt / steps * 1e3, 4)
-              bucket.fill_(float(rk.rank + 1))
-              parallel.allreduce_gradients(bucket, average=False)
-              res["sum_check"] = bool(abs(float(bucket[0]) - rk.world * (rk.world + 1) / 2) < 1e-3 and
-                                      abs(float(bucket[-1]) - rk.world * (rk.world + 1) / 2) < 1e-3)
-              dt = timed(rk, lambda: parallel.allreduce_gradients(bucket, average=False), steps, 5, spin=False)
-              res["allreduce_ms"] = round(dt / steps * 1e3, 4)
-              if mode == "direct" and rk.world <= 2:
-                  res["note"] = "world <= 2: the direct form is the library all-reduce"
-            except Exception as exc:          # a mode the backend cannot run must not cost the whole line (every rank raises alike)
-                res["error"] = f"{type(exc).__name__}: {exc}"[:300]
+                res["ms_per_step"] = round(dt / steps * 1e3, 4)            # two pieces: 83 % overlapped with the end of backward
+                keep_p = os.environ.get("KM_ALLREDUCE_PIECES")
+                os.environ["KM_ALLREDUCE_PIECES"] = "1"
+                try:
+                    dt = timed(rk, lambda: tr.step(audio, emo, target), steps, 5, spin=False)
+                finally:
+                    if keep_p is None:
+                        os.environ.pop("KM_ALLREDUCE_PIECES", None)
+                    else:
+                        os.environ["KM_ALLREDUCE_PIECES"] = keep_p
+                res["ms_per_step_one_piece"] = round(dt / steps * 1e3, 4)  # the whole bucket as ONE collective behind the step
+            bucket.fill_(float(rk.rank + 1))
+            parallel.allreduce_gradients(bucket, average=False)
+            res["sum_check"] = bool(abs(float(bucket[0]) - rk.world * (rk.world + 1) / 2) < 1e-3 and
+                                    abs(float(bucket[-1]) - rk.world * (rk.world + 1) / 2) < 1e-3)
+            dt = timed(rk, lambda: parallel.allreduce_gradients(bucket, average=False), steps, 5, spin=False)
+            res["allreduce_ms"] = round(dt / steps * 1e3, 4)
+            if mode == "direct" and rk.world <= 2:
+                res["note"] = "world <= 2: the direct form is the library all-reduce"
             out[mode] = res
     finally:
         if keep is None:
@@ -326,13 +366,24 @@ def run_c2(args, rk: Ranks):
     state = torch.zeros(B, 52, device=rk.dev)
     out = torch.empty(B, 52, device=rk.dev)
 
+    # `value` is measured on ROTATING inputs: K distinct audio batches (> 256 MiB together) taken round-robin, so the samples
+    # of a step come from HBM, not from the Infinity Cache a single replayed 139.7 MB batch would sit in
+    bufs, rot_bytes = rotating_inputs(torch, audio)
+    it = [0]
+
     def step(first=False):
-        eng.forward_audio(audio, emo, state=state, first=first, out=out)
+        a = bufs[it[0] % len(bufs)]
+        it[0] += 1
+        eng.forward_audio(a, emo, state=state, first=first, out=out)
+
+    def step_cached():
+        eng.forward_audio(audio, emo, state=state, first=False, out=out)
 
     step(first=True)
     dt = timed(rk, step, args.steps, args.warmup)
     ms_per_step = dt / args.steps * 1e3
     value = B * rk.world * args.steps / dt
+    ms_cached = _timed_once(rk, step_cached, args.steps, args.warmup) / args.steps * 1e3      # ONE batch replayed (rounds 1-3)
 
     # ---- per-kernel timing, live: HIP events recorded by the library on the launch stream(s) around the kernels of
     # the same step that was timed above.  Under the overlapped schedule the two kernels share the chip, so their
@@ -422,9 +473,14 @@ def run_c2(args, rk: Ranks):
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "rtf_30fps": round(30.0 / (value / rk.world), 8), "rccl_ranks": rk.rccl_ranks,
+        # K distinct audio batches used round-robin (together past the 256 MiB Infinity Cache): `value` / `ms_per_step` /
+        # kernel_ms / roofline are measured on them; ms_per_step_cached_input = the same step replaying ONE batch (what
+        # rounds 1-3 reported: its 139.7 MB stay on-die)
+        "input_rotation": {"buffers": len(bufs), "bytes_total": rot_bytes, "infinity_cache_bytes": INFINITY_CACHE_BYTES},
+        "ms_per_step_cached_input": round(ms_cached, 4),
         "config": {"workload": "C2: 256 windows/GPU x 136448 samples (8.5 s @16 kHz) -> 1024-pt STFT, hop 533, "
                                "80-bin log-mel (257 frames) -> dual-stream attention d_model=256, 8 heads, "
-                               "window 256 -> 52 coefficients + EMA; from audio resident in HBM",
+                               "window 256 -> 52 coefficients + EMA; from audio resident in HBM (rotating batches)",
                    "windows_per_gpu": B, "samples_per_window": L, "parallelism": f"window-sharded x{rk.world}, no collective",
                    },
         "roofline": roofline, "roofline_other_kernel": other, "step_roofline": step_roof, "kernel_ms": stage_ms,
@@ -767,7 +823,16 @@ def run_c4(args, rk: Ranks):
     audio = torch.from_numpy(audio_np).to(rk.dev)
     emo = torch.from_numpy(emo_np).to(rk.dev)
     out = torch.empty(B, 52, device=rk.dev)
-    dt = timed(rk, lambda: eng.forward_audio(audio, emo, out=out), args.steps, args.warmup)
+    bufs, rot_bytes = rotating_inputs(torch, audio)      # see run_c2: the samples of a timed step come from HBM
+    it = [0]
+
+    def step():
+        a = bufs[it[0] % len(bufs)]
+        it[0] += 1
+        eng.forward_audio(a, emo, out=out)
+
+    dt = timed(rk, step, args.steps, args.warmup)
+    ms_cached = _timed_once(rk, lambda: eng.forward_audio(audio, emo, out=out), args.steps, args.warmup) / args.steps * 1e3
     cpu = None
     if rk.rank == 0 and rk.world == 1 and args.cpu_seconds > 0:
         import numpy as np
@@ -783,15 +848,17 @@ def run_c4(args, rk: Ranks):
         "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rtf_60fps": round(60.0 / (value / rk.world), 8),
         "rccl_ranks": rk.rccl_ranks,
+        "input_rotation": {"buffers": len(bufs), "bytes_total": rot_bytes, "infinity_cache_bytes": INFINITY_CACHE_BYTES},
+        "ms_per_step_cached_input": round(ms_cached, 4),
         "config": {"workload": f"C4: {B} windows/GPU x {L} samples, hop 266, 513 frames -> dual-stream attention d_model=512, "
-                               f"{H} heads, window 512 -> 52 coefficients; from audio resident in HBM", "windows_per_gpu": B,
+                               f"{H} heads, window 512 -> 52 coefficients; from audio resident in HBM (rotating batches)", "windows_per_gpu": B,
                    "parallelism": f"window-sharded x{rk.world}, no collective"},
         "roofline": {"kernel": "whole step (front end + encoder_ln + scores_softmax + attn_out)", "bound": "mfma",
                      "achieved": round(exe, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(exe / PEAK_F32_MFMA_TFLOPS, 4), "algorithmic_frac": round(alg / PEAK_F32_MFMA_TFLOPS, 4),
                      "traffic": None, "executed_flops_per_window": executed_flops_per_frame_c4(H),
                      "note": "MFMA FLOPs the three core kernels issue (bench.py header) over the WHOLE step incl. the VALU front end; "
-                             "per kernel: profiles/r02_c4_kernel_stats.txt, r02_c4_harness.txt"},
+                             "per kernel: profiles/r04_c4_kernel_stats.txt (r03_/r02_ for earlier rounds), r02_c4_harness.txt"},
         "cpu_baseline": cpu,
     }
 

@@ -31,7 +31,9 @@
 extern "C" {
 #endif
 
-#define KM_ABI_VERSION 1
+/* 2: km_koemorph_config grew (output_activation, smoothing_method, smoothing_window); km_loss_config grew (ds_*) and now
+ * starts with its own abi_version -- a caller built against the version-1 header is refused instead of being read past. */
+#define KM_ABI_VERSION 2
 
 typedef enum km_status {
     KM_OK = 0,
@@ -254,6 +256,7 @@ int km_train_set_optimizer_state(km_handle h, const float* exp_avg_host, const f
  * is NULL, landmark when landmark_w_dev is NULL -- as the reference skips them.  Pointers must stay valid for every
  * later km_train_step* call (they are read on the step's stream).  cfg = NULL switches the extra terms off. */
 typedef struct km_loss_config {
+    int32_t abi_version;             /* KM_ABI_VERSION: km_train_set_loss refuses anything else (the struct has grown) */
     float perceptual_weight, temporal_weight, sparsity_weight, smoothness_weight, landmark_weight, velocity_weight;
     const float* prev_pred_dev;
     const float* prev_target_dev;
@@ -295,7 +298,7 @@ int km_train_set_dropout_step(km_handle h, int64_t step);
 
 /* Overlapping the data-parallel gradient all-reduce with the end of the backward pass (new construction: the reference is
  * single-process).  The flat bucket is laid out so that the tensors the backward pass finishes last come last:
- *   km_train_grad_split   *early_floats = E: floats [0, E) of flat_grad (83 % at d_model 256) are final after phase 10 of
+ *   km_train_grad_split   *early_floats = E: floats [0, E) of flat_grad (83 % at d_model 256) are final after phase 11 of
  *                         14 of km_train_step*, the rest when the call's work completes
  *   km_train_wait_early   make `stream` wait (hipStreamWaitEvent) for that point of the most recent km_train_step*: a
  *                         side stream can then all-reduce flat_grad[0:E] while the launch stream still computes the tail */

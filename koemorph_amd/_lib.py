@@ -10,7 +10,7 @@ from typing import Optional
 
 from . import build as _build
 
-KM_ABI_VERSION = 1
+KM_ABI_VERSION = 2
 
 
 class KoeMorphError(RuntimeError):
@@ -48,7 +48,7 @@ class KMKoeMorphConfig(C.Structure):
 
 
 class KMLossConfig(C.Structure):
-    _fields_ = [("perceptual_weight", C.c_float), ("temporal_weight", C.c_float), ("sparsity_weight", C.c_float),
+    _fields_ = [("abi_version", C.c_int32), ("perceptual_weight", C.c_float), ("temporal_weight", C.c_float), ("sparsity_weight", C.c_float),
                 ("smoothness_weight", C.c_float), ("landmark_weight", C.c_float), ("velocity_weight", C.c_float),
                 ("prev_pred_dev", C.c_void_p), ("prev_target_dev", C.c_void_p), ("landmark_w_dev", C.c_void_p),
                 ("audio_energy_dev", C.c_void_p), ("ds_velocity_weight", C.c_float), ("ds_separation_weight", C.c_float),
@@ -155,13 +155,15 @@ def load(build_if_missing: bool = True) -> C.CDLL:
         try:
             _build.build_library()
         except Exception as exc:
-            # A stale library that cannot be rebuilt (a GPU box without write access, say) is still loaded, but never
-            # silently: the ABI check below catches a changed interface, this warning covers changed kernels.
-            if not os.path.exists(path) or os.environ.get("KM_STRICT_BUILD"):
-                raise
+            # A library OLDER than its sources that cannot be rebuilt (a GPU box without hipcc or write access) is refused:
+            # loading it would benchmark or test old kernels under new sources without anyone noticing.  KM_ALLOW_STALE=1
+            # loads it anyway, with a warning; the ABI check below still catches a changed interface.
+            if not os.path.exists(path) or os.environ.get("KM_ALLOW_STALE") != "1":
+                raise KoeMorphError(KM_ERR_HIP, f"libkoemorph_hip.so is missing or older than its sources and the rebuild "
+                                                f"failed ({exc}); set KM_ALLOW_STALE=1 to load the stale library") from exc
             import warnings
             warnings.warn(f"libkoemorph_hip.so is OLDER than its sources and the rebuild failed ({exc}); "
-                          "loading the stale library", RuntimeWarning, stacklevel=2)
+                          "loading the stale library (KM_ALLOW_STALE=1)", RuntimeWarning, stacklevel=2)
     if not os.path.exists(path):
         raise KoeMorphError(KM_ERR_HIP, f"{path} is missing: run `python -m koemorph_amd.build` "
                                         "(there is no CPU fallback)")

@@ -446,6 +446,10 @@ int km_audio_energy(const float* features_dev, int64_t B, int64_t T, int64_t D, 
 int km_train_set_loss(km_handle h, const km_loss_config* cfg) {
     if (int rc = need_train(h, 1)) return rc;
     Context* c = h;
+    // the struct has grown since ABI version 1 and holds device pointers the loss tail dereferences: a caller built against
+    // an older header must be refused, not read past
+    if (cfg && cfg->abi_version != KM_ABI_VERSION)
+        return fail(KM_ERR_INVALID_ARG, "km_loss_config.abi_version %d != %d", cfg->abi_version, KM_ABI_VERSION);
     if (cfg) c->tr_loss_cfg = *cfg; else c->tr_loss_cfg = km_loss_config{};
     return KM_OK;
 }

@@ -33,7 +33,10 @@ __device__ __forceinline__ void kmm_tail_dev(const KmmTail& a, int64_t b, int q,
             a.state[b * NB + q] = y;
         } else if (a.smooth > 0) {                                             // decoder.py:294-340: history ring, one slot per call
             float* ring = a.state + b * ((int64_t)a.window * NB + 1);
-            const int ptr = (int)ring[(int64_t)a.window * NB];                  // every thread reads it before thread 0 moves it
+            // the slot pointer lives in the CALLER's float state: anything but 0 .. window - 1 (a state that was not zeroed,
+            // a NaN) restarts at slot 0 instead of indexing the ring with it
+            const float pf = ring[(int64_t)a.window * NB];                      // every thread reads it before thread 0 moves it
+            const int ptr = (pf >= 0.f && pf < (float)a.window) ? (int)pf : 0;
             float v[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) v[k] = k < a.window ? (k == ptr ? y : ring[k * NB + q]) : 0.f;
@@ -67,7 +70,8 @@ __device__ __forceinline__ void kmm_tail_dev(const KmmTail& a, int64_t b, int q,
     __syncthreads();
     if (a.smooth > 0 && q == 0) {       // after every thread of the element has read the pointer
         float* pp = a.state + b * ((int64_t)a.window * NB + 1) + (int64_t)a.window * NB;
-        const int ptr = (int)pp[0];
+        const float pf = pp[0];
+        const int ptr = (pf >= 0.f && pf < (float)a.window) ? (int)pf : 0;
         pp[0] = (float)((ptr + 1) % a.window);
     }
     if (q < NB) {

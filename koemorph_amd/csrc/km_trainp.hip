@@ -665,6 +665,11 @@ struct Program {
         for (const auto& r : pend_prev) conflict = conflict || r.out == g.C;
         for (const auto& r : pend_cur) conflict = conflict || r.out == g.C;
         if (conflict && !splittable) { rc = fail(KM_ERR_UNSUPPORTED, "training program: a product writes an output with a pending reduction"); return; }
+        // a conflicting product MUST go through a partial: written directly it would race with the reduction still to come
+        if (conflict && (int64_t)S * g.M * g.N + 4 > scratch_left) {
+            rc = fail(KM_ERR_WORKSPACE, "training program: no room for the partial of a product whose output has a pending reduction");
+            return;
+        }
         if ((S > 1 || conflict) && (int64_t)S * g.M * g.N + 4 <= scratch_left) {
             float* part = scratch;
             const int64_t n = (int64_t)g.M * g.N;
@@ -1094,10 +1099,16 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         e.p0 = dE; e.p1 = E0; e.p2 = P("emotion_norm.weight"); e.p3 = emu; e.p4 = ers; e.q0 = dE0; e.q1 = Te; e.n0 = B; e.i0 = (int)d;
         pg.elem(OP_LN_BWD, e, blocks4(B));
     }
+    // nothing of this phase may be deferred to a reduction in P12: the "early" event below declares its gradients final
+    // (with train_split_min_k < 256 or d_model > 1024 the K = d products here would otherwise split)
+    const bool allow_split_saved = pg.allow_split;
+    pg.allow_split = false;
     pg.gemm(NN(dQb, d, inw, d, Gd("mouth_queries"), d, 28, d, d), 1);
     pg.gemm(TN(dQb, d, P("mouth_queries"), d, gin_w, d, d, d, 28), 1);       // query rows of in_proj: dWq = dQ^T mq, dbq = column sums of dQ
     colsum(dQb, 28, d, d, gin_b, 0, ones);
+    pg.allow_split = allow_split_saved;
     RUN(pg.end_phase(st));
+    if (!pg.pend_prev.empty()) return fail(KM_ERR_UNSUPPORTED, "training program: a reduction is still pending behind phase 11 (internal)");
     // everything but the "late" group of the bucket (km_train_init) is final: a side stream may start its all-reduce
     HIP_TRY(hipEventRecord((hipEvent_t)c->tr_ev[0], st));
     c->tr_early_recorded = true;

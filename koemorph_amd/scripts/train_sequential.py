@@ -142,7 +142,16 @@ class SequentialTrainer:
         self.trainer.load_params(sd)
         self.epoch = int(ckpt["epoch"]); self.global_step = int(ckpt["global_step"])
         self.best_val_loss = float(ckpt.get("best_val_loss", float("inf")))
-        self.trainer.load_optimizer_state(ckpt["optimizer_state_dict"])
+        try:
+            self.trainer.load_optimizer_state(ckpt["optimizer_state_dict"])
+        except (ValueError, KeyError, TypeError, AttributeError) as exc:
+            # a checkpoint of the reference's own trainer (optimizer_state_dict = a torch.optim dict keyed by parameter index,
+            # src/train_sequential.py:303-339) or of a build that predates the per-key layout: the weights above are what
+            # matters, the moments restart -- the same thing torch users do with load_state_dict(strict=False) on a new optimizer
+            import warnings
+            warnings.warn(f"optimizer state of {path} not loaded ({exc}); resuming from the model weights with fresh AdamW moments",
+                          RuntimeWarning, stacklevel=2)
+            self.trainer.restart_optimizer(self.epoch)
         cf = int(ckpt.get("current_file_idx", -1))
         self.current_file_idx = None if cf < 0 else cf
 

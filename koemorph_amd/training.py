@@ -137,6 +137,18 @@ class Trainer:
         if "dropout_step" in st:
             check(self._lib.km_train_set_dropout_step(self._h, int(st["dropout_step"])))
 
+    def restart_optimizer(self, epoch: int = 0) -> None:
+        """Fresh AdamW moments and step counters with the schedule positioned at ``epoch``: what a resume falls back to when
+        the checkpoint's optimizer state cannot be assigned to tensors (a foreign ``torch.optim`` dict, a pre-per-key layout)."""
+        z = np.zeros(self.n_params, np.float32)
+        steps = np.zeros(2, np.int32)
+        check(self._lib.km_train_set_optimizer_state(self._h, z.ctypes.data, z.ctypes.data, self.n_params, steps.ctypes.data))
+        self.step_count = 0
+        self.epoch = int(epoch)
+        self.lr = cosine_warm_restarts_lr(self.epoch, self.base_lr)
+        self.ema_state.zero_()
+        self._ema_batch = None
+
     def reset_temporal_state(self):
         self._ema_batch = None
 
@@ -179,7 +191,7 @@ class Trainer:
         ``ds_*``: the velocity and stream-separation terms of ``DualStreamLoss`` (src/train_dual_stream.py:434-516; its
         L1 / L2 terms are ``l1_weight`` / ``mse_weight`` of the trainer: 1.0 / 0.1 there); ``ds_prev_pred`` (B,52) = the
         previous step's predictions (a constant)."""
-        from ._lib import KMLossConfig
+        from ._lib import KM_ABI_VERSION, KMLossConfig
         keep = []
         def dev(t, shape_tail):
             if t is None:
@@ -197,7 +209,7 @@ class Trainer:
             with torch.cuda.device(self.device):
                 check(self._lib.km_audio_energy(_ptr(af), af.shape[0], af.shape[1], af.shape[2], _ptr(energy), _stream_ptr(self.device)))
             keep.append(energy)
-        cfg = KMLossConfig(perceptual_weight, temporal_weight, sparsity_weight, smoothness_weight, landmark_weight,
+        cfg = KMLossConfig(KM_ABI_VERSION, perceptual_weight, temporal_weight, sparsity_weight, smoothness_weight, landmark_weight,
                            velocity_weight, dev(prev_pred, (52,)), dev(prev_target, (52,)), dev(landmark_weights, (136, 52)),
                            None if energy is None else _ptr(energy), ds_velocity_weight, ds_separation_weight,
                            dev(ds_prev_pred, (52,)))
@@ -237,14 +249,16 @@ class Trainer:
     def _allreduce_two_piece(self, weight: Optional[float], overlap: bool) -> None:
         """The step's one gradient exchange, issued as two pieces: floats [0, E) of the bucket (83 %: everything but the
         tensors the backward pass finishes last, km_train_grad_split) are reduced on a side stream that waits only for
-        phase 10 of the 14 (km_train_wait_early), i.e. while the launch stream still computes the LayerNorm / channel
+        phase 11 of the 14 (km_train_wait_early), i.e. while the launch stream still computes the LayerNorm / channel
         encoder gradients; the rest follows on the launch stream when the step is done.  Every rank issues the same two
         collectives whether or not it ran a step (a rank without windows contributes zeros): only the placement differs."""
         import ctypes
         early = ctypes.c_int64(0)
         check(self._lib.km_train_grad_split(self._h, ctypes.byref(early)))
         E = int(early.value)
-        if E <= 0 or E >= self.n_params:
+        # KM_ALLREDUCE_PIECES=1: the exchange as ONE collective behind the step (on a latency-bound 3.35 MB bucket the second
+        # piece's full latency sits on the critical path; bench.py --gpus N times both forms in its `collective` object)
+        if E <= 0 or E >= self.n_params or os.environ.get("KM_ALLREDUCE_PIECES", "2") == "1":
             parallel.allreduce_gradients(self.flat_grad, weight=weight)
             return
         if not overlap or os.environ.get("KM_ALLREDUCE_OVERLAP", "1") == "0":

@@ -153,6 +153,20 @@ def test_sequential_trainer_script_end_to_end(tmp_path):
     assert m3a["total"] == m3b["total"] and m3a["lr"] == m3b["lr"]
     for (k, a), (_, b) in zip(st.state_dict().items(), st2.state_dict().items()):
         assert torch.equal(a, b), k
+    # a checkpoint with a FOREIGN optimizer_state_dict (the reference's trainer stores torch.optim.AdamW's dict, keyed by
+    # parameter index; src/train_sequential.py:303-339) resumes from the weights with fresh moments instead of aborting
+    foreign = dict(ckpt)
+    foreign["optimizer_state_dict"] = {"state": {0: {"step": torch.tensor(3.0)}}, "param_groups": [{"lr": 1e-3, "params": [0]}]}
+    fpath = tmp_path / "ck" / "foreign.pth"
+    torch.save(foreign, fpath)
+    eng3 = Engine(); eng3.load_state_dict(synth.make_core_params(0)); eng3.finalize()
+    st3 = ts.SequentialTrainer(eng3, SequentialKoeMorphDataset(tmp_path, **kw), learning_rate=1e-3, l1_weight=0.1)
+    with pytest.warns(RuntimeWarning, match="fresh AdamW moments"):
+        st3.load_checkpoint(fpath)
+    assert st3.epoch == 2 and st3.trainer.step_count == 0 and st3.trainer.epoch == 2
+    for k, v in st3.state_dict().items():
+        assert torch.equal(v, ckpt["model_state_dict"][k]), k
+    assert np.isfinite(st3.train_epoch()["total"])
 
 
 @pytest.mark.parametrize("mode,kw", [("dense", {}), ("sparse", {"initial_stride": 16}), ("progressive", {"initial_stride": 12, "final_stride": 2, "epoch": 3, "max_epochs": 7}),
