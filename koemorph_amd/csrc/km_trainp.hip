@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstring>
 #include <vector>
 
@@ -40,6 +41,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     } while (0)
 
 #include "km_gemm_dev.h"
+#include "km_gemm_dma_dev.h"
 #include "km_train_tail.h"
 
 // ---- operations of a phase ------------------------------------------------------------------------------------
@@ -70,17 +72,20 @@ struct Op {
     int kind;
     int gx, gy;            // OP_GEMM: tiles along N and M (blocks = gx * gy * batch)
     int bm;                // OP_GEMM: tile rows (32 when the product would leave most of the chip idle with 64)
-    int va, vb;            // OP_GEMM: 16-byte loads are legal for operand A / B
+    short va, vb;          // OP_GEMM: 16-byte loads are legal for operand A / B
+    short dma;             // OP_GEMM: the product runs on the LDS-DMA tile (km_gemm_dma_dev.h)
+    signed char ma, mb;    //          its operand modes (0 k-contiguous, 1 row-contiguous)
     union {
         GemmArgs g;
         ElemArgs e;
     };
 };
 
-constexpr int kMaxOps = 17;     // 4 + 17 * 4 + 17 * sizeof(Op) stays under the 4 KB kernel-argument limit
+constexpr int kMaxOps = 17;     // 8 + 17 * 4 + 17 * sizeof(Op) stays under the 4 KB kernel-argument limit
 static_assert(sizeof(GemmArgs) <= 208, "Phase has to stay under the 4 KB kernel-argument limit");
 struct Phase {
     int n_ops;
+    int ns;                // ring stages of the LDS-DMA tiles of this phase: 8 when its workgroups are alone on their CUs, else 4
     int block_end[kMaxOps];
     Op ops[kMaxOps];
 };
@@ -396,10 +401,11 @@ __device__ __forceinline__ void attn_bwd_mfma_dev(const ElemArgs& a, int vb, flo
     __syncthreads();
 }
 
+// vb / tid: block and thread index of the operation's 256-thread block
 template <bool ATTN>
-__device__ __forceinline__ void op_elem(const Op& op, int vb, float* smem) {
+__device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* smem) {
     const ElemArgs& a = op.e;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63, wv = tid >> 6;
     switch (op.kind) {
     case OP_ZERO: {
         const int64_t i = ((int64_t)vb * 256 + tid) * 4;
@@ -574,23 +580,48 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, float* smem) {
 #define KM_TRAINP_D 2          /* k-tiles of operand loads in flight per thread (gemm_tile_dev) */
 #endif
 #ifndef KM_TRAINP_WAVES
-#define KM_TRAINP_WAVES 5      /* waves per SIMD the phases without attention blocks are compiled for */
+#define KM_TRAINP_WAVES 4      /* waves per SIMD the phases without attention blocks are compiled for */
 #endif
 #ifndef KM_TRAINP_WAVES_ATTN
 #define KM_TRAINP_WAVES_ATTN 4
 #endif
+// The 4 KB Phase is never touched as a by-value object: its words are read through the kernel-argument segment pointer
+// (constant address space, uniform offsets: scalar loads).
+// Indexing the by-value argument at run time works only as long as the compiler manages to lower it to such loads itself --
+// beyond some amount of inlined code (round 3: both attention block families; round 4: the LDS-DMA tiles) it copies the whole
+// argument into scratch memory instead, 4 KB per thread, and every phase runs several times slower.
+typedef const __attribute__((address_space(4))) unsigned* KernargWords;
+static_assert(sizeof(Op) % 4 == 0 && offsetof(Phase, ops) % 8 == 0, "operations are addressed in words, pointers inside stay 8-byte aligned");
+
 template <bool ATTN>
-__global__ __launch_bounds__(256, ATTN ? KM_TRAINP_WAVES_ATTN : KM_TRAINP_WAVES) void phase_kernel(Phase p) {
+__global__ __launch_bounds__(256, ATTN ? KM_TRAINP_WAVES_ATTN : KM_TRAINP_WAVES) void phase_kernel(Phase p_arg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // the host sizes it for the phase's largest operation
-    const int vb = blockIdx.x;
+    (void)p_arg;
+    KernargWords ka = (KernargWords)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int W_NOPS = offsetof(Phase, n_ops) / 4, W_NS = offsetof(Phase, ns) / 4, W_END = offsetof(Phase, block_end) / 4,
+                  W_OPS = offsetof(Phase, ops) / 4, W_OP = sizeof(Op) / 4;
+    const int vb = blockIdx.x, n_ops = (int)ka[W_NOPS], p_ns = (int)ka[W_NS];
     int i = 0;
-    while (i + 1 < p.n_ops && vb >= p.block_end[i]) ++i;            // workgroup-uniform
-    const int local = vb - (i ? p.block_end[i - 1] : 0);
-    const Op& op = p.ops[i];
+    while (i + 1 < n_ops && vb >= (int)ka[W_END + i]) ++i;            // workgroup-uniform
+    const int local = vb - (i ? (int)ka[W_END + i - 1] : 0);
+    // a generic pointer derived from the kernel-argument segment pointer: the address-space inference pass turns every access
+    // through it back into a constant-address-space (scalar) load, and there is no local object the compiler could spill
+    const Op& op = *(const Op*)(ka + W_OPS + i * W_OP);
     if (op.kind == OP_GEMM) {
         const int per = op.gx * op.gy;
         const int bz = local / per, t = local - bz * per;
         const int tx = t % op.gx, ty = t / op.gx;
+        if (op.dma) {
+            if (op.bm == 32) {
+                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<32, 0, 0>(op.g, tx, ty, bz, smem, p_ns);
+                else if (op.ma == 0) gemm_tile_dma_dev<32, 0, 1>(op.g, tx, ty, bz, smem, p_ns);
+                else gemm_tile_dma_dev<32, 1, 1>(op.g, tx, ty, bz, smem, p_ns);
+            } else {
+                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<64, 0, 0>(op.g, tx, ty, bz, smem, p_ns);
+                else if (op.ma == 0) gemm_tile_dma_dev<64, 0, 1>(op.g, tx, ty, bz, smem, p_ns);
+                else gemm_tile_dma_dev<64, 1, 1>(op.g, tx, ty, bz, smem, p_ns);
+            }
+        } else
         // operand B of the channel encoder (rows of 259 floats) is the one product without 16-byte rows
         if (op.bm == 32) {
             if (op.va && op.vb) gemm_tile_dev<32, KM_TRAINP_D, true, true>(op.g, tx, ty, bz, smem);
@@ -602,7 +633,7 @@ __global__ __launch_bounds__(256, ATTN ? KM_TRAINP_WAVES_ATTN : KM_TRAINP_WAVES)
             else gemm_tile_dev<64, KM_TRAINP_D, false, false>(op.g, tx, ty, bz, smem);
         }
     } else {
-        op_elem<ATTN>(op, local, smem);
+        op_elem<ATTN>(op, local, (int)threadIdx.x, smem);
     }
 }
 
@@ -620,7 +651,12 @@ struct PendingReduce { const float* part; float* out; int n, S, acc; };
 
 struct Program {
     Phase cur{};
+    int nb[kMaxOps] = {};                // blocks of each operation in units of 256-thread blocks (products: per output batch entry)
+    int gbatch[kMaxOps] = {};            // products: output batch entries
     int blocks = 0;
+    int launches = 0;
+    bool use_dma = true, any_dma = false, dma_bm64 = false;      // LDS-DMA tiles (option train_no_dma switches them off)
+    int alone_max = 256;                 // a phase of at most this many workgroups has its CUs to itself: 8 ring stages
     int rc = KM_OK;
     size_t lds = 0;
     bool has_attn = false;        // the phase holds an attention block: phase_kernel<true>
@@ -644,13 +680,16 @@ struct Program {
         if (nblocks <= 0) return;
         if (cur.n_ops >= kMaxOps) { rc = fail(KM_ERR_UNSUPPORTED, "training program: more than %d operations in one phase", kMaxOps); return; }
         cur.ops[cur.n_ops] = op;
+        nb[cur.n_ops] = nblocks; gbatch[cur.n_ops] = 1;
         blocks += nblocks;
         cur.block_end[cur.n_ops] = blocks;
         ++cur.n_ops;
         if (op_per_launch) {      // timing aid (option train_op_per_launch): every operation is its own launch, in program order
+            cur.ns = blocks <= alone_max ? 8 : 4;
+            if (op.kind == OP_GEMM && op.dma) need_lds((size_t)gdma::lds_floats(op.bm, cur.ns) * sizeof(float));
             if (has_attn) hipLaunchKernelGGL(phase_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, dbg_stream, cur);
             else hipLaunchKernelGGL(phase_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, dbg_stream, cur);
-            cur = Phase{}; blocks = 0; lds = 0; has_attn = false;
+            cur = Phase{}; blocks = 0; lds = 0; has_attn = false; any_dma = false; dma_bm64 = false;
         }
     }
     void gemm(const GemmArgs& g_in, int batch) {
@@ -694,10 +733,13 @@ struct Program {
             rc = fail(KM_ERR_UNSUPPORTED, "training program: operand larger than the 2 GiB a buffer descriptor addresses");
             return;
         }
+        { int ma = 0, mb = 0; op.dma = (use_dma && gemm_dma_ok(g, &ma, &mb)) ? 1 : 0; op.ma = (signed char)ma; op.mb = (signed char)mb; }
+        if (op.dma) { any_dma = true; if (op.bm == 64) dma_bm64 = true; }
         op.va = gemm_operand_vec(g.A, g.a_rs, g.a_cs, g.a_bs1, g.a_bs2, g.a_kbs) ? 1 : 0;
         op.vb = gemm_operand_vec(g.B, g.b_cs, g.b_rs, g.b_bs1, g.b_bs2, g.b_kbs) ? 1 : 0;
         if (!op.va) op.vb = 0;                   // three instantiations: (vec, vec), (vec, scalar), (scalar, scalar)
         add(op, op.gx * op.gy * batch);
+        if (!rc && !op_per_launch) gbatch[cur.n_ops - 1] = batch;
     }
     void need_lds(size_t bytes) { if (bytes > lds) lds = bytes; }
     void elem(int kind, const ElemArgs& e, int64_t nblocks) {
@@ -729,6 +771,9 @@ struct Program {
         pend_prev.swap(pend_cur);
         if (rc) return rc;
         if (cur.n_ops > 0) {
+            ++launches;
+            cur.ns = blocks <= alone_max ? 8 : 4;
+            if (any_dma) need_lds((size_t)gdma::lds_floats(dma_bm64 ? 64 : 32, cur.ns) * sizeof(float));
             if (has_attn) hipLaunchKernelGGL(phase_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, cur);
             else hipLaunchKernelGGL(phase_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, st, cur);
             HIP_TRY(hipGetLastError());
@@ -736,7 +781,7 @@ struct Program {
         cur = Phase{};
         blocks = 0;
         lds = 0;
-        has_attn = false;
+        has_attn = false; any_dma = false; dma_bm64 = false;
         return KM_OK;
     }
 };
@@ -900,6 +945,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     pg.allow_split = !c->opt.train_no_split;
     if (c->opt.train_bm32_below > 0) pg.bm32_below = c->opt.train_bm32_below;
     pg.op_per_launch = c->opt.train_op_per_launch != 0; pg.dbg_stream = st;
+    pg.use_dma = !c->opt.train_no_dma;
     if (c->opt.train_split_min_k > 0) { pg.min_k = c->opt.train_split_min_k; pg.chain = c->opt.train_split_min_k; }
     auto blocks4 = [](int64_t rows) { return (rows + 3) / 4; };            // one wave per row, 4 rows per block
     auto blocks256 = [](int64_t n) { return (n + 255) / 256; };

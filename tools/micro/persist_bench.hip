@@ -119,16 +119,16 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, st));
         CK(hipStreamSynchronize(st));
         float ms = 0.f; CK(hipEventElapsedTime(&ms, e0, e1));
-        CK(hipEventRecord(e0, st));
-        for (int i = 0; i < reps; ++i) CK(hipMemsetAsync(a, 0, bytes, st));
-        CK(hipEventRecord(e1, st));
-        CK(hipStreamSynchronize(st));
-        float ms0 = 0.f; CK(hipEventElapsedTime(&ms0, e0, e1));
         // check the chain of the last repetition
         float* last = (nph & 1) ? b : a;
         CK(hipMemcpy(host.data(), last, bytes, hipMemcpyDeviceToHost));
         size_t bad = 0;
         for (float x : host) bad += x != (float)nph;
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) CK(hipMemsetAsync(a, 0, bytes, st));
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float ms0 = 0.f; CK(hipEventElapsedTime(&ms0, e0, e1));
         unsigned tmo = 0;
         CK(hipMemcpy(&tmo, state + kmsync::kTimeoutWord, 4, hipMemcpyDeviceToHost));
         const double us = (ms - ms0) * 1e3 / reps;
