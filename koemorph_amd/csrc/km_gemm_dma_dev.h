@@ -21,12 +21,13 @@
 //         16 .. 31 swapped with 0 .. 15 in every other group of four k).  A fragment is four ds_read_b32 at compile-time
 //         offsets; lane groups lg and lg + 1 of a 32-lane half then read different halves of the 32 banks.
 //     Both operands use the k partition of km_gemm_dev.h (lane group lg supplies k = 16 kb + 4 lg + s to MFMA s).
-//   * Pipeline.  A ring of NS stage buffers (NS = 8 when a product's workgroups are alone on their CUs: K = 256 is
-//     requested whole at entry; NS = 4 when several workgroups share a CU), NS - 1 stages in flight: wait until stage `it`
-//     has landed (s_waitcnt vmcnt((NS - 2) L), L loads per thread and stage -- stages past the end are issued out of range so
-//     that the count stays uniform), s_barrier (everyone's part of stage `it` has landed, everyone is done reading stage
-//     it - 1), request stage it + NS - 1 into the buffer just freed, then fragments + MFMAs of stage `it`.  Raw s_barrier
-//     and inline-asm waits: __syncthreads() would drain the DMA queue (cdna_hip_programming.md, "Pipelining across barriers").
+//   * Pipeline.  A ring of NS stage buffers (gdma::ring_stages), NS - 2 stages in flight under a step's MFMAs.  Step `it`:
+//     s_waitcnt vmcnt((NS - 3) L) -- stage it + 1 of this thread has landed (L loads per thread and stage; stages past the end are
+//     issued out of range so that the count stays uniform) --, s_barrier (everyone's part of it has landed; everyone's
+//     fragment reads of stage it - 1 are complete), request stage it + NS - 1 into the buffer of stage it - 1, fetch the
+//     fragments of stage it + 1 into the second register set, then the MFMAs of stage `it` on the set fetched a step earlier:
+//     LDS latency and the DMA issue sit under the matrix pipe.  Raw s_barrier and inline-asm waits: __syncthreads() would
+//     drain the DMA queue (cdna_hip_programming.md, "Pipelining across barriers").
 //   * Eligibility (gemm_dma_ok): K a multiple of 32, no contraction batch, 16-byte aligned slots, operand modes (0,0) NT,
 //     (0,1) NN or (1,1) TN.  Rows outside the matrix are zero-filled by the descriptor's range check (they only feed output
 //     elements that are never stored).  Everything else runs on the register-staged tile.
@@ -40,6 +41,9 @@ namespace gdma {
 constexpr int BN = 64, BK = 32;
 constexpr int stage_floats(int BM) { return (BM + BN) * BK; }
 constexpr int lds_floats(int BM, int NS) { return NS * stage_floats(BM); }
+// ring stages: 8 for the 32-row tiles of a phase whose workgroups are alone on their CUs (the 8-window step: the whole K = 256 is
+// requested at entry, 96 KB of LDS), else 4 (48 / 64 KB: several workgroups per CU hide each other's prologue and epilogue)
+constexpr int ring_stages(int BM, bool alone) { return BM == 32 && alone ? 8 : 4; }
 }
 
 typedef __attribute__((address_space(3))) void* km_lds_ptr;
@@ -83,31 +87,38 @@ struct DmaOperand {
             }
         }
     }
-    // request k-tile nk into the stage image `img` (wave-uniform pointer); dead: a stage past the end (everything out of range)
-    __device__ __forceinline__ void issue(float* img, int wave, int nk, bool dead) const {
+    // request k-tile nk into the stage image `img` (wave-uniform pointer); dead = 0x80000000 for a stage past the end (the OR
+    // sends every lane out of range: branch-free, the DMA count per stage stays uniform), else 0
+    __device__ __forceinline__ void issue(float* img, int wave, int nk, unsigned dead) const {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const unsigned o = dead ? OOB : voff[i] + (unsigned)nk * kstep;
+            const unsigned o = (voff[i] + (unsigned)nk * kstep) | dead;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (km_lds_ptr)(img + (i * 256 + 64 * wave) * 4), 16, o, 0, 0, 0);
         }
     }
 };
 
-// per-lane read position of one 16-row tile of an operand image (rows rowbase .. rowbase + 15, rowbase a multiple of 16)
-template <int ROWS, int MODE>
-struct DmaFragment {
-    int base, sw;
+// per-lane read positions of the NT 16-row tiles of an operand image that a wave owns (rows rowbase + 16 t + lj).  The swizzles
+// depend on lj and lg only, so the tiles differ by compile-time offsets in mode 0 and by one position per tile in mode 1.
+template <int ROWS, int MODE, int NT>
+struct DmaFragments {
+    int pos[MODE == 0 ? 2 : NT];
     __device__ __forceinline__ void init(int rowbase, int lg, int lj) {
-        const int R = rowbase + lj;
-        if constexpr (MODE == 0) { base = R * 32; sw = (R >> 1) & 7; }
-        else { base = 4 * lg * ROWS + (R ^ (16 * (lg & 1))); sw = 0; }
-    }
-    // the lane's operand values of the four MFMAs of k block kb (k = 16 kb + 4 lg + s, s = 0 .. 3)
-    __device__ __forceinline__ f32x4 read(const float* img, int kb, int lg) const {
         if constexpr (MODE == 0) {
-            return *reinterpret_cast<const f32x4*>(img + base + (((4 * kb + lg) ^ sw) << 2));
+            const int sw = (lj >> 1) & 7;                        // (R >> 1) & 7 with R = rowbase + 16 t + lj, rowbase a multiple of 16
+            pos[0] = (rowbase + lj) * 32 + (((lg) ^ sw) << 2);   // k block 0: chunk lg
+            pos[1] = (rowbase + lj) * 32 + (((4 + lg) ^ sw) << 2);
         } else {
-            const float* p = img + base + 16 * kb * ROWS;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) pos[t] = 4 * lg * ROWS + ((rowbase + 16 * t + lj) ^ (16 * (lg & 1)));
+        }
+    }
+    // the lane's operand values of the four MFMAs of k block kb (k = 16 kb + 4 lg + s, s = 0 .. 3) for tile t
+    __device__ __forceinline__ f32x4 read(const float* img, int t, int kb) const {
+        if constexpr (MODE == 0) {
+            return *reinterpret_cast<const f32x4*>(img + pos[kb] + t * 16 * 32);
+        } else {
+            const float* p = img + pos[t] + 16 * kb * ROWS;
             return f32x4{p[0], p[ROWS], p[2 * ROWS], p[3 * ROWS]};
         }
     }
@@ -115,9 +126,91 @@ struct DmaFragment {
 
 template <int N> __device__ __forceinline__ void km_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// tile (bx, by) of output batch bz; smem = gdma::lds_floats(BM, ns) floats, 16-byte aligned; ns = 4 or 8 ring stages
-template <int BM, int MA, int MB>
-__device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int by, int bz, float* smem, int ns) {
+// Epilogue of the DMA tile: C through a buffer descriptor -- a row outside the matrix lies beyond its range (the store is dropped,
+// a load returns 0), a column outside sets the offset's top bit -- so no per-element branch; row offsets advance by adds.
+// alpha, bias (per column / per row), beta C, activation, dropout as in gemm_tile_epilogue; every load before the first store.
+template <int MT>
+__device__ __forceinline__ void gemm_tile_epilogue_buf(const GemmArgs& g, float* C, const f32x4 (&acc)[MT][2], int mw, int nw, int lg, int lj) {
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(C, 0, (unsigned)(((int64_t)(g.M - 1) * g.c_rs + g.N) * 4), 0x00020000);
+    const int n_a = nw + lj, n_b = nw + 16 + lj;
+    const unsigned oob_a = n_a < g.N ? 0u : 0x80000000u, oob_b = n_b < g.N ? 0u : 0x80000000u;
+    const unsigned rstep = (unsigned)g.c_rs * 4u;
+    const unsigned row0 = (unsigned)(mw + 4 * lg) * rstep + (unsigned)n_a * 4u;           // element (i = 0, r = 0, jn = 0)
+    float va[MT][4], vb[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { va[i][r] = g.alpha * acc[i][0][r]; vb[i][r] = g.alpha * acc[i][1][r]; }
+    if (g.bias_mode == 1) {
+        const float ba = g.bias[n_a < g.N ? n_a : g.N - 1], bb = g.bias[n_b < g.N ? n_b : g.N - 1];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { va[i][r] += ba; vb[i][r] += bb; }
+    } else if (g.bias_mode == 2) {
+        float bv[MT][4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int m = mw + 16 * i + 4 * lg + r; bv[i][r] = g.bias[m < g.M ? m : g.M - 1]; }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { va[i][r] += bv[i][r]; vb[i][r] += bv[i][r]; }
+    }
+    if (g.beta != 0.f) {
+        float oa[MT][4], ob[MT][4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned o = row0 + (unsigned)(16 * i + r) * rstep;
+                oa[i][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, o | oob_a, 0, 0));
+                ob[i][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, (o + 64u) | oob_b, 0, 0));
+            }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { va[i][r] += g.beta * oa[i][r]; vb[i][r] += g.beta * ob[i][r]; }
+    }
+    if (g.relu != 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { va[i][r] = gemm_act(va[i][r], g.relu); vb[i][r] = gemm_act(vb[i][r], g.relu); }
+    }
+    if (g.drop) {
+        unsigned char ka[MT][4], kb[MT][4];
+        const int nca = n_a < g.N ? n_a : g.N - 1, ncb = n_b < g.N ? n_b : g.N - 1;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mw + 16 * i + 4 * lg + r;
+                const unsigned char* row = g.drop + gemm_drop_row(g.drop_map, m < g.M ? m : g.M - 1) * g.N;
+                ka[i][r] = row[nca]; kb[i][r] = row[ncb];
+            }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                va[i][r] = ka[i][r] ? va[i][r] * g.drop_scale : 0.f;
+                vb[i][r] = kb[i][r] ? vb[i][r] * g.drop_scale : 0.f;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned o = row0 + (unsigned)(16 * i + r) * rstep;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(va[i][r]), rc, o | oob_a, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vb[i][r]), rc, (o + 64u) | oob_b, 0, 0);
+        }
+}
+
+// tile (bx, by) of output batch bz; smem = gdma::lds_floats(BM, NS) floats, 16-byte aligned; NS = 4 or 8 ring stages
+template <int BM, int NS, int MA, int MB>
+__device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int by, int bz, float* smem) {
     using namespace gdma;
     constexpr int MT = BM / 32, SF = stage_floats(BM), L = BM / 32 + 2;      // L: DMA instructions per thread and stage
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: it enters LDS-DMA destinations
@@ -130,48 +223,68 @@ __device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int
     ta.init(g.A + z1 * g.a_bs1 + z2 * g.a_bs2, g.a_rs, g.a_cs, m0, g.M, gemm_operand_extent(g.M, g.a_rs, g.K, g.a_cs, 1, 0), tid);
     tb.init(g.B + z1 * g.b_bs1 + z2 * g.b_bs2, g.b_cs, g.b_rs, n0, g.N, gemm_operand_extent(g.N, g.b_cs, g.K, g.b_rs, 1, 0), tid);
     float* C = g.C + z1 * g.c_bs1 + z2 * g.c_bs2;
-    DmaFragment<BM, MA> fa[MT];
-    DmaFragment<BN, MB> fb[2];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) fa[i].init(16 * MT * wm + 16 * i, lg, lj);
-#pragma unroll
-    for (int jn = 0; jn < 2; ++jn) fb[jn].init(32 * wn + 16 * jn, lg, lj);
+    DmaFragments<BM, MA, MT> fa;
+    DmaFragments<BN, MB, 2> fb;
+    fa.init(16 * MT * wm, lg, lj);
+    fb.init(32 * wn, lg, lj);
     f32x4 acc[MT][2];
 #pragma unroll
     for (int i = 0; i < MT; ++i) { acc[i][0] = f32x4{0, 0, 0, 0}; acc[i][1] = f32x4{0, 0, 0, 0}; }
-    const int kt = g.K / BK, mask = ns - 1;
+    const int kt = g.K / BK;
     KM_TILE_STAMP(1);
     auto issue = [&](int j) {
-        float* img = smem + (j & mask) * SF;
-        ta.issue(img, wave, j, j >= kt);
-        tb.issue(img + BM * BK, wave, j, j >= kt);
+        float* img = smem + (j & (NS - 1)) * SF;
+        const unsigned dead = j >= kt ? 0x80000000u : 0u;
+        ta.issue(img, wave, j, dead);
+        tb.issue(img + BM * BK, wave, j, dead);
     };
-    for (int j = 0; j < ns - 1; ++j) issue(j);
-    for (int it = 0; it < kt; ++it) {
-        if (ns == 8) km_wait_vmcnt<6 * L>(); else km_wait_vmcnt<2 * L>();       // stage `it` of this thread has landed
-        __builtin_amdgcn_s_barrier();                                          // ... and everyone's; stage it - 1 is free
-        if (it == 0) KM_TILE_STAMP(2);
-        issue(it + ns - 1);
-        const float* As = smem + (it & mask) * SF;
+    // fragments of one stage: [tile][k block]
+    auto fetch = [&](int j, f32x4 (&af)[MT][2], f32x4 (&bf)[2][2]) {
+        const float* As = smem + (j & (NS - 1)) * SF;
         const float* Bs = As + BM * BK;
 #pragma unroll
-        for (int kb = 0; kb < BK / 16; ++kb) {
-            f32x4 af[MT], bf[2];
+        for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = fa[i].read(As, kb, lg);
+            for (int i = 0; i < MT; ++i) af[i][kb] = fa.read(As, i, kb);
 #pragma unroll
-            for (int jn = 0; jn < 2; ++jn) bf[jn] = fb[jn].read(Bs, kb, lg);
+            for (int jn = 0; jn < 2; ++jn) bf[jn][kb] = fb.read(Bs, jn, kb);
+        }
+    };
+    auto mfmas = [&](const f32x4 (&af)[MT][2], const f32x4 (&bf)[2][2]) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    acc[i][0] = KM_MFMA(af[i][q], bf[0][q], acc[i][0]);
-                    acc[i][1] = KM_MFMA(af[i][q], bf[1][q], acc[i][1]);
+                    acc[i][0] = KM_MFMA(af[i][kb][q], bf[0][kb][q], acc[i][0]);
+                    acc[i][1] = KM_MFMA(af[i][kb][q], bf[1][kb][q], acc[i][1]);
                 }
-        }
+    };
+    // one step: stage it + 1 has landed everywhere, the buffer of stage it - 1 is free; request stage it + NS - 1 into it, fetch
+    // the fragments of stage it + 1 (they arrive under the MFMAs of stage it, whose fragments were fetched a step earlier)
+    auto step = [&](int it, const f32x4 (&af)[MT][2], const f32x4 (&bf)[2][2], f32x4 (&af_n)[MT][2], f32x4 (&bf_n)[2][2]) {
+        km_wait_vmcnt<(NS - 3) * L>();
+        __builtin_amdgcn_s_barrier();
+        issue(it + NS - 1);
+        fetch(it + 1, af_n, bf_n);
+        mfmas(af, bf);
+    };
+#pragma unroll
+    for (int j = 0; j < NS - 1; ++j) issue(j);
+    km_wait_vmcnt<(NS - 2) * L>();                 // stage 0 of this thread has landed
+    __builtin_amdgcn_s_barrier();                  // ... and everyone's
+    KM_TILE_STAMP(2);
+    f32x4 af0[MT][2], bf0[2][2], af1[MT][2], bf1[2][2];
+    fetch(0, af0, bf0);
+    int it = 0;
+    for (; it + 1 < kt; it += 2) {                 // two steps per iteration: the fragment register sets alternate statically
+        step(it, af0, bf0, af1, bf1);
+        step(it + 1, af1, bf1, af0, bf0);
     }
+    if (it < kt) step(it, af0, bf0, af1, bf1);
     km_wait_vmcnt<0>();           // the out-of-range stages behind the last one are still writing zeros into the ring
     KM_TILE_STAMP(3);
-    gemm_tile_epilogue<MT>(g, C, acc, m0 + 16 * MT * wm, n0 + 32 * wn, lg, lj);
+    gemm_tile_epilogue_buf<MT>(g, C, acc, m0 + 16 * MT * wm, n0 + 32 * wn, lg, lj);
     __syncthreads();              // the caller may reuse smem (another tile of the same workgroup)
 }

@@ -73,7 +73,7 @@ struct Op {
     int gx, gy;            // OP_GEMM: tiles along N and M (blocks = gx * gy * batch)
     int bm;                // OP_GEMM: tile rows (32 when the product would leave most of the chip idle with 64)
     short va, vb;          // OP_GEMM: 16-byte loads are legal for operand A / B
-    short dma;             // OP_GEMM: the product runs on the LDS-DMA tile (km_gemm_dma_dev.h)
+    signed char dma, ns;   // OP_GEMM: the product runs on the LDS-DMA tile (km_gemm_dma_dev.h) with a ring of ns stages
     signed char ma, mb;    //          its operand modes (0 k-contiguous, 1 row-contiguous)
     union {
         GemmArgs g;
@@ -85,7 +85,6 @@ constexpr int kMaxOps = 17;     // 8 + 17 * 4 + 17 * sizeof(Op) stays under the 
 static_assert(sizeof(GemmArgs) <= 208, "Phase has to stay under the 4 KB kernel-argument limit");
 struct Phase {
     int n_ops;
-    int ns;                // ring stages of the LDS-DMA tiles of this phase: 8 when its workgroups are alone on their CUs, else 4
     int block_end[kMaxOps];
     Op ops[kMaxOps];
 };
@@ -598,9 +597,9 @@ __global__ __launch_bounds__(256, ATTN ? KM_TRAINP_WAVES_ATTN : KM_TRAINP_WAVES)
     extern __shared__ __attribute__((aligned(16))) float smem[];      // the host sizes it for the phase's largest operation
     (void)p_arg;
     KernargWords ka = (KernargWords)__builtin_amdgcn_kernarg_segment_ptr();
-    constexpr int W_NOPS = offsetof(Phase, n_ops) / 4, W_NS = offsetof(Phase, ns) / 4, W_END = offsetof(Phase, block_end) / 4,
+    constexpr int W_NOPS = offsetof(Phase, n_ops) / 4, W_END = offsetof(Phase, block_end) / 4,
                   W_OPS = offsetof(Phase, ops) / 4, W_OP = sizeof(Op) / 4;
-    const int vb = blockIdx.x, n_ops = (int)ka[W_NOPS], p_ns = (int)ka[W_NS];
+    const int vb = blockIdx.x, n_ops = (int)ka[W_NOPS];
     int i = 0;
     while (i + 1 < n_ops && vb >= (int)ka[W_END + i]) ++i;            // workgroup-uniform
     const int local = vb - (i ? (int)ka[W_END + i - 1] : 0);
@@ -612,14 +611,18 @@ __global__ __launch_bounds__(256, ATTN ? KM_TRAINP_WAVES_ATTN : KM_TRAINP_WAVES)
         const int bz = local / per, t = local - bz * per;
         const int tx = t % op.gx, ty = t / op.gx;
         if (op.dma) {
-            if (op.bm == 32) {
-                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<32, 0, 0>(op.g, tx, ty, bz, smem, p_ns);
-                else if (op.ma == 0) gemm_tile_dma_dev<32, 0, 1>(op.g, tx, ty, bz, smem, p_ns);
-                else gemm_tile_dma_dev<32, 1, 1>(op.g, tx, ty, bz, smem, p_ns);
+            if (op.bm == 32 && op.ns == 8) {
+                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<32, 8, 0, 0>(op.g, tx, ty, bz, smem);
+                else if (op.ma == 0) gemm_tile_dma_dev<32, 8, 0, 1>(op.g, tx, ty, bz, smem);
+                else gemm_tile_dma_dev<32, 8, 1, 1>(op.g, tx, ty, bz, smem);
+            } else if (op.bm == 32) {
+                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<32, 4, 0, 0>(op.g, tx, ty, bz, smem);
+                else if (op.ma == 0) gemm_tile_dma_dev<32, 4, 0, 1>(op.g, tx, ty, bz, smem);
+                else gemm_tile_dma_dev<32, 4, 1, 1>(op.g, tx, ty, bz, smem);
             } else {
-                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<64, 0, 0>(op.g, tx, ty, bz, smem, p_ns);
-                else if (op.ma == 0) gemm_tile_dma_dev<64, 0, 1>(op.g, tx, ty, bz, smem, p_ns);
-                else gemm_tile_dma_dev<64, 1, 1>(op.g, tx, ty, bz, smem, p_ns);
+                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<64, 4, 0, 0>(op.g, tx, ty, bz, smem);
+                else if (op.ma == 0) gemm_tile_dma_dev<64, 4, 0, 1>(op.g, tx, ty, bz, smem);
+                else gemm_tile_dma_dev<64, 4, 1, 1>(op.g, tx, ty, bz, smem);
             }
         } else
         // operand B of the channel encoder (rows of 259 floats) is the one product without 16-byte rows
@@ -656,7 +659,7 @@ struct Program {
     int blocks = 0;
     int launches = 0;
     bool use_dma = true, any_dma = false, dma_bm64 = false;      // LDS-DMA tiles (option train_no_dma switches them off)
-    int alone_max = 256;                 // a phase of at most this many workgroups has its CUs to itself: 8 ring stages
+    int alone_max = 256;                 // see end_phase
     int rc = KM_OK;
     size_t lds = 0;
     bool has_attn = false;        // the phase holds an attention block: phase_kernel<true>
@@ -685,8 +688,10 @@ struct Program {
         cur.block_end[cur.n_ops] = blocks;
         ++cur.n_ops;
         if (op_per_launch) {      // timing aid (option train_op_per_launch): every operation is its own launch, in program order
-            cur.ns = blocks <= alone_max ? 8 : 4;
-            if (op.kind == OP_GEMM && op.dma) need_lds((size_t)gdma::lds_floats(op.bm, cur.ns) * sizeof(float));
+            if (op.kind == OP_GEMM && op.dma) {
+                cur.ops[cur.n_ops - 1].ns = (signed char)gdma::ring_stages(op.bm, blocks <= alone_max);
+                need_lds((size_t)gdma::lds_floats(op.bm, cur.ops[cur.n_ops - 1].ns) * sizeof(float));
+            }
             if (has_attn) hipLaunchKernelGGL(phase_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, dbg_stream, cur);
             else hipLaunchKernelGGL(phase_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, dbg_stream, cur);
             cur = Phase{}; blocks = 0; lds = 0; has_attn = false; any_dma = false; dma_bm64 = false;
@@ -734,7 +739,7 @@ struct Program {
             return;
         }
         { int ma = 0, mb = 0; op.dma = (use_dma && gemm_dma_ok(g, &ma, &mb)) ? 1 : 0; op.ma = (signed char)ma; op.mb = (signed char)mb; }
-        if (op.dma) { any_dma = true; if (op.bm == 64) dma_bm64 = true; }
+        if (op.dma) { if (op.bm == 64) dma_bm64 = true; else any_dma = true; }
         op.va = gemm_operand_vec(g.A, g.a_rs, g.a_cs, g.a_bs1, g.a_bs2, g.a_kbs) ? 1 : 0;
         op.vb = gemm_operand_vec(g.B, g.b_cs, g.b_rs, g.b_bs1, g.b_bs2, g.b_kbs) ? 1 : 0;
         if (!op.va) op.vb = 0;                   // three instantiations: (vec, vec), (vec, scalar), (scalar, scalar)
@@ -772,8 +777,15 @@ struct Program {
         if (rc) return rc;
         if (cur.n_ops > 0) {
             ++launches;
-            cur.ns = blocks <= alone_max ? 8 : 4;
-            if (any_dma) need_lds((size_t)gdma::lds_floats(dma_bm64 ? 64 : 32, cur.ns) * sizeof(float));
+            // ring depth of the LDS-DMA tiles: a phase of at most alone_max workgroups has the chip to itself (one workgroup
+            // per CU: deep rings); beyond that LDS is occupancy
+            const bool alone = blocks <= alone_max;
+            for (int i = 0; i < cur.n_ops; ++i) {
+                Op& o = cur.ops[i];
+                if (o.kind != OP_GEMM || !o.dma) continue;
+                o.ns = (signed char)gdma::ring_stages(o.bm, alone);
+                need_lds((size_t)gdma::lds_floats(o.bm, o.ns) * sizeof(float));
+            }
             if (has_attn) hipLaunchKernelGGL(phase_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, cur);
             else hipLaunchKernelGGL(phase_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, st, cur);
             HIP_TRY(hipGetLastError());

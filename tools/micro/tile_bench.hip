@@ -8,6 +8,7 @@
 //   tile_bench [--m 640] [--n 512] [--k 256] [--variant narrow2|narrow4|narrow8|wide2|wide4]
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -45,10 +46,10 @@ __global__ __launch_bounds__(256 * KG) void k_wide(GemmArgs g, int gx, unsigned 
     TB_STAMP(7);
 }
 template <int BM>
-__global__ __launch_bounds__(256) void k_dma(GemmArgs g, int gx, int ns) {
+__global__ __launch_bounds__(256) void k_dma(GemmArgs g, int gx) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     TB_STAMP(0);
-    gemm_tile_dma_dev<BM, 0, 0>(g, blockIdx.x % gx, blockIdx.x / gx, 0, smem, ns);
+    gemm_tile_dma_dev<BM, BM == 32 ? 8 : 4, 0, 0>(g, blockIdx.x % gx, blockIdx.x / gx, 0, smem);
     TB_STAMP(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TB_STAMP(7);
@@ -89,10 +90,9 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL((k_narrow<BM_, D_>), dim3(blocks), dim3(256), l, st, g, gx, sp); } while (0)
 #define WIDE(BM_, KG_) do { size_t l = (size_t)KG_ * ggd::lds_floats(BM_) * 4; hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wide<BM_, KG_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         hipLaunchKernelGGL((k_wide<BM_, KG_>), dim3(blocks), dim3(256 * KG_), l, st, g, gx, sp); } while (0)
-#define DMA(BM_, NS_) do { size_t l = (size_t)gdma::lds_floats(BM_, NS_) * 4; hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dma<BM_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((k_dma<BM_>), dim3(blocks), dim3(256), l, st, g, gx, NS_); } while (0)
-        if (variant == "dma8") { if (bm == 32) DMA(32, 8); else DMA(64, 8); return; }
-        if (variant == "dma4") { if (bm == 32) DMA(32, 4); else DMA(64, 4); return; }
+#define DMA(BM_) do { size_t l = (size_t)gdma::lds_floats(BM_, gdma::ring_stages(BM_, true)) * 4; hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dma<BM_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((k_dma<BM_>), dim3(blocks), dim3(256), l, st, g, gx); } while (0)
+        if (variant == "dma") { if (bm == 32) DMA(32); else DMA(64); return; }
         if (bm == 32) {
             if (variant == "narrow2") NARROW(32, 2); else if (variant == "narrow4") NARROW(32, 4); else if (variant == "narrow8") NARROW(32, 8);
             else if (variant == "wide2") WIDE(32, 2); else if (variant == "wide4") WIDE(32, 4); else { printf("unknown variant\n"); exit(1); }
@@ -112,6 +112,22 @@ int main(int argc, char** argv) {
     for (int i = 0; i < reps; ++i) { hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, st, A, (size_t)M * K, 1.0f); hipLaunchKernelGGL(k_empty, dim3(blocks), dim3(256), 0, st); }
     CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
     CK(hipEventElapsedTime(&ms0, e0, e1));
+    // the variant against the register-staged tile on the same operands (claimed bit-identical)
+    {
+        std::vector<float> c0((size_t)M * N), c1((size_t)M * N);
+        const std::string keep = variant;
+        CK(hipMemsetAsync(C, 0xff, (size_t)M * N * 4, st));
+        launch(nullptr); CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost));
+        variant = "narrow2";
+        CK(hipMemsetAsync(C, 0xff, (size_t)M * N * 4, st));
+        launch(nullptr); CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(c0.data(), C, c0.size() * 4, hipMemcpyDeviceToHost));
+        variant = keep;
+        size_t diff = 0; double mx = 0;
+        for (size_t i = 0; i < c0.size(); ++i) { if (memcmp(&c0[i], &c1[i], 4)) ++diff; const double d = fabs((double)c0[i] - c1[i]); if (d > mx || d != d) mx = d; }
+        printf("%s vs narrow2: %zu of %zu elements differ bitwise, max |diff| %.3g (C[0] = %g, C[last] = %g)\n", variant.c_str(), diff, c0.size(), mx, c1[0], c1.back());
+    }
     // one stamped launch
     hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, st, A, (size_t)M * K, 1.0f);
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &stamps, sizeof(stamps)));
