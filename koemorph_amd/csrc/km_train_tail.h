@@ -39,6 +39,10 @@ struct TailArgs {
     float* part; unsigned* ctr;
     float* d_b2;          // or null: gradient of the decoder's output bias = sum of every dL/dz
     int* drop_ctr;        // or null: the dropout generator's step counter, advanced once per step
+    // or null: gradients of the decoder's hidden layer, dH[r][m] = dL/dz[r] w2[m] keep_scale [H[r][m] > 0] (H is post-ReLU,
+    // post-dropout: H > 0 <=> kept and active), for the mouth rows (dh1) and the 24 expression rows per window (dhe).  The
+    // phased step used to spend a phase of its own on this outer product (round 4: one launch less)
+    float* dh1; float* dhe; float keep_scale;
 };
 
 // One workgroup: decoder output layer, sigmoid, stream weights, clamp, EMA, loss and the gradient of the loss
@@ -266,6 +270,24 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
                 const int slot = tr_mouth_slot(i);
                 if (slot >= 0) a.grow[(int64_t)b * 28 + slot] = dzv;
                 else a.grow[(int64_t)a.B * 28 + (int64_t)b * 24 + tr_expr_slot(i)] = dzv;
+            }
+        }
+    }
+    if (a.dh1 && a.grow) {      // every dL/dz of this workgroup's windows is in a.grow: the hidden layer's gradient, 4 units per thread
+        __threadfence_block();
+        __syncthreads();
+        const int dh4 = a.DH >> 2, per_win = 52 * dh4;
+        for (int wl = 0; wl < n_own; ++wl) {
+            const int64_t b = wg + (int64_t)wl * G;
+            for (int e = threadIdx.x; e < per_win; e += 64 * NW) {
+                const int r = e / dh4, m4 = e - r * dh4;
+                const int64_t row = r < 28 ? b * 28 + r : (int64_t)a.B * 28 + b * 24 + (r - 28);
+                const float gs = a.grow[row], ks = a.keep_scale;
+                const float* hp = r < 28 ? a.h1 + row * a.DH : a.he + (row - (int64_t)a.B * 28) * a.DH;
+                float* dp = r < 28 ? a.dh1 + row * a.DH : a.dhe + (row - (int64_t)a.B * 28) * a.DH;
+                const float4 h = reinterpret_cast<const float4*>(hp)[m4], w = reinterpret_cast<const float4*>(a.w2)[m4];
+                reinterpret_cast<float4*>(dp)[m4] = make_float4(h.x > 0.f ? gs * w.x * ks : 0.f, h.y > 0.f ? gs * w.y * ks : 0.f,
+                                                                 h.z > 0.f ? gs * w.z * ks : 0.f, h.w > 0.f ? gs * w.w * ks : 0.f);
             }
         }
     }

@@ -679,23 +679,22 @@ struct Program {
             if (K % S == 0 && K / S >= 128 && tiles * S <= 512 && std::abs(S - want) < std::abs(best - want)) best = S;
         return best;
     }
-    void add(const Op& op, int nblocks) {
+    // op_lds: dynamic LDS the operation needs (the LDS-DMA tiles' rings are sized in launch_cur)
+    void add(const Op& op, int nblocks, size_t op_lds = 0) {
         if (nblocks <= 0) return;
+        // a full phase (the 4 KB kernel argument holds kMaxOps operations) is launched and continued in a second launch: at large
+        // batches the reductions of the previous phase's split products join the phase's own operations
+        if (cur.n_ops >= kMaxOps && !op_per_launch) { if (int r = launch_cur(dbg_stream)) { rc = r; return; } }
         if (cur.n_ops >= kMaxOps) { rc = fail(KM_ERR_UNSUPPORTED, "training program: more than %d operations in one phase", kMaxOps); return; }
+        need_lds(op_lds);
+        if (op.kind == OP_ATTN_FWD || op.kind == OP_ATTN_BWD) has_attn = true;
+        if (op.kind == OP_GEMM && op.dma) { if (op.bm == 64) dma_bm64 = true; else any_dma = true; }
         cur.ops[cur.n_ops] = op;
         nb[cur.n_ops] = nblocks; gbatch[cur.n_ops] = 1;
         blocks += nblocks;
         cur.block_end[cur.n_ops] = blocks;
         ++cur.n_ops;
-        if (op_per_launch) {      // timing aid (option train_op_per_launch): every operation is its own launch, in program order
-            if (op.kind == OP_GEMM && op.dma) {
-                cur.ops[cur.n_ops - 1].ns = (signed char)gdma::ring_stages(op.bm, blocks <= alone_max);
-                need_lds((size_t)gdma::lds_floats(op.bm, cur.ops[cur.n_ops - 1].ns) * sizeof(float));
-            }
-            if (has_attn) hipLaunchKernelGGL(phase_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, dbg_stream, cur);
-            else hipLaunchKernelGGL(phase_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, dbg_stream, cur);
-            cur = Phase{}; blocks = 0; lds = 0; has_attn = false; any_dma = false; dma_bm64 = false;
-        }
+        if (op_per_launch) { if (int r = launch_cur(dbg_stream)) rc = r; }      // timing aid (option train_op_per_launch): every operation is its own launch, in program order
     }
     void gemm(const GemmArgs& g_in, int batch) {
         GemmArgs g = g_in;
@@ -728,7 +727,6 @@ struct Program {
         op.kind = OP_GEMM; op.g = g;
         op.gx = (g.N + 63) / 64; op.gy = (g.M + 63) / 64; op.bm = 64;
         if (g.M <= 32 || op.gx * op.gy * batch < bm32_below) { op.bm = 32; op.gy = (g.M + 31) / 32; }   // finer tiles: more CUs, half the chain
-        need_lds((size_t)ggd::lds_floats(op.bm) * sizeof(float));
         if ((g.a_cs != 1 && g.a_rs != 1) || (g.b_rs != 1 && g.b_cs != 1)) {
             rc = fail(KM_ERR_UNSUPPORTED, "training program: an operand is contiguous neither along k nor along its rows");
             return;
@@ -739,19 +737,17 @@ struct Program {
             return;
         }
         { int ma = 0, mb = 0; op.dma = (use_dma && gemm_dma_ok(g, &ma, &mb)) ? 1 : 0; op.ma = (signed char)ma; op.mb = (signed char)mb; }
-        if (op.dma) { if (op.bm == 64) dma_bm64 = true; else any_dma = true; }
         op.va = gemm_operand_vec(g.A, g.a_rs, g.a_cs, g.a_bs1, g.a_bs2, g.a_kbs) ? 1 : 0;
         op.vb = gemm_operand_vec(g.B, g.b_cs, g.b_rs, g.b_bs1, g.b_bs2, g.b_kbs) ? 1 : 0;
         if (!op.va) op.vb = 0;                   // three instantiations: (vec, vec), (vec, scalar), (scalar, scalar)
-        add(op, op.gx * op.gy * batch);
+        add(op, op.gx * op.gy * batch, (size_t)ggd::lds_floats(op.bm) * sizeof(float));
         if (!rc && !op_per_launch) gbatch[cur.n_ops - 1] = batch;
     }
     void need_lds(size_t bytes) { if (bytes > lds) lds = bytes; }
-    void elem(int kind, const ElemArgs& e, int64_t nblocks) {
+    void elem(int kind, const ElemArgs& e, int64_t nblocks, size_t op_lds = 0) {
         Op op{};
-        if (kind == OP_ATTN_FWD || kind == OP_ATTN_BWD) has_attn = true;
         op.kind = kind; op.e = e;
-        add(op, (int)nblocks);
+        add(op, (int)nblocks, op_lds);
     }
     void add_pending_reduces() {          // the partials written by the previous phase, four reductions per operation
         for (size_t i = 0; i < pend_prev.size(); i += 4) {
@@ -771,9 +767,8 @@ struct Program {
         }
         pend_prev.clear();
     }
-    int end_phase(hipStream_t st) {
-        add_pending_reduces();
-        pend_prev.swap(pend_cur);
+    // launch what the phase holds so far (its operations are independent of each other, so a phase may be cut anywhere)
+    int launch_cur(hipStream_t st) {
         if (rc) return rc;
         if (cur.n_ops > 0) {
             ++launches;
@@ -795,6 +790,11 @@ struct Program {
         lds = 0;
         has_attn = false; any_dma = false; dma_bm64 = false;
         return KM_OK;
+    }
+    int end_phase(hipStream_t st) {
+        add_pending_reduces();
+        pend_prev.swap(pend_cur);
+        return launch_cur(st);
     }
 };
 
@@ -975,7 +975,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     unsigned scale_bits;
     std::memcpy(&scale_bits, &scale, sizeof(scale_bits));
 
-    // ================= P0: clean bucket, ones, masks, packed input, input-independent products =================
+    // ================= P0: clean bucket, ones, masks, packed input (element-wise only: 5 us instead of 15) =================
     {
         ElemArgs e{};
         e.q0 = flat_grad; e.n0 = c->tr_nparams;
@@ -1010,14 +1010,10 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         pg.elem(OP_PACKX, e, blocks256(B * KP * (NKk / 4)));
     }
     const float* X = xp_dev ? xp_dev : xp;
-    pg.gemm(NT(P("mouth_queries"), d, inw, d, Qb, d, 28, d, inb, 0), 1);                                  // Q = mq Wq^T + bq
-    pg.gemm(NN(Wmo, d, Wo, d, T1m, d, d, d, d), 1);                                                        // T1 = Wmo Wo
-    pg.gemm(NN(Weo, d, Woe, d, T1e, d, d, d, d), 1);
-    { GemmArgs g = G(Wmo, d, 1, bo, 1, 0, t1m, 1, d, 1, d); g.bias = bmo; g.bias_mode = 2; pg.gemm(g, 1); }   // t1 = Wmo bo + bmo
-    { GemmArgs g = G(Weo, d, 1, boe, 1, 0, t1e, 1, d, 1, d); g.bias = beo; g.bias_mode = 2; pg.gemm(g, 1); }
-    pg.gemm(NT(emo, ED, P("emotion_encoder.weight"), ED, E0, d, B, d, P("emotion_encoder.bias"), 0), 1);
     RUN(pg.end_phase(st));
-    // ================= P1: channel encoder; folds; emotion LayerNorm =================
+    // ================= P1: channel encoder; beside it the input-independent products (Q, T1 = Wmo Wo) and E0 =================
+    // (round 4: they used to sit in P0, whose K = 256 tile chains made that phase as long as a product phase for nothing the
+    // channel encoder waits for; the emotion chain and the folds run one phase later than before, still ahead of their readers)
     if (asrc) {       // the window maxima were read in P0: clean slots for the next front-end launch (no memset)
         ElemArgs z{};
         z.q0 = reinterpret_cast<float*>(c->ws_melmax); z.n0 = c->ws_windows;
@@ -1029,49 +1025,54 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         g.a_bs1 = KP * NKk; g.c_bs1 = NKk * d; g.bias = P("mel_channel_encoder.bias"); g.bias_mode = 1;
         pg.gemm(g, (int)B);
     }
-    pg.gemm(NN(W1, d, T1m, d, Wfm, d, DH, d, d), 1);                                                        // Wf = W1 T1
-    pg.gemm(NN(W1, d, T1e, d, Wfe, d, DH, d, d), 1);
-    { GemmArgs g = G(W1, d, 1, t1m, 1, 0, bfm, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }     // bf = W1 t1 + b1
-    { GemmArgs g = G(W1, d, 1, t1e, 1, 0, bfe, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }
-    {
-        ElemArgs e{};
-        e.p0 = E0; e.q0 = E; e.n0 = B; e.i0 = (int)d; e.p1 = P("emotion_norm.weight"); e.p2 = P("emotion_norm.bias"); e.q1 = emu; e.q2 = ers;
-        pg.elem(OP_LN_FWD, e, blocks4(B));
-    }
+    pg.gemm(NT(P("mouth_queries"), d, inw, d, Qb, d, 28, d, inb, 0), 1);                                  // Q = mq Wq^T + bq
+    pg.gemm(NN(Wmo, d, Wo, d, T1m, d, d, d, d), 1);                                                        // T1 = Wmo Wo
+    pg.gemm(NN(Weo, d, Woe, d, T1e, d, d, d, d), 1);
+    { GemmArgs g = G(Wmo, d, 1, bo, 1, 0, t1m, 1, d, 1, d); g.bias = bmo; g.bias_mode = 2; pg.gemm(g, 1); }   // t1 = Wmo bo + bmo
+    { GemmArgs g = G(Weo, d, 1, boe, 1, 0, t1e, 1, d, 1, d); g.bias = beo; g.bias_mode = 2; pg.gemm(g, 1); }
+    pg.gemm(NT(emo, ED, P("emotion_encoder.weight"), ED, E0, d, B, d, P("emotion_encoder.bias"), 0), 1);
     RUN(pg.end_phase(st));
-    // ================= P2: LayerNorm; emotion value projection =================
+    // ================= P2: LayerNorm (both streams); folds Wf = W1 T1 =================
     {
         ElemArgs e{};
         e.p0 = Y0; e.q0 = Y; e.n0 = R; e.i0 = (int)d; e.p1 = P("mel_norm.weight"); e.p2 = P("mel_norm.bias"); e.q1 = mu; e.q2 = rs;
         pg.elem(OP_LN_FWD, e, blocks4(R));
     }
+    {
+        ElemArgs e{};
+        e.p0 = E0; e.q0 = E; e.n0 = B; e.i0 = (int)d; e.p1 = P("emotion_norm.weight"); e.p2 = P("emotion_norm.bias"); e.q1 = emu; e.q2 = ers;
+        pg.elem(OP_LN_FWD, e, blocks4(B));
+    }
+    pg.gemm(NN(W1, d, T1m, d, Wfm, d, DH, d, d), 1);                                                        // Wf = W1 T1
+    pg.gemm(NN(W1, d, T1e, d, Wfe, d, DH, d, d), 1);
+    { GemmArgs g = G(W1, d, 1, t1m, 1, 0, bfm, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }     // bf = W1 t1 + b1
+    { GemmArgs g = G(W1, d, 1, t1e, 1, 0, bfe, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }
+    RUN(pg.end_phase(st));
+    // ================= P3: [K | V]; emotion value projection =================
+    pg.gemm(NT(Y, d, inw + d * d, d, KV, 2 * d, R, 2 * d, inb + d, 0), 1);
     pg.gemm(NT(E, d, einw + 2 * d * d, d, Ve, d, B, d, einb + 2 * d, 0), 1);
     RUN(pg.end_phase(st));
-    // ================= P3: [K | V]; emotion attention (one key: weight 1, dropped or kept per head and query) =================
-    pg.gemm(NT(Y, d, inw + d * d, d, KV, 2 * d, R, 2 * d, inb + d, 0), 1);
+    // ================= P4: attention (scores, softmax, dropout, P V) per (window, head); emotion attention (one key: weight 1,
+    // dropped or kept per head and query) =================
+    {
+        ElemArgs e{};
+        e.p0 = Qb; e.p1 = KV; e.q0 = Pm; e.q1 = A; e.i0 = (int)d; e.i1 = (int)hd; e.i2 = (int)NKk; e.i3 = (int)H;
+        e.mask = m_mel; e.f0 = keep_scale; e.u0 = scale_bits;
+        pg.elem(OP_ATTN_FWD, e, B * H, (size_t)attn_mfma_fwd_lds_floats((int)hd, (int)NKk) * sizeof(float));
+    }
     {
         ElemArgs e{};
         e.p0 = Ve; e.q0 = Ae; e.n0 = B; e.i0 = (int)d; e.i1 = (int)hd; e.mask = m_emo; e.f0 = keep_scale;
         pg.elem(OP_EMO_EXPAND, e, blocks256(Re * d));
     }
     RUN(pg.end_phase(st));
-    // ================= P4: attention (scores, softmax, dropout, P V) per (window, head); emotion rows through the fold =================
-    {
-        ElemArgs e{};
-        e.p0 = Qb; e.p1 = KV; e.q0 = Pm; e.q1 = A; e.i0 = (int)d; e.i1 = (int)hd; e.i2 = (int)NKk; e.i3 = (int)H;
-        e.mask = m_mel; e.f0 = keep_scale; e.u0 = scale_bits;
-        pg.need_lds((size_t)attn_mfma_fwd_lds_floats((int)hd, (int)NKk) * sizeof(float));
-        pg.elem(OP_ATTN_FWD, e, B * H);
-    }
+    // ================= P5: decoder hidden through the fold (+ ReLU + dropout), both streams; O1, Oe1 beside it =================
+    { GemmArgs g = NT(A, d, Wfm, d, H1, DH, Rm, DH, bfm, 1); g.drop = m_dec; g.drop_scale = keep_scale; g.drop_map = 1; pg.gemm(g, 1); }
     { GemmArgs g = NT(Ae, d, Wfe, d, He, DH, Re, DH, bfe, 1); g.drop = m_dec; g.drop_scale = keep_scale; g.drop_map = 2; pg.gemm(g, 1); }
+    pg.gemm(NT(A, d, Wo, d, O1, d, Rm, d, bo, 0), 1);
     pg.gemm(NT(Ae, d, Woe, d, Oe1, d, Re, d, boe, 0), 1);
     RUN(pg.end_phase(st));
-    // ================= P5: decoder hidden through the fold (+ ReLU + dropout); O1, Oe2 beside it =================
-    { GemmArgs g = NT(A, d, Wfm, d, H1, DH, Rm, DH, bfm, 1); g.drop = m_dec; g.drop_scale = keep_scale; g.drop_map = 1; pg.gemm(g, 1); }
-    pg.gemm(NT(A, d, Wo, d, O1, d, Rm, d, bo, 0), 1);
-    pg.gemm(NT(Oe1, d, Weo, d, Oe2, d, Re, d, beo, 0), 1);
-    RUN(pg.end_phase(st));
-    // ================= P6: decoder output layer + loss tail (one workgroup) =================
+    // ================= P6: decoder output layer + loss tail; it also writes the hidden layer's gradients dH =================
     {
         TailArgs t{};
         t.zrows = zrows; t.zrows_out = zrows; t.grow = grow; t.h1 = H1; t.he = He; t.w2 = w2; t.b2 = b2;
@@ -1082,6 +1083,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         t.B = (int)B; t.DH = (int)DH; t.expr_rows = 24; t.audio_energy = c->tr_loss_cfg.audio_energy_dev; t.out2 = out_dev;
         t.d_b2 = Gd("blendshape_decoder.3.bias"); t.drop_ctr = (drop && c->tr_dropout_mode == 0) ? c->trp_drop_ctr : nullptr;
         t.part = c->trp_tail_part; t.ctr = c->trp_tail_ctr;
+        t.dh1 = dH1; t.dhe = dHe; t.keep_scale = keep_scale;
         // one workgroup per two windows (the 8-window step: four, 231.7 us against 240 with one), at most 32; the audio-visual term
         // couples the whole batch: one
         const bool av = c->tr_loss_cfg.perceptual_weight > 0.f && c->tr_loss_cfg.audio_energy_dev;
@@ -1091,33 +1093,23 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         hipLaunchKernelGGL(trainp_tail_kernel, dim3((unsigned)groups), dim3(1024), 0, st, t);
         HIP_TRY(hipGetLastError());
     }
-    // ================= P7: decoder output layer backward; O2 (needed from P8 on) =================
-    {
-        ElemArgs e{};
-        e.p0 = grow; e.p1 = H1; e.p2 = w2; e.q0 = dH1; e.n0 = Rm; e.i0 = (int)DH; e.f0 = keep_scale;
-        pg.elem(OP_RELU_OUTER, e, blocks256(Rm * DH));
-        e.p0 = grow + Rm; e.p1 = He; e.q0 = dHe; e.n0 = Re;
-        pg.elem(OP_RELU_OUTER, e, blocks256(Re * DH));
-    }
-    colsum(H1, Rm, DH, DH, Gd("blendshape_decoder.3.weight"), 0, grow);                                     // dw2 = sum_r g[r] H1[r]
-    pg.gemm(NT(O1, d, Wmo, d, O2, d, Rm, d, bmo, 0), 1);
-    RUN(pg.end_phase(st));
-    // ================= P8: input gradients through the fold; decoder[0] parameter gradients =================
+    // ================= P8: input gradients through the fold; O2, Oe2 (needed by the decoder[0] gradients); dw2, db1 =================
+    // (P7 -- the outer product dH = g w2 [H > 0] and O2 -- is gone: the tail writes dH, O2 rides here)
     pg.gemm(NN(dH1, DH, Wfm, d, dA, d, Rm, d, DH), 1);
     pg.gemm(NN(dHe, DH, Wfe, d, dAe, d, Re, d, DH), 1);
     pg.gemm(NN(dH1, DH, W1, d, dO2, d, Rm, d, DH), 1);
     pg.gemm(NN(dHe, DH, W1, d, dOe2, d, Re, d, DH), 1);
-    pg.gemm(TN(dH1, DH, O2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, Rm), 1);
+    pg.gemm(NT(O1, d, Wmo, d, O2, d, Rm, d, bmo, 0), 1);
+    pg.gemm(NT(Oe1, d, Weo, d, Oe2, d, Re, d, beo, 0), 1);
+    colsum(H1, Rm, DH, DH, Gd("blendshape_decoder.3.weight"), 0, grow);                                     // dw2 = sum_r g[r] H1[r]
     colsum(dH1, Rm, DH, DH, Gd("blendshape_decoder.0.bias"), 0, ones);
-    colsum(He, Re, DH, DH, Gd("blendshape_decoder.3.weight"), 1, grow + Rm);
     RUN(pg.end_phase(st));
-    // ================= P9: attention backward per (window, head); emotion value gradient; output projections =================
+    // ================= P9: attention backward per (window, head); emotion value gradient; output projections; decoder[0] weight =================
     {
         ElemArgs e{};
         e.p0 = Qb; e.p1 = KV; e.p2 = Pm; e.p3 = dA; e.q0 = dKV; e.q1 = dQ_part; e.i0 = (int)d; e.i1 = (int)hd; e.i2 = (int)NKk; e.i3 = (int)H;
         e.mask = m_mel; e.f0 = keep_scale; e.u0 = scale_bits;
-        pg.need_lds(attn_lds);
-        pg.elem(OP_ATTN_BWD, e, B * H);
+        pg.elem(OP_ATTN_BWD, e, B * H, attn_lds);
     }
     {
         ElemArgs e{};
@@ -1126,6 +1118,8 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     }
     pg.gemm(NN(dO2, d, Wmo, d, dO1, d, Rm, d, d), 1);
     pg.gemm(NN(dOe2, d, Weo, d, dOe1, d, Re, d, d), 1);
+    pg.gemm(TN(dH1, DH, O2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, Rm), 1);
+    colsum(He, Re, DH, DH, Gd("blendshape_decoder.3.weight"), 1, grow + Rm);
     RUN(pg.end_phase(st));
     // ================= P10: dY; in_proj [K | V] gradients; dQ; out_proj gradients; emotion value projection backward =================
     pg.gemm(NN(dKV, 2 * d, inw + d * d, d, dY, d, R, d, 2 * d), 1);
