@@ -299,11 +299,11 @@ int km_train_init(km_handle h, int64_t max_windows, void* stream) {
     {   // phased step (km_trainp.hip): packed input first, then a fixed part, then per-window activations; dropout masks
         int64_t fixed = 0;
         const int64_t per = trainp_act_floats(c, &fixed);
-        const int64_t KP = (c->KT + 15) / 16 * 16;
+        const int64_t KP = trainp_kp(c);
         c->trp_act_floats = max_windows * (per + KP * c->NK) + fixed + 4096;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_act), (size_t)c->trp_act_floats * sizeof(float)));
         // split-K partials: up to 16 partial outputs of every weight / bias gradient that is a product over the rows of the batch
-        c->trp_split_floats = 16 * (5 * (int64_t)c->d * c->d + 2 * (int64_t)c->DH * c->d + 16 * (int64_t)c->d) + 1024;
+        c->trp_split_floats = 16 * (5 * (int64_t)c->d * c->d + 2 * (int64_t)c->DH * c->d + 16 * (int64_t)c->d + (int64_t)c->d * c->KT) + 1024;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_split), (size_t)c->trp_split_floats * sizeof(float)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_tail_part), (size_t)32 * 64 * sizeof(float)));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_tail_ctr), sizeof(unsigned)));

@@ -221,6 +221,7 @@ int train_adamw(Context* c, const float* flat_grad, float lr, float b1, float b2
 
 // km_trainp.hip
 int64_t trainp_act_floats(Context* c, int64_t* fixed);
+int64_t trainp_kp(Context* c);
 int64_t trainp_mask_alloc_bytes(Context* c);
 int trainp_mask_sizes(Context* c, int64_t B, int64_t* mel, int64_t* emo, int64_t* dec);
 int trainp_copy_masks(Context* c, int64_t B, unsigned char* mel, unsigned char* emo, unsigned char* dec, int to_device, void* stream);

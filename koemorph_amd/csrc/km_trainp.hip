@@ -47,7 +47,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---- operations of a phase ------------------------------------------------------------------------------------
 enum OpKind : int {
     OP_GEMM = 0, OP_ZERO, OP_FILL, OP_MASKGEN, OP_PACKX, OP_LOGPACK, OP_LN_FWD, OP_LN_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_RELU_OUTER, OP_REDUCE,
-    OP_EMO_EXPAND, OP_EMO_REDUCE, OP_REDUCE4
+    OP_EMO_EXPAND, OP_EMO_REDUCE, OP_REDUCE4, OP_PADROWS
 };
 
 struct ElemArgs {
@@ -431,8 +431,9 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
         else for (int k = 0; i4 * 4 + k < a.n0; ++k) a.mask_out[i4 * 4 + k] = k4[k];
         break;
     }
-    case OP_PACKX: {        // xp (B, KP, NK) <- mel (B, t_in, NK) rows [0, tv), zeros to T, 3 short rows, zeros to KP
-        const int64_t i = (int64_t)vb * 256 + tid;           // one float4 each
+    case OP_PACKX: {        // xt (B, NK, KP) <- mel (B, t_in, NK) rows [0, tv), zeros to T, 3 short rows, zeros to KP -- TRANSPOSED:
+        // channel rows of KP frames (see train_forward_backward_phased: both products that read it then run on the LDS-DMA tile)
+        const int64_t i = (int64_t)vb * 256 + tid;           // one float4 of channels each
         const int nk4 = a.i0 / 4, KP = a.i1, T = a.i2, t_in = a.i3;
         if (i >= a.n0 * KP * nk4) break;
         const int64_t row = i / nk4; const int c4 = (int)(i - row * nk4);
@@ -441,11 +442,12 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t < tv) v = reinterpret_cast<const float4*>(a.p0 + (b * t_in + t) * a.i0)[c4];
         else if (t >= T && t < T + 3) v = reinterpret_cast<const float4*>(a.p1 + (b * 3 + (t - T)) * a.i0)[c4];
-        reinterpret_cast<float4*>(a.q0)[i] = v;
+        float* o = a.q0 + (b * a.i0 + 4 * c4) * KP + t;
+        o[0] = v.x; o[KP] = v.y; o[2 * KP] = v.z; o[3 * KP] = v.w;
         break;
     }
-    case OP_LOGPACK: {      // xp (B, KP, NK) <- the front end's power-mel (B, F, NK) + window maxima: dB / log conversion and row
-        // packing (T long rows, the last 3 frames, zero rows) -- mel_log_packed_kernel as an op of phase 0, one launch less
+    case OP_LOGPACK: {      // xt (B, NK, KP) <- the front end's power-mel (B, F, NK) + window maxima: dB / log conversion and row
+        // packing (T long frames, the last 3 frames, zeros to KP) -- mel_log_packed_kernel as an op of phase 0, one launch less
         const int64_t i = (int64_t)vb * 256 + tid;           // one value each, as the stand-alone kernel (same log_one())
         const int NKk = a.i0, KP = a.i1, T = a.i2, F = a.i3;
         if (i >= a.n0 * KP * NKk) break;
@@ -459,7 +461,14 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
             const int q = r - T;
             if (F >= 3) f = F - 3 + q; else if (q < F) f = q;
         }
-        a.q0[i] = f >= 0 ? log_one(a.lp, a.p0[(b * F + f) * NKk + m], ref_db, floor_db) : 0.f;
+        a.q0[(b * NKk + m) * KP + r] = f >= 0 ? log_one(a.lp, a.p0[(b * F + f) * NKk + m], ref_db, floor_db) : 0.f;
+        break;
+    }
+    case OP_PADROWS: {      // q0 (n0 rows x i1) <- p0 (n0 rows x i0), zeros beyond column i0: the channel encoder weight with rows of KP
+        const int64_t i = (int64_t)vb * 256 + tid;
+        if (i >= a.n0 * a.i1) break;
+        const int64_t r = i / a.i1; const int t = (int)(i - r * a.i1);
+        a.q0[i] = t < a.i0 ? a.p0[r * a.i0 + t] : 0.f;
         break;
     }
     case OP_LN_FWD: {       // y = LayerNorm(x), statistics saved; one wave per row
@@ -827,16 +836,19 @@ static int split_rows(int64_t rows) {
     return S < 1 ? 1 : (S > 32 ? 32 : S);
 }
 
+// frames per channel row of the packed encoder input: T + 3 rounded up to the LDS-DMA tile's k step (zeros beyond T + 3)
+int64_t trainp_kp(Context* c) { return (c->KT + 31) / 32 * 32; }
+
 int64_t trainp_mask_bytes(Context* c) { return (int64_t)c->H * 28 * c->NK + (int64_t)c->H * 24 + 52 * (int64_t)c->DH; }
 
 // floats per window + a fixed part (returned through *fixed)
 int64_t trainp_act_floats(Context* c, int64_t* fixed) {
-    const int64_t d = c->d, H = c->H, NKk = c->NK, DH = c->DH, KP = (c->KT + 15) / 16 * 16;
+    const int64_t d = c->d, H = c->H, NKk = c->NK, DH = c->DH, KP = trainp_kp(c);
     const int64_t per = KP * NKk + 2 * NKk * d + 2 * NKk + 2 * NKk * d /* KV */ + 3 * H * 28 * NKk /* P, Pd, dP */ + H * 28 * NKk /* dS */ +
                         3 * 28 * d + 28 * DH + 3 * 24 * d + 24 * DH + 64 /* z */ + (28 + 24) * DH /* dH */ + 6 * (28 + 24) * d / 2 /* dA dO2 dO1 x2 */ +
                         2 * NKk * d /* dKV */ + 2 * NKk * d /* dY dY0 */ + 8 * d + 8 + 5 * 52 + 4 + d * c->KT /* dWce partial */ + 28 * d /* dQ partial */ +
                         (trainp_mask_bytes(c) + 3) / 4 + 64;
-    if (fixed) *fixed = 2 * 28 * d + 2 * d * d + 2 * DH * d + 2 * d + 2 * DH + 64 /* folds */ + 32 * (4 * d + 2 * DH + 4 * d) /* split partials */ + 1024;
+    if (fixed) *fixed = 2 * 28 * d + 2 * d * d + 2 * DH * d + 2 * d + 2 * DH + 64 /* folds */ + d * KP /* channel encoder weight, rows of KP */ + 32 * (4 * d + 2 * DH + 4 * d) /* split partials */ + 1024;
     return per;
 }
 
@@ -888,7 +900,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
                                   float* out_dev, float* ema_state, int ema_first, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int64_t d = c->d, H = c->H, hd = c->hd, T = c->T, KT = c->KT, DH = c->DH, NKk = c->NK, ED = c->ED;
-    const int64_t KP = (KT + 15) / 16 * 16;
+    const int64_t KP = trainp_kp(c);
     const int64_t R = B * NKk, Rm = B * 28, Re = B * 24;
     if (NKk % 4 != 0 || NKk > 16 * kAttnMaxKT)
         return fail(KM_ERR_UNSUPPORTED, "phased training step needs num_mel_channels <= %d, a multiple of 4 (got %lld)", 16 * kAttnMaxKT, (long long)NKk);
@@ -903,6 +915,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     float* T1m = take(d * d); float* T1e = take(d * d); float* Wfm = take(DH * d); float* Wfe = take(DH * d);
     float* t1m = take(d); float* t1e = take(d); float* bfm = take(DH); float* bfe = take(DH);
     float* ones = take(c->tr_windows * NKk);
+    float* WceP = take(d * KP);                             // channel encoder weight with rows padded to KP (zeros), rebuilt every step
     // per-window part
     float* Y0 = take(R * d); float* Y = take(R * d); float* mu = take(R); float* rs = take(R);
     float* KV = take(R * 2 * d);
@@ -917,7 +930,6 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     float* E0 = take(B * d); float* E = take(B * d); float* Ve = take(B * d); float* dVe = take(B * d); float* dE = take(B * d); float* dE0 = take(B * d);
     float* emu = take(B); float* ers = take(B);
     float* bs = take(B * 52); float* outb = take(B * 52); float* dz = take(B * 52); float* tfac = take(B * 52); float* txp = take(B * 52);
-    float* dWce_part = take(B * d * KT);
     float* dQ_part = take(B * 28 * d);
     if ((w - c->trp_act) > c->trp_act_floats) return fail(KM_ERR_WORKSPACE, "phased training workspace too small (internal)");
 
@@ -989,6 +1001,9 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         ElemArgs f{};
         f.q0 = ones; f.n0 = R; f.f0 = 1.0f;
         pg.elem(OP_FILL, f, blocks256(R));
+        ElemArgs w{};
+        w.p0 = Wce; w.q0 = WceP; w.n0 = d; w.i0 = (int)KT; w.i1 = (int)KP;
+        pg.elem(OP_PADROWS, w, blocks256(d * KP));
     }
     if (drop && c->tr_dropout_mode == 0) {
         int64_t nm, ne, nd;
@@ -1020,9 +1035,11 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         pg.elem(OP_ZERO, z, (c->ws_windows + 1023) / 1024);
         c->melmax_dirty = false;
     }
-    {   // Y0[b] (NK x d) = X_b^T Wce^T + b over the KT packed rows
-        GemmArgs g = G(X, 1, NKk, Wce, 1, KT, Y0, d, NKk, d, KT);
-        g.a_bs1 = KP * NKk; g.c_bs1 = NKk * d; g.bias = P("mel_channel_encoder.bias"); g.bias_mode = 1;
+    {   // Y0[b] (NK x d) = XT_b (NK x KP) WceP^T + b: both operands k-contiguous with K = KP a multiple of 32 (zeros beyond KT on
+        // both sides): the LDS-DMA tile.  Round 3 read X (B, KP, NK) as a row-contiguous operand against Wce's rows of 259
+        // floats on the register tile (scalar loads): 12 us of the 8-window step
+        GemmArgs g = NT(X, KP, WceP, KP, Y0, d, NKk, d, P("mel_channel_encoder.bias"), 0);
+        g.a_bs1 = KP * NKk; g.c_bs1 = NKk * d;
         pg.gemm(g, (int)B);
     }
     pg.gemm(NT(P("mouth_queries"), d, inw, d, Qb, d, 28, d, inb, 0), 1);                                  // Q = mq Wq^T + bq
@@ -1084,10 +1101,10 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         t.d_b2 = Gd("blendshape_decoder.3.bias"); t.drop_ctr = (drop && c->tr_dropout_mode == 0) ? c->trp_drop_ctr : nullptr;
         t.part = c->trp_tail_part; t.ctr = c->trp_tail_ctr;
         t.dh1 = dH1; t.dhe = dHe; t.keep_scale = keep_scale;
-        // one workgroup per two windows (the 8-window step: four, 231.7 us against 240 with one), at most 32; the audio-visual term
-        // couples the whole batch: one
+        // one workgroup per window, at most 32 (round 4, with the hidden layer's gradient in the tail: 8 workgroups 0.1628 ms per
+        // 8-window step, 4: 0.1653, 2: 0.1717); the audio-visual term couples the whole batch: one
         const bool av = c->tr_loss_cfg.perceptual_weight > 0.f && c->tr_loss_cfg.audio_energy_dev;
-        int groups = av ? 1 : (int)((B + 1) / 2);
+        int groups = av ? 1 : (int)B;
         if (c->opt.train_tail_groups > 0 && !av) groups = c->opt.train_tail_groups;
         groups = groups < 1 ? 1 : (groups > 32 ? 32 : groups);
         hipLaunchKernelGGL(trainp_tail_kernel, dim3((unsigned)groups), dim3(1024), 0, st, t);
@@ -1164,19 +1181,11 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     // everything but the "late" group of the bucket (km_train_init) is final: a side stream may start its all-reduce
     HIP_TRY(hipEventRecord((hipEvent_t)c->tr_ev[0], st));
     c->tr_early_recorded = true;
-    // ================= P12: channel encoder gradients (per-window partials); LayerNorm parameters; emotion encoder =================
-    // dWce = sum_b dY0_b^T X_b: `parts` partial sums over groups of B / parts consecutive windows (contraction batch), summed
-    // by P13; parts == 1 writes the gradient itself and P13 has nothing to do
-    int parts = 1;                                       // contraction chains of about 640 rows (8 windows): 8 windows -> 1 (0.2282 ms
-    for (int q = 1; q <= 16 && q <= B / 8; ++q) if (B % q == 0) parts = q;     // against 0.2313 with 8 partial sums and a summing phase)
-    if (c->opt.train_dwce_parts > 0 && B % c->opt.train_dwce_parts == 0) parts = c->opt.train_dwce_parts;
-    {
-        const int64_t gsz = B / parts;
-        GemmArgs g = G(dY0, 1, d, X, 1, NKk, parts == 1 ? Gd("mel_channel_encoder.weight") : dWce_part, KT, d, KT, NKk);
-        g.kb_count = (int)gsz; g.a_kbs = NKk * d; g.b_kbs = KP * NKk;
-        g.a_bs1 = gsz * NKk * d; g.b_bs1 = gsz * KP * NKk; g.c_bs1 = d * KT;
-        pg.gemm(g, parts);
-    }
+    // ================= P12: channel encoder gradients; LayerNorm parameters; emotion encoder =================
+    // dWce (d x KT) = dY0^T XT over ALL rows (window, channel) of the batch: with the transposed input it is ONE product with a
+    // uniform k stride (round 3: a contraction batch over the windows on the register tile, 19 us at 8 windows); split along K
+    // like every other gradient product when the batch is large (partials summed by P13)
+    pg.gemm(TN(dY0, d, X, KP, Gd("mel_channel_encoder.weight"), KT, d, KT, R), 1);
     colsum(dY0, R, d, d, Gd("mel_channel_encoder.bias"), 0, ones);
     colsum(Tm, R, d, d, Gd("mel_norm.weight"), 0, ones);
     colsum(dY, R, d, d, Gd("mel_norm.bias"), 0, ones);
@@ -1185,10 +1194,8 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     pg.gemm(TN(dE0, d, emo, ED, Gd("emotion_encoder.weight"), ED, d, ED, B), 1);
     colsum(dE0, B, d, d, Gd("emotion_encoder.bias"), 0, ones);
     RUN(pg.end_phase(st));
-    // ================= P13: sum the per-window partials of the channel encoder weight =================
-    if (parts > 1) reduce(dWce_part, parts, d * KT, d * KT, Gd("mel_channel_encoder.weight"), 0);
+    // ================= P13: the partial sums of P12's split products (large batches) =================
     RUN(pg.end_phase(st));
-    RUN(pg.end_phase(st));            // (partials of a split product of P13: there is none today)
     return KM_OK;
 }
 
