@@ -164,6 +164,20 @@ __device__ __forceinline__ void attn_fwd_mfma_dev(const ElemArgs& a, int vb, flo
     float* Ss = Vs + NKp * QS;                // [32][SS]  Pd = P keep / (1 - p), rows 28..31 zero
     const float scale = __uint_as_float(a.u0);
     const float* kvb = a.p1 + (int64_t)b * NKk * 2 * d + h * hd;
+    // The dropout bytes of the score elements this lane will own (waves 0 and 1: row 16 wv + 4 g + r, key 16 t + j) are requested
+    // FIRST, with everything else of the block.  Round 3 loaded each byte inside the softmax loop, between the stores of P: a
+    // byte load may alias any store, so the compiler kept program order -- twenty dependent memory round trips per lane made
+    // this block (14 us alone on the chip) the longest operation of the forward pass.
+    unsigned char keepb[4][kAttnMaxKT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < kAttnMaxKT; ++t) {
+            const int row = 16 * (wv & 1) + 4 * g + r, k = 16 * t + j;
+            const int64_t pi = (((int64_t)b * H + h) * 28 + (row < 28 ? row : 27)) * NKk + (k < NKk ? k : 0);
+            keepb[r][t] = 1;
+            if (a.mask) keepb[r][t] = a.mask[pi];
+        }
     // Staging: Q (32 rows, 28 real), K and V (NKp rows, NK real) are consecutive [row][QS] images, so a float4 unit of any of
     // them is (row, c4) -> smem + row * QS + 4 c4.  ALL of a thread's loads are issued before its first LDS store: one memory
     // round trip for the block (three dependent ones made the block as slow as its plain-FMA predecessor).  Padding rows load
@@ -226,8 +240,7 @@ __device__ __forceinline__ void attn_fwd_mfma_dev(const ElemArgs& a, int vb, flo
                     const int k = 16 * t + j;
                     const float pv = S[t][r] / sum;
                     const bool live = row < 28 && k < NKk;
-                    const int64_t pi = (((int64_t)b * H + h) * 28 + (row < 28 ? row : 27)) * NKk + (k < NKk ? k : 0);
-                    const float pd = a.mask ? (a.mask[pi] ? pv * a.f0 : 0.f) : pv;
+                    const float pd = a.mask ? (keepb[r][t] ? pv * a.f0 : 0.f) : pv;
                     if (live) a.q0[prow + k] = pv;
                     Ss[row * SS + k] = live ? pd : 0.f;
                 }
@@ -266,6 +279,16 @@ __device__ __forceinline__ void attn_bwd_mfma_dev(const ElemArgs& a, int vb, flo
     const int64_t prow0 = ((int64_t)b * H + h) * 28 * NKk;
     const float* kvb = a.p1 + (int64_t)b * NKk * 2 * d + h * hd;
     const float* gab = a.p3 + (int64_t)b * 28 * d + h * hd;
+    // dropout bytes of the lane's dP elements (waves 0 and 1), requested up front: see attn_fwd_mfma_dev
+    unsigned char keepb[4][kAttnMaxKT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < kAttnMaxKT; ++t) {
+            const int row = 16 * (wv & 1) + 4 * g + r, k = 16 * t + j;
+            keepb[r][t] = 1;
+            if (a.mask) keepb[r][t] = a.mask[prow0 + (int64_t)(row < 28 ? row : 27) * NKk + (k < NKk ? k : 0)];
+        }
     // (rows 28..31: a real row is loaded and a zero selected -- a select between a load and a constant is compiled as a select
     // of ADDRESSES with the constant in scratch memory, which drags the whole kernel argument there)
     // Staging as in the forward block: Q, dA (32 rows each), K, V (NKp rows) are consecutive [row][QS] images; P and
@@ -347,7 +370,7 @@ __device__ __forceinline__ void attn_bwd_mfma_dev(const ElemArgs& a, int vb, flo
                     const int k = 16 * t + j;
                     pv[t] = Ps[row * SS + k];
                     float gv = G[t][r];
-                    if (a.mask) { const unsigned char keep = a.mask[prow0 + (int64_t)(row < 28 ? row : 27) * NKk + (k < NKk ? k : 0)]; gv = (row < 28 && k < NKk && keep) ? gv * a.f0 : 0.f; }
+                    if (a.mask) gv = (row < 28 && k < NKk && keepb[r][t]) ? gv * a.f0 : 0.f;
                     G[t][r] = gv;
                     sacc += gv * pv[t];
                 }
@@ -558,11 +581,17 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
         const int d = a.i0, hd = a.i1, H = d / hd;
         if (i >= a.n0 * d) break;
         const int64_t b = i / d; const int cidx = (int)(i - b * d);
-        float s = 0.f;
-        for (int q = 0; q < 24; ++q) {
-            const float g = a.p0[(b * 24 + q) * d + cidx];
-            s += a.mask ? (a.mask[(b * H + cidx / hd) * 24 + q] ? g * a.f0 : 0.f) : g;
+        float gq[24];
+        unsigned char kq[24];
+#pragma unroll
+        for (int q = 0; q < 24; ++q) { gq[q] = a.p0[(b * 24 + q) * d + cidx]; kq[q] = 1; }
+        if (a.mask) {
+#pragma unroll
+            for (int q = 0; q < 24; ++q) kq[q] = a.mask[(b * H + cidx / hd) * 24 + q];
         }
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 24; ++q) s += a.mask ? (kq[q] ? gq[q] * a.f0 : 0.f) : gq[q];      // the same order as the loop it replaces
         a.q0[i] = s;
         break;
     }
@@ -987,42 +1016,23 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     unsigned scale_bits;
     std::memcpy(&scale_bits, &scale, sizeof(scale_bits));
 
-    // ================= P0: clean bucket, ones, masks, packed input (element-wise only: 5 us instead of 15) =================
-    {
+    // ================= P0: what the channel encoder waits for and nothing else: packed input, padded weight =================
+    // (the gradient bucket, the ones vector and the dropout masks are first read in P4 / P8: they are made in P2, beside the
+    // LayerNorm, where they cost nothing -- P0 7.6 -> 4.7 us at 8 windows)
+    if (asrc) {                                // from audio: the power-mel of the front end -> packed log-mel rows (read by P1)
         ElemArgs e{};
-        e.q0 = flat_grad; e.n0 = c->tr_nparams;
-        pg.elem(OP_ZERO, e, (c->tr_nparams + 1023) / 1024);
-        if (asrc) {                            // from audio: the power-mel of the front end -> packed log-mel rows (read by P1)
-            ElemArgs e{};
-            e.p0 = asrc->melpow; e.p1 = reinterpret_cast<const float*>(asrc->melmax); e.q0 = const_cast<float*>(xp_dev); e.n0 = B;
-            e.i0 = (int)NKk; e.i1 = (int)KP; e.i2 = (int)T; e.i3 = asrc->n_frames; e.lp = *asrc->lp;
-            pg.elem(OP_LOGPACK, e, blocks256(B * KP * NKk));
-        }
-        ElemArgs f{};
-        f.q0 = ones; f.n0 = R; f.f0 = 1.0f;
-        pg.elem(OP_FILL, f, blocks256(R));
-        ElemArgs w{};
-        w.p0 = Wce; w.q0 = WceP; w.n0 = d; w.i0 = (int)KT; w.i1 = (int)KP;
-        pg.elem(OP_PADROWS, w, blocks256(d * KP));
-    }
-    if (drop && c->tr_dropout_mode == 0) {
-        int64_t nm, ne, nd;
-        trainp_mask_sizes(c, B, &nm, &ne, &nd);
-        const double t32 = (double)p_drop * 4294967296.0;
-        const unsigned thr = (unsigned)(t32 > 4294967295.0 ? 4294967295.0 : t32);
-        unsigned char* regions[3] = {ms.mel, ms.emo, ms.dec};
-        const int64_t sizes[3] = {nm, ne, nd};
-        for (int r = 0; r < 3; ++r) {
-            ElemArgs e{};
-            e.mask_out = regions[r]; e.n0 = sizes[r]; e.i0 = r; e.i1 = (int)thr; e.u0 = (unsigned)c->tr_dropout_seed;
-            e.u1 = (unsigned)(c->tr_dropout_seed >> 32); e.p0 = reinterpret_cast<const float*>(c->trp_drop_ctr);
-            pg.elem(OP_MASKGEN, e, (sizes[r] + 1023) / 1024);
-        }
-    }
-    if (!xp_dev) {
+        e.p0 = asrc->melpow; e.p1 = reinterpret_cast<const float*>(asrc->melmax); e.q0 = const_cast<float*>(xp_dev); e.n0 = B;
+        e.i0 = (int)NKk; e.i1 = (int)KP; e.i2 = (int)T; e.i3 = asrc->n_frames; e.lp = *asrc->lp;
+        pg.elem(OP_LOGPACK, e, blocks256(B * KP * NKk));
+    } else {
         ElemArgs e{};
         e.p0 = mel; e.p1 = mel_short; e.q0 = xp; e.n0 = B; e.i0 = (int)NKk; e.i1 = (int)KP; e.i2 = (int)T; e.i3 = (int)T_in;
         pg.elem(OP_PACKX, e, blocks256(B * KP * (NKk / 4)));
+    }
+    {
+        ElemArgs w{};
+        w.p0 = Wce; w.q0 = WceP; w.n0 = d; w.i0 = (int)KT; w.i1 = (int)KP;
+        pg.elem(OP_PADROWS, w, blocks256(d * KP));
     }
     const float* X = xp_dev ? xp_dev : xp;
     RUN(pg.end_phase(st));
@@ -1049,7 +1059,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     { GemmArgs g = G(Weo, d, 1, boe, 1, 0, t1e, 1, d, 1, d); g.bias = beo; g.bias_mode = 2; pg.gemm(g, 1); }
     pg.gemm(NT(emo, ED, P("emotion_encoder.weight"), ED, E0, d, B, d, P("emotion_encoder.bias"), 0), 1);
     RUN(pg.end_phase(st));
-    // ================= P2: LayerNorm (both streams); folds Wf = W1 T1 =================
+    // ================= P2: LayerNorm (both streams); folds Wf = W1 T1; clean bucket, ones, dropout masks =================
     {
         ElemArgs e{};
         e.p0 = Y0; e.q0 = Y; e.n0 = R; e.i0 = (int)d; e.p1 = P("mel_norm.weight"); e.p2 = P("mel_norm.bias"); e.q1 = mu; e.q2 = rs;
@@ -1064,6 +1074,29 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     pg.gemm(NN(W1, d, T1e, d, Wfe, d, DH, d, d), 1);
     { GemmArgs g = G(W1, d, 1, t1m, 1, 0, bfm, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }     // bf = W1 t1 + b1
     { GemmArgs g = G(W1, d, 1, t1e, 1, 0, bfe, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }
+    // (behind the phase's own work in dispatch order: workgroups are handed out in operation order)
+    {
+        ElemArgs e{};
+        e.q0 = flat_grad; e.n0 = c->tr_nparams;
+        pg.elem(OP_ZERO, e, (c->tr_nparams + 1023) / 1024);
+        ElemArgs f{};
+        f.q0 = ones; f.n0 = R; f.f0 = 1.0f;
+        pg.elem(OP_FILL, f, blocks256(R));
+    }
+    if (drop && c->tr_dropout_mode == 0) {
+        int64_t nm, ne, nd;
+        trainp_mask_sizes(c, B, &nm, &ne, &nd);
+        const double t32 = (double)p_drop * 4294967296.0;
+        const unsigned thr = (unsigned)(t32 > 4294967295.0 ? 4294967295.0 : t32);
+        unsigned char* regions[3] = {ms.mel, ms.emo, ms.dec};
+        const int64_t sizes[3] = {nm, ne, nd};
+        for (int r = 0; r < 3; ++r) {
+            ElemArgs e{};
+            e.mask_out = regions[r]; e.n0 = sizes[r]; e.i0 = r; e.i1 = (int)thr; e.u0 = (unsigned)c->tr_dropout_seed;
+            e.u1 = (unsigned)(c->tr_dropout_seed >> 32); e.p0 = reinterpret_cast<const float*>(c->trp_drop_ctr);
+            pg.elem(OP_MASKGEN, e, (sizes[r] + 1023) / 1024);
+        }
+    }
     RUN(pg.end_phase(st));
     // ================= P3: [K | V]; emotion value projection =================
     pg.gemm(NT(Y, d, inw + d * d, d, KV, 2 * d, R, 2 * d, inb + d, 0), 1);
