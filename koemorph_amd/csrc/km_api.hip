@@ -559,6 +559,14 @@ int km_legacy_forward(km_handle h, const float* audio_dev, int64_t B, int64_t L,
     if (B > c->ws_windows || n_frames > c->ws_frames || !c->ws_generic)
         return fail(KM_ERR_WORKSPACE, "workspace too small for %lld windows x %lld samples: call km_reserve",
                     (long long)B, (long long)L);
+    if (legacy_pow_ok(c)) {
+        // front end -> power-mel + window maxima; the fused encoder converts to dB while it stages its rows and the attention
+        // kernel re-zeroes the maxima: no mel_log_kernel launch, no memset (round 4; 18 us of the 460 per 256 windows)
+        if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, L, stream)) return rc;
+        const LogParams lp = plan_log_params(c->mel_plans[0]);
+        const LegacyPowSrc src{c->ws_melpow, c->ws_melmax, &lp};
+        return launch_legacy(c, nullptr, B, n_frames, out_dev, stream, &src);
+    }
     if (int rc = launch_mel(c, c->mel_plans[0], audio_dev, B, L, 0, c->ws_mel, nullptr, stream)) return rc;
     return launch_legacy(c, c->ws_mel, B, n_frames, out_dev, stream);
 }

@@ -242,7 +242,9 @@ int finalize_host_koemorph(Context* c);
 int64_t koemorph_ws_floats(Context* c, int64_t T);
 int launch_koemorph(Context* c, const float* mel, const float* emo, int64_t B, int64_t T, const unsigned char* kvalid, const float* prev,
                     float* state, int apply_constraints, float* out, float* raw, float* attn, void* stream);
-int launch_legacy(Context* c, const float* mel, int64_t B, int64_t T_mel, float* out, void* stream);
+struct LegacyPowSrc { const float* melpow; unsigned* melmax; const LogParams* lp; };      // the front end's power-mel as the legacy model's input
+bool legacy_pow_ok(Context* c);
+int launch_legacy(Context* c, const float* mel, int64_t B, int64_t T_mel, float* out, void* stream, const LegacyPowSrc* pow_src = nullptr);
 int launch_gather_clip_logits(Context* c, const float* zclip, float* zwin, int64_t nw, int64_t w0, int wins_per_clip, void* stream);
 int launch_core_generic_packed(Context* c, const float* xp, int64_t B, const float* zemo, float* out, float* raw, float* attn,
                                void* stream);

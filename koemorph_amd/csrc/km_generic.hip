@@ -762,12 +762,15 @@ static GemmArgs lin(const float* A, int64_t a_rs, const float* W, int K, float* 
 // x 8 heads x 257 keys.  O (B, 52, d): O^T tiles leave as 16-byte stores.
 __global__ __launch_bounds__(256) void legacy_attention_kernel(const float* __restrict__ Qs, const float* __restrict__ Kp,
                                                               const float* __restrict__ Vp, float* __restrict__ O, int64_t BH, int Tm,
-                                                              int H, int NQ) {
+                                                              int H, int NQ, unsigned* __restrict__ zero_max) {
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int64_t bh = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (bh >= BH) return;                       // wave-uniform; no barrier below
     const int64_t b = bh / H;
     const int h = (int)(bh - b * H), d = 32 * H;
+    // the window maxima of the front end were consumed by the launch before this one (the encoder with the fused dB conversion):
+    // clean slots for the next front-end launch, no memset on the step path
+    if (zero_max && h == 0 && lane == 0) zero_max[b] = 0u;
     float qT[2][4][4];                          // [dim tile][query tile][reg]: Q^T[16 dt + 4 g + s][16 qt + j]
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -859,10 +862,17 @@ __global__ __launch_bounds__(256) void legacy_attention_kernel(const float* __re
     }
 }
 
-int launch_legacy_encoder_fused(Context* c, const float* mel, int64_t rows, float* Kp, float* Vp, void* stream);      // km_kmmf.hip
+int launch_legacy_encoder_fused(Context* c, const float* mel, int64_t rows, float* Kp, float* Vp, void* stream, const unsigned* melmax,
+                                int Tm, const LogParams* lp);      // km_kmmf.hip
 int launch_legacy_tail_fused(Context* c, const float* O, int64_t B, float* out, void* stream);
 
-int launch_legacy(Context* c, const float* mel, int64_t B, int64_t Tm, float* out, void* stream) {
+// pow_src != null: `mel` is ignored, the fused encoder reads the front end's power-mel + window maxima and converts on the fly
+// (the caller has checked legacy_pow_ok); the attention kernel then puts the maxima back to zero
+bool legacy_pow_ok(Context* c) {
+    return c->legacy_fused && !c->opt.legacy_no_enc_fusion && !c->opt.legacy_no_attn_fusion && c->hd == 32 && c->NB <= 64 &&
+           (reinterpret_cast<uintptr_t>(c->ws_melpow) & 15) == 0;
+}
+int launch_legacy(Context* c, const float* mel, int64_t B, int64_t Tm, float* out, void* stream, const LegacyPowSrc* pow_src) {
     const int d = c->d, H = c->H, hd = c->hd, NQ = c->NB, hid = c->legacy_hidden, NKk = c->NK;
     float* E1 = c->ws_generic;
     float* E = E1 + B * Tm * d;
@@ -874,9 +884,13 @@ int launch_legacy(Context* c, const float* mel, int64_t B, int64_t Tm, float* ou
     float* D1 = A1 + B * NQ * d;
     float* D2 = D1 + B * NQ * hid;
     float* D3 = D2 + B * NQ * hid;
-    if (c->legacy_fused && !c->opt.legacy_no_enc_fusion && (reinterpret_cast<uintptr_t>(mel) & 15) == 0) {
+    unsigned* zero_max = nullptr;
+    if (pow_src) {
+        if (int rc = launch_legacy_encoder_fused(c, pow_src->melpow, B * Tm, Kp, Vp, stream, pow_src->melmax, (int)Tm, pow_src->lp)) return rc;
+        zero_max = pow_src->melmax;
+    } else if (c->legacy_fused && !c->opt.legacy_no_enc_fusion && (reinterpret_cast<uintptr_t>(mel) & 15) == 0) {
         // audio_encoder + key / value projections with the hidden activations resident in LDS (km_kmmf.hip)
-        if (int rc = launch_legacy_encoder_fused(c, mel, B * Tm, Kp, Vp, stream)) return rc;
+        if (int rc = launch_legacy_encoder_fused(c, mel, B * Tm, Kp, Vp, stream, nullptr, (int)Tm, nullptr)) return rc;
     } else {
     // audio_encoder: Linear(80,d) ReLU [Dropout] Linear(d,d) ReLU [Dropout]   (:44-51, :129)
     if (int rc = launch_gemm(lin(mel, NKk, dv(c, "l_w0"), NKk, E1, B * Tm, d, dv(c, "l_b0"), 1), 1, stream)) return rc;
@@ -887,7 +901,7 @@ int launch_legacy(Context* c, const float* mel, int64_t B, int64_t Tm, float* ou
     }
     if (hd == 32 && NQ <= 64 && !c->opt.legacy_no_attn_fusion) {
         hipLaunchKernelGGL(legacy_attention_kernel, dim3((unsigned)((B * H + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dv(c, "l_q"), Kp, Vp, O,
-                           B * H, (int)Tm, H, NQ);
+                           B * H, (int)Tm, H, NQ, zero_max);
         HIP_TRY(hipGetLastError());
     } else {
     GemmArgs g{};

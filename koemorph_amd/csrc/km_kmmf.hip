@@ -24,6 +24,7 @@
 #include <string>
 
 #include "km_context.h"
+#include "km_device.h"
 #include "km_gemm.h"
 #include "km_kmmf.h"
 
@@ -99,6 +100,10 @@ __device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 la
 #endif
 #ifndef KM_KMMF_DEC_PIN
 #define KM_KMMF_DEC_PIN 0
+#endif
+#ifndef KM_LEGACY_ENC_PIN
+#define KM_LEGACY_ENC_PIN 1      /* round 4, measured and dropped: weight fragments THREE k blocks ahead (four register sets in turn) in the legacy
+                                   encoder: 0.453 against 0.451 ms per forward -- its waves do not wait for the weights */
 #endif
 template <int MT, int NTW, int PIN>
 __device__ __forceinline__ void mm_cols(f32x4 (&acc)[MT][NTW], const float* X, const float* wp, int t0, int kbs, int kb0, int nkb, int lane) {
@@ -826,8 +831,12 @@ __global__ __launch_bounds__(512) void kmmf_decode_kernel(DecArgs a) {
 // workgroup: the two hidden activations never leave LDS, the four weights are MFMA operands straight from L2 (blob lgf_enc).
 // Replaces four NT GEMM launches over (B Tm, 256) activations.  K, V (rows, 256) row-major for legacy_attention_kernel.
 // ---------------------------------------------------------------------------------------------------------
+// melmax != null: `mel` is the front end's POWER-mel (rows = (window, frame), Tm frames per window) and the dB / log conversion
+// against the window's maximum happens while a tile is staged (the same log_one() as mel_log_kernel: that launch and the
+// memset of the maxima behind it are gone from km_legacy_forward; legacy_attention_kernel, the next launch, re-zeroes them).
 __global__ __launch_bounds__(256) void legacy_encoder_kernel(const float* __restrict__ mel, const float* __restrict__ blob, int64_t rows,
-                                                            float* __restrict__ Kp, float* __restrict__ Vp) {
+                                                            float* __restrict__ Kp, float* __restrict__ Vp,
+                                                            const unsigned* __restrict__ melmax, int Tm, LogParams lp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* A = smem;
     float* Bi = smem + EIMG;
@@ -838,7 +847,15 @@ __global__ __launch_bounds__(256) void legacy_encoder_kernel(const float* __rest
     for (int i = tid; i < EROWS * (LG_MEL / 4); i += ENTH) {
         const int r = i / (LG_MEL / 4), c4 = i - r * (LG_MEL / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r0 + r < rows) v = *reinterpret_cast<const float4*>(mel + (r0 + r) * LG_MEL + 4 * c4);
+        if (r0 + r < rows) {
+            v = *reinterpret_cast<const float4*>(mel + (r0 + r) * LG_MEL + 4 * c4);
+            if (melmax) {
+                float ref_db, floor_db;
+                log_window_consts(lp, __uint_as_float(melmax[(r0 + r) / Tm]), ref_db, floor_db);
+                v = make_float4(log_one(lp, v.x, ref_db, floor_db), log_one(lp, v.y, ref_db, floor_db), log_one(lp, v.z, ref_db, floor_db),
+                                log_one(lp, v.w, ref_db, floor_db));
+            }
+        }
         *reinterpret_cast<float4*>(A + r * XS + 4 * c4) = v;
     }
     __syncthreads();
@@ -848,7 +865,7 @@ __global__ __launch_bounds__(256) void legacy_encoder_kernel(const float* __rest
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0, 0, 0, 0};
-        mm_cols<2, 4, KM_KMMF_ENC_PIN>(acc, src, blob + w_off, 4 * wave, kbs, 0, kbs, lane);
+        mm_cols<2, 4, KM_LEGACY_ENC_PIN>(acc, src, blob + w_off, 4 * wave, kbs, 0, kbs, lane);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const float bb = blob[b_off + col0 + 16 * nt + j];
@@ -871,7 +888,7 @@ __global__ __launch_bounds__(256) void legacy_encoder_kernel(const float* __rest
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0, 0, 0, 0};
-        mm_cols<2, 4, KM_KMMF_ENC_PIN>(acc, A, blob + w_off, 4 * wave, KBD, 0, KBD, lane);
+        mm_cols<2, 4, KM_LEGACY_ENC_PIN>(acc, A, blob + w_off, 4 * wave, KBD, 0, KBD, lane);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const float bb = blob[b_off + col0 + 16 * nt + j];
@@ -1020,13 +1037,14 @@ int launch_kmmf_decode(Context* c, const float* xm, const float* xe, int64_t B, 
 
 
 // SimplifiedKoeMorphModel: K, V (rows, 256) of the attention from the mel rows (rows, 80), one launch
-int launch_legacy_encoder_fused(Context* c, const float* mel, int64_t rows, float* Kp, float* Vp, void* stream) {
+int launch_legacy_encoder_fused(Context* c, const float* mel, int64_t rows, float* Kp, float* Vp, void* stream, const unsigned* melmax,
+                                int Tm, const LogParams* lp) {
     static PerDeviceOnce once;
     if (once.first(c->device))
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kf::legacy_encoder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     2 * kf::EIMG * 4));
     hipLaunchKernelGGL(kf::legacy_encoder_kernel, dim3((unsigned)((rows + kf::EROWS - 1) / kf::EROWS)), dim3(kf::ENTH), 2 * kf::EIMG * 4,
-                       (hipStream_t)stream, mel, dvp(c, "lgf_enc"), rows, Kp, Vp);
+                       (hipStream_t)stream, mel, dvp(c, "lgf_enc"), rows, Kp, Vp, melmax, Tm, lp ? LogParams(*lp) : LogParams{});
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }
