@@ -198,6 +198,13 @@ int km_pipeline_flush(km_handle h, void* stream);
  * per-window evaluation (KM_SEQ_PER_WINDOW=1 selects that for comparison).  This entry point may allocate (grow-only
  * clip-level buffers sized B*L) on first use, so capture it in a hipGraph only after a warm-up call. */
 int64_t km_sequence_num_outputs(km_handle h, int64_t L, int32_t stride_frames);
+/* The temporal smoothing of a whole sequence, in place: x_dev (B, N, 52), y[0] = x[0], y[n] = alpha x[n] + (1 - alpha) y[n - 1]
+ * along the frame axis with alpha = sigmoid(smoothing_alpha) -- what SequentialDualStreamModel.forward's per-position calls of
+ * apply_temporal_smoothing add up to (src/model/sequential_dual_stream_model.py:99-151,
+ * simplified_dual_stream_model.py:341-368).  It is the last step of km_sequence_forward(smooth = 1); exported so that a clip
+ * whose output frames were computed in chunks on several GPUs (km_sequence_forward with smooth = 0 on each chunk, SURVEY.md
+ * section 8e) is smoothed once, over the gathered frames. */
+int km_ema_scan(km_handle h, float* x_dev, int64_t B, int64_t N, void* stream);
 int km_sequence_forward(km_handle h, const float* audio_dev, int64_t B, int64_t L,
                         const float* emotion_dev, int32_t stride_frames, int32_t smooth,
                         float* out_dev, void* stream);

@@ -93,6 +93,7 @@ SIGNATURES = {
     "km_pipeline_flush": (C.c_int, [_h, _p]),
     "km_sequence_num_outputs": (_i64, [_h, _i64, _i32]),
     "km_sequence_forward": (C.c_int, [_h, _p, _i64, _i64, _p, _i32, _i32, _p, _p]),
+    "km_ema_scan": (C.c_int, [_h, _p, _i64, _i64, _p]),
     "km_train_init": (C.c_int, [_h, _i64, _p]),
     "km_train_num_params": (_i64, [_h]),
     "km_train_param_offset": (_i64, [_h, C.c_char_p]),

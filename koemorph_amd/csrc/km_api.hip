@@ -571,6 +571,13 @@ int km_legacy_forward(km_handle h, const float* audio_dev, int64_t B, int64_t L,
     return launch_legacy(c, c->ws_mel, B, n_frames, out_dev, stream);
 }
 
+int km_ema_scan(km_handle h, float* x_dev, int64_t B, int64_t N, void* stream) {
+    if (int rc = need_ready(h)) return rc;
+    if (h->kind != 0) return fail(KM_ERR_INVALID_ARG, "this entry point needs a dual-stream handle (km_create)");
+    if (!x_dev || B <= 0 || N <= 0) return fail(KM_ERR_INVALID_ARG, "km_ema_scan: bad argument");
+    return launch_ema_scan(h, x_dev, B, N, stream);
+}
+
 int km_smooth(km_handle h, float* x_dev, float* state_dev, int64_t B, int32_t first, void* stream) {
     if (int rc = need_ready(h)) return rc;
     if (!x_dev || !state_dev || B <= 0) return fail(KM_ERR_INVALID_ARG, "km_smooth: bad argument");

@@ -327,5 +327,13 @@ class Engine:
                                                 1 if smooth else 0, _ptr(out), _stream_ptr(audio.device)))
         return out
 
+    def ema_scan(self, seq) -> None:
+        """In-place temporal smoothing of (B, N, 52) along the frame axis (km_ema_scan): the last step of sequence_forward,
+        exported for sequences whose frames were computed in chunks (parallel.sequence_apply)."""
+        torch = _torch()
+        seq = self._chk(seq, "seq", 3)
+        with torch.cuda.device(seq.device):
+            check(self._lib.km_ema_scan(self._h, _ptr(seq), seq.shape[0], seq.shape[1], _stream_ptr(seq.device)))
+
     def sequence_num_outputs(self, L: int, stride_frames: int = 1) -> int:
         return int(self._lib.km_sequence_num_outputs(self._h, L, stride_frames))

@@ -76,6 +76,51 @@ def sharded_apply(fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], audi
     return torch.cat([p[: h - l] for p, (l, h) in zip(parts, sizes)], dim=0)
 
 
+def sequence_chunk(L: int, hop: int, window_frames: int, stride_frames: int, n_out: int, rank: int, world: int):
+    """This rank's contiguous chunk [lo, hi) of a clip's ``n_out`` output frames and the sample range [s0, s1) of the clip it
+    needs: window i starts at sample i * stride * hop and spans window_frames * hop samples, so a chunk of n windows reads
+    (n - 1) * stride * hop + window_frames * hop samples -- its own span plus a halo of one window.
+    The last chunk ends with the clip (its windows are zero-padded beyond it exactly as on one GPU)."""
+    lo, hi = shard_range(n_out, rank, world)
+    if hi <= lo:
+        return lo, hi, 0, 0
+    s0 = lo * stride_frames * hop
+    s1 = min(L, s0 + (hi - lo - 1) * stride_frames * hop + window_frames * hop)
+    return lo, hi, s0, s1
+
+
+def sequence_apply(engine, audio: torch.Tensor, emotion: torch.Tensor, stride_frames: int = 1, smooth: bool = True) -> torch.Tensor:
+    """``SequentialDualStreamModel.forward`` of ONE batch of clips over all ranks (reference
+    src/model/sequential_dual_stream_model.py:84-151): every rank holds the clips, computes a contiguous chunk of each clip's
+    output frames WITHOUT smoothing (``engine.sequence_forward`` on the chunk's samples + one window of halo), the chunks are
+    all-gathered in rank order (208 bytes per frame: the only exchange, and it is not on the kernels' path) and the EMA --
+    a first-order recurrence along the frame axis -- runs once over the gathered (B, N, 52).  Every rank returns the full
+    sequence; it is bit-identical to the single-rank result because every window is computed by the same kernels from the same
+    samples whichever sub-clip it is addressed in."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return engine.sequence_forward(audio, emotion, stride_frames, smooth=smooth)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    B, L = audio.shape
+    hop, T = int(engine.mel.hop_length), int(engine.mel_sequence_length)
+    N = int(engine.sequence_num_outputs(L, stride_frames))
+    nb = int(getattr(engine, "num_blendshapes", 52))
+    lo, hi, s0, s1 = sequence_chunk(L, hop, T, stride_frames, N, rank, world)
+    sizes = [shard_range(N, r, world) for r in range(world)]
+    maxn = max(h - l for l, h in sizes)
+    pad = torch.zeros((B, maxn, nb), dtype=torch.float32, device=audio.device)
+    if hi > lo:
+        part = engine.sequence_forward(audio[:, s0:s1].contiguous(), emotion, stride_frames, smooth=False)
+        if part.shape[1] != hi - lo:
+            raise RuntimeError(f"sequence chunk [{lo}, {hi}) of {N} frames came back with {part.shape[1]} frames")
+        pad[:, : hi - lo] = part
+    parts: List[torch.Tensor] = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    seq = torch.cat([p[:, : h - l] for p, (l, h) in zip(parts, sizes)], dim=1).contiguous()
+    if smooth and seq.shape[1] > 0:
+        engine.ema_scan(seq)
+    return seq
+
+
 class DirectAllReduce:
     """Sum of a flat fp32 tensor over the ranks as ONE exchange over every link at once (opt-in: KM_ALLREDUCE=direct).
 

@@ -172,3 +172,48 @@ def test_bench_two_rank_rehearsal():
     for mode in ("ring", "direct"):
         assert col[mode]["ms_per_step"] > 0 and col[mode]["allreduce_ms"] > 0
     assert col["default"] == "ring"
+
+
+def _seq_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch
+    import torch.distributed as dist
+    from koemorph_amd import synth
+    from koemorph_amd.model import SequentialDualStreamModel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    params = synth.make_core_params(5, style="trained")
+    res = {}
+    for stride, L in ((1, 136448 + 533 * 9 + 100), (3, 136448 + 533 * 20)):
+        audio = torch.from_numpy(synth.make_audio(70 + stride, 2, L)).cuda()
+        emo = torch.from_numpy(synth.normal(80 + stride, (2, 256))).cuda()
+        m = SequentialDualStreamModel(stride_frames=stride, shard_across_ranks=True).cuda().eval()
+        sd = {"dual_stream_attention." + k: torch.from_numpy(v) for k, v in params.items()}
+        sd["smoothing_alpha"] = torch.tensor(0.8)
+        m.load_state_dict(sd)
+        sharded = m(audio, emotion_features=emo)["blendshapes"]
+        m.shard_across_ranks = False
+        single = m(audio, emotion_features=emo)["blendshapes"]
+        res[stride] = (tuple(sharded.shape), bool(torch.equal(sharded, single)))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sequence_mode_is_bit_identical_to_one_rank():
+    """SURVEY.md section 8e, sequence mode: each rank computes a contiguous chunk of every clip's output frames (its samples
+    + one window of halo, no smoothing), the chunks are gathered and the EMA runs once -- bit-identical to km_sequence_forward on
+    one rank (10 / 7 output frames over two ranks, stride 1 and 3, a ragged clip end)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seq_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, res in out:
+        assert res[1] == ((2, 10, 52), True), (rank, res)
+        assert res[3] == ((2, 7, 52), True), (rank, res)

@@ -138,3 +138,78 @@ def test_direct_allreduce_world3():
         assert p.exitcode == 0
     assert all(r[1] and r[2] for r in res)
     assert torch.equal(res[0][3], res[1][3]) and torch.equal(res[0][3], res[2][3])
+
+
+# ---- sequence mode across ranks: chunks of a clip's output frames + one window of halo -----------------
+class _FakeMel:
+    hop_length = 10
+
+
+class _FakeSeqEngine:
+    """Host-side stand-in for koemorph_amd.engine.Engine: a window's "blendshapes" are sums over its (zero-padded) samples, the
+    EMA is the real recurrence -- enough to pin chunk ranges, halos, tail padding, gather order and the one smoothing pass."""
+    mel = _FakeMel()
+    mel_sequence_length = 4          # window = 40 samples
+    num_blendshapes = 3
+    alpha = 0.7
+
+    def sequence_num_outputs(self, L, stride):
+        return max(1, (L // 10 - 4) // stride + 1)
+
+    def sequence_forward(self, audio, emo, stride, smooth=True):
+        B, L = audio.shape
+        N = self.sequence_num_outputs(L, stride)
+        out = torch.zeros(B, N, 3)
+        for i in range(N):
+            w = torch.zeros(B, 40)
+            seg = audio[:, i * stride * 10: i * stride * 10 + 40]
+            w[:, : seg.shape[1]] = seg
+            out[:, i] = torch.stack([w.sum(1), (w * torch.arange(40.0)).sum(1), w[:, 0] + emo.sum(1)], dim=1)
+        if smooth:
+            self.ema_scan(out)
+        return out
+
+    def ema_scan(self, seq):
+        for n in range(1, seq.shape[1]):
+            seq[:, n] = self.alpha * seq[:, n] + (1 - self.alpha) * seq[:, n - 1]
+
+
+def _seq_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_from_env("gloo")
+    eng = _FakeSeqEngine()
+    g = torch.Generator().manual_seed(1)
+    ok = True
+    for L, stride in ((40 + 10 * 9, 1), (40 + 10 * 9 + 7, 2), (40 + 10 * 2, 1), (25, 1), (40 + 10 * 30 + 3, 3)):
+        audio = torch.randn(2, L, generator=g)
+        emo = torch.randn(2, 5, generator=g)
+        want = eng.sequence_forward(audio, emo, stride, smooth=True)
+        got = parallel.sequence_apply(eng, audio, emo, stride, smooth=True)
+        ok = ok and torch.equal(got, want)
+        got = parallel.sequence_apply(eng, audio, emo, stride, smooth=False)
+        ok = ok and torch.equal(got, eng.sequence_forward(audio, emo, stride, smooth=False))
+    # the chunks tile the output frames, and a chunk's sample range is its own span + one window of halo, cut at the clip end
+    N = eng.sequence_num_outputs(137, 2)
+    spans = [parallel.sequence_chunk(137, 10, 4, 2, N, r, world) for r in range(world)]
+    ok = ok and spans[0][0] == 0 and spans[-1][1] == N and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    for lo, hi, s0, s1 in spans:
+        if hi > lo:
+            ok = ok and s0 == lo * 20 and s1 == min(137, s0 + (hi - lo - 1) * 20 + 40)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sequence_mode_chunks_over_ranks(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seq_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(r, True) for r in range(world)]
