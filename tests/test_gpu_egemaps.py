@@ -4,7 +4,13 @@ itself (third-party, absent, see the oracle's header) -- and against known answe
 Tolerances: the oracle runs in float64 with numpy's FFT and np.roots, the kernels in float32 with an LDS radix-2 FFT and a
 Durand-Kerner root finder.  Continuous descriptors agree to 1e-3 relative or better; descriptors behind a discrete decision
 (which candidate, where a pitch mark lands) are compared on the frames where the decisions coincide, and the agreement rate
-itself is asserted."""
+itself is asserted.
+
+Agreement thresholds (round 4): tools/egemaps_agreement.py measures, over eight seeds of the speech-like test signal (195
+frames, 135 voiced in both), voicing decisions 100 % equal, all three formants valid in both on 100 % of the voiced frames
+and pitch marks (jitter) equal on 100 % of them.  The assertions below allow ONE OR TWO frames of 195 / 135 to differ (0.99 /
+0.97) -- a frame whose normalised autocorrelation sits within float32 rounding of the 0.55 voicing cutoff, or whose two best
+pitch-mark lags tie, may legitimately fall on either side -- instead of the 2 % / 10 % of rounds 2 - 3."""
 import numpy as np
 import pytest
 import torch
@@ -48,21 +54,21 @@ def test_low_level_descriptors_match_oracle(engine):
     np.testing.assert_allclose(rec[:, R["rms"]], d["rms"], rtol=1e-4, atol=1e-7)
     # pitch: same voicing decision on (almost) every frame, same F0 where both are voiced
     gv, ov = rec[:, R["f0"]] > 0, d["f0"] > 0
-    assert (gv == ov).mean() > 0.98 and ov.sum() > 50
+    assert (gv == ov).mean() >= 0.99 and ov.sum() > 50
     both = gv & ov
     np.testing.assert_allclose(rec[both, R["f0"]], d["f0"][both], rtol=2e-3)
     np.testing.assert_allclose(rec[both, R["voi"]], d["voicing"][both], atol=5e-3)
     # formants (voiced frames): the same roots
     for i in range(3):
         ok = both & (rec[:, R["F"] + i] > 0) & (d["F"][:, i] > 0)
-        assert ok.sum() > 0.9 * both.sum()
+        assert ok.sum() >= 0.97 * both.sum()
         np.testing.assert_allclose(rec[ok, R["F"] + i], d["F"][ok, i], rtol=5e-3, atol=2.0)
         assert np.median(np.abs(rec[ok, R["BW"] + i] - d["BW"][ok, i])) < 2.0
     np.testing.assert_allclose(rec[both, R["hnr"]], d["HNRdBACF"][both], atol=0.2)
     np.testing.assert_allclose(rec[both, R["h1h2"]], d["H1-H2"][both], atol=0.05)
     # jitter / shimmer depend on where the pitch marks land: compare where they agree, and require that to be the rule
     same = both & (np.abs(rec[:, R["jit"]] - d["jitterLocal"]) < 1e-4)
-    assert same.sum() > 0.9 * both.sum()
+    assert same.sum() >= 0.97 * both.sum()
     np.testing.assert_allclose(rec[same, R["shim"]], d["shimmerLocaldB"][same], atol=2e-3)
 
 

@@ -1,5 +1,7 @@
 """eGeMAPSv02 front end throughput: 20 s windows per second on one GPU (synthetic voiced audio), with a per-kernel split
-when run under rocprofv3.   python tools/bench_egemaps.py [windows=64] [reps=20]"""
+when run under rocprofv3.   python tools/bench_egemaps.py [windows=64] [reps=20]
+Per-kernel roofs (HBM fraction of the algorithmic bytes, executed vector work against the vector pipe, LDS busy, wait share):
+tools/prof_egemaps.sh -> profiles/r04_egemaps_roofline.txt."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
