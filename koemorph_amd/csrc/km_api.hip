@@ -305,7 +305,7 @@ int km_train_init(km_handle h, int64_t max_windows, void* stream) {
         // split-K partials: up to 16 partial outputs of every weight / bias gradient that is a product over the rows of the batch
         c->trp_split_floats = 16 * (5 * (int64_t)c->d * c->d + 2 * (int64_t)c->DH * c->d + 16 * (int64_t)c->d + (int64_t)c->d * c->KT) + 1024;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_split), (size_t)c->trp_split_floats * sizeof(float)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_tail_part), (size_t)32 * 64 * sizeof(float)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_tail_part), (size_t)1024 * 64 * sizeof(float)));      // one row of sums per tail workgroup
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_tail_ctr), sizeof(unsigned)));
         HIP_TRY(hipMemsetAsync(c->trp_tail_ctr, 0, sizeof(unsigned), (hipStream_t)stream));
         HIP_TRY(hipMalloc(&c->trp_masks, (size_t)trainp_mask_alloc_bytes(c)));

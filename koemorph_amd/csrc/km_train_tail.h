@@ -365,3 +365,246 @@ __device__ __forceinline__ void train_tail_dev(const TailArgs& a) {
         }
     }
 }
+
+// ---- one window per 256-thread workgroup (the phased step, round 4) ---------------------------------------------------------
+// The same arithmetic as train_tail_dev, term by term and in the same order (the logits' 16-lane sums included), for a
+// workgroup that owns exactly ONE window: its 52 hidden rows are staged in LDS once (they feed the logits AND the hidden layer's
+// gradient), the prediction, the loss gradient and dL/dz stay in registers / LDS from the logits to dH, and every operand the
+// window needs is requested at kernel entry.  train_tail_dev went to memory and back between its passes (logits -> pass A ->
+// pass B -> dH: four dependent round trips and three fences; 17 us per 8-window step for a microsecond of arithmetic).
+// Not for the audio-visual term (it couples the windows of the batch: train_tail_dev with one workgroup).
+__device__ __forceinline__ void train_tail_window_dev(const TailArgs& a, float* smem) {
+    const int tid = threadIdx.x, i = tid & 63, w = tid >> 6;
+    const int G = (int)gridDim.x, b = (int)blockIdx.x, DH = a.DH, dh4 = DH >> 2;
+    float* Hs = smem;                         // [52][DH]  post-ReLU hidden rows of this window (mouth rows 0..27, expression 28..51)
+    float* w2s = Hs + 52 * DH;                // [DH]
+    float* zs = w2s + DH;                     // [64] logits by ROW (mouth slot / 28 + expression slot)
+    float* gs = zs + 64;                      // [64] dL/dz by row
+    float* e_s = gs + 64;                     // [64] prediction error by coefficient (landmark term)
+    float* u_s = e_s + 64;                    // [136]
+    float* tot_s = u_s + 136;                 // [64]
+    int* last_s = reinterpret_cast<int*>(tot_s + 64);
+    auto wsum64 = [](float v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    };
+    auto wmax64 = [](float v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+        return v;
+    };
+    const km_loss_config& lc = a.lc;
+    const int64_t rm = (int64_t)a.B * 28;
+    // ---- everything the window needs, requested up front ----
+    float4 hv[7];                             // 52 dh4 float4 of hidden rows over 256 threads: at most 7 each at DH = 128
+    const int nh4 = 52 * dh4;
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+        const int e = tid + 256 * u, r = e / dh4, m4 = e - r * dh4;
+        hv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < nh4) hv[u] = reinterpret_cast<const float4*>(r < 28 ? a.h1 + ((int64_t)b * 28 + r) * DH : a.he + ((int64_t)b * 24 + (r - 28)) * DH)[m4];
+    }
+    const float w2v = tid < DH ? a.w2[tid] : 0.f;
+    const bool c52 = w == 0 && i < 52;
+    const float mel_w_i = c52 ? a.mel_w[i] : 0.f, emo_w_i = c52 ? a.emo_w[i] : 0.f;
+    const float alpha_raw = a.alpha_p[0], b2v = a.b2[0];
+    const float tgt = c52 ? a.target[(int64_t)b * 52 + i] : 0.f;
+    const bool ema_on = a.ema_state && !a.ema_first;
+    const float prev_state = (c52 && ema_on) ? a.ema_state[(int64_t)b * 52 + i] : 0.f;
+    const bool have_prev = lc.prev_pred_dev && lc.prev_target_dev;
+    const bool t_on = lc.temporal_weight > 0.f && have_prev, v_on = lc.velocity_weight > 0.f && have_prev;
+    const bool lm_on = lc.landmark_weight > 0.f && lc.landmark_w_dev;
+    const bool dsv_on = lc.ds_velocity_weight > 0.f && lc.ds_prev_pred_dev;
+    float pp_t = 0.f, pt_t = 0.f, pp_ds = 0.f;
+    if (c52 && (t_on || v_on)) { pp_t = lc.prev_pred_dev[(int64_t)b * 52 + i]; pt_t = lc.prev_target_dev[(int64_t)b * 52 + i]; }
+    if (c52 && dsv_on) pp_ds = lc.ds_prev_pred_dev[(int64_t)b * 52 + i];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+        const int e = tid + 256 * u;
+        if (e < nh4) reinterpret_cast<float4*>(Hs)[e] = hv[u];
+    }
+    if (tid < DH) w2s[tid] = w2v;
+    __syncthreads();
+    // ---- decoder output layer: z[row] = H[row] . w2 + b2, 16 lanes per row striding the hidden units (train_tail_dev's order) ----
+    {
+        const int sub = tid >> 4, l16 = tid & 15;          // 16 rows per pass
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = 16 * pass + sub;
+            float sacc = 0.f;
+            if (r < 52)
+                for (int k = l16; k < DH; k += 16) sacc = fmaf(Hs[r * DH + k], w2s[k], sacc);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+            if (l16 == 0 && r < 52) zs[r] = sacc + b2v;
+        }
+    }
+    __syncthreads();
+    float loss_acc = 0.f, dws = 0.f, dal = 0.f, db2 = 0.f, wm_i = 0.f, we_i = 0.f;
+    if (w == 0) {
+        // stream weight softmaxes (dual_stream_attention.py:252-253), lane k = coefficient k
+        const float vm = i < 52 ? mel_w_i / a.temperature : -INFINITY, ve = i < 52 ? emo_w_i / a.temperature : -INFINITY;
+        const float mm = wmax64(vm), me = wmax64(ve);
+        const float em = i < 52 ? expf(vm - mm) : 0.f, ee = i < 52 ? expf(ve - me) : 0.f;
+        const float sm = wsum64(em), se = wsum64(ee);
+        wm_i = i < 52 ? em / sm : 0.f; we_i = i < 52 ? ee / se : 0.f;
+        const float wsum_i = 0.5f * wm_i + 0.5f * we_i;
+        const float alpha = 1.0f / (1.0f + expf(-alpha_raw));
+        const float inv_n = 1.0f / (float)(a.B * 52);
+        // ---- pass A: y = EMA(clamp(wsum * sigmoid(z))) ----
+        float y = 0.f, bsig = 0.f, fac = 0.f, xp = 0.f;
+        if (i < 52) {
+            const int slot = tr_mouth_slot(i);
+            const float z = slot >= 0 ? zs[slot] : zs[28 + tr_expr_slot(i)];
+            bsig = 1.0f / (1.0f + expf(-z));
+            const float f = wsum_i * bsig;
+            const float x = fminf(fmaxf(f, 0.f), 1.f);
+            y = x;
+            float dy_dx = 1.f;
+            if (a.ema_state) {
+                if (!a.ema_first) { y = alpha * x + (1.0f - alpha) * prev_state; dy_dx = alpha; xp = x - prev_state; }
+                a.ema_state[(int64_t)b * 52 + i] = y;
+            }
+            a.bs[(int64_t)b * 52 + i] = bsig;
+            a.out[(int64_t)b * 52 + i] = y;
+            if (a.out2) a.out2[(int64_t)b * 52 + i] = y;
+            fac = dy_dx * ((f >= 0.f && f <= 1.f) ? 1.f : 0.f);
+            a.fac[(int64_t)b * 52 + i] = fac;
+            a.xp[(int64_t)b * 52 + i] = xp;
+        }
+        // ---- pass B: loss terms and dL/dy ----
+        float pg = 0.f;
+        if (i < 52) pg = i < 12 ? 1.0f / 12.f : (i < 32 ? 2.0f / 20.f : (i < 44 ? 1.0f / 12.f : 1.5f / 8.f));
+        const float y_left = __shfl_up(y, 1), y_right = __shfl_down(y, 1);
+        float e = 0.f, dy = 0.f;
+        if (i < 52) {
+            e = y - tgt;
+            loss_acc += (a.mse_w * e * e + a.l1_w * fabsf(e)) * inv_n;
+            dy = (a.mse_w * 2.0f * e + a.l1_w * sgnf(e)) * inv_n;
+            if (lc.perceptual_weight > 0.f) {
+                const float wgt = lc.perceptual_weight * pg / (float)a.B;
+                loss_acc += wgt * e * e;
+                dy += wgt * 2.0f * e;
+            }
+            if (t_on || v_on) {
+                const float dd = (y - pp_t) - (tgt - pt_t);
+                if (t_on) { loss_acc += lc.temporal_weight * dd * dd * inv_n; dy += lc.temporal_weight * 2.0f * dd * inv_n; }
+                if (v_on) { loss_acc += lc.velocity_weight * fabsf(dd) * inv_n; dy += lc.velocity_weight * sgnf(dd) * inv_n; }
+            }
+            if (dsv_on) {
+                const float dd = (y - pp_ds) - (tgt - pp_ds);
+                loss_acc += lc.ds_velocity_weight * dd * dd * inv_n;
+                dy += lc.ds_velocity_weight * 2.0f * dd * inv_n;
+            }
+            if (lc.sparsity_weight > 0.f) { loss_acc += lc.sparsity_weight * fabsf(y) * inv_n; dy += lc.sparsity_weight * sgnf(y) * inv_n; }
+            if (lc.smoothness_weight > 0.f) {
+                const float wgt = lc.smoothness_weight / (float)(a.B * 51);
+                if (i > 0) { const float dl = y - y_left; loss_acc += wgt * fabsf(dl); dy += wgt * sgnf(dl); }
+                if (i < 51) { const float dr = y_right - y; dy -= wgt * sgnf(dr); }
+            }
+            e_s[i] = e;
+        }
+        if (lc.ds_separation_weight > 0.f) {
+            const bool mouth = i < 52 && tr_mouth_slot(i) >= 0;
+            const float ms = wsum64(mouth ? y : 0.f), es = wsum64((i < 52 && !mouth) ? y : 0.f);
+            const float diff = ms * (1.0f / 28.0f) - es * (1.0f / 24.0f);
+            const float wgt = lc.ds_separation_weight / (float)a.B;
+            if (i == 0) loss_acc += wgt * fabsf(diff);
+            if (i < 52) dy += wgt * sgnf(diff) * (mouth ? 1.0f / 28.0f : -1.0f / 24.0f);
+        }
+        if (lm_on) {
+            __builtin_amdgcn_wave_barrier();
+            for (int k = i; k < 136; k += 64) {
+                float u = 0.f;
+                for (int jj = 0; jj < 52; ++jj) u += e_s[jj] * lc.landmark_w_dev[k * 52 + jj];
+                u_s[k] = u;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float wgt = lc.landmark_weight / (float)(a.B * 136);
+            if (i < 52) {
+                float gsum = 0.f;
+                for (int k = 0; k < 136; ++k) gsum += u_s[k] * lc.landmark_w_dev[k * 52 + i];
+                dy += wgt * 2.0f * gsum;
+            }
+            if (i == 0) { float q = 0.f; for (int k = 0; k < 136; ++k) q += u_s[k] * u_s[k]; loss_acc += wgt * q; }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (i < 52) {
+            if (ema_on) dal += dy * xp * alpha * (1.0f - alpha);
+            const float df = dy * fac;
+            dws += df * bsig;
+            const float dzv = df * wsum_i * bsig * (1.0f - bsig);
+            a.dz[(int64_t)b * 52 + i] = dzv;
+            db2 += dzv;
+            const int slot = tr_mouth_slot(i);
+            const int row = slot >= 0 ? slot : 28 + tr_expr_slot(i);
+            gs[row] = dzv;
+            if (a.grow) {
+                if (slot >= 0) a.grow[(int64_t)b * 28 + slot] = dzv;
+                else a.grow[rm + (int64_t)b * 24 + tr_expr_slot(i)] = dzv;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the hidden layer's gradient dH[r][m] = dL/dz[r] w2[m] keep_scale [H[r][m] > 0], from the LDS copies ----
+    if (a.dh1) {
+        const float ks = a.keep_scale;
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int e4 = tid + 256 * u;
+            if (e4 < nh4) {
+                const int r = e4 / dh4, m4 = e4 - r * dh4;
+                const float g = gs[r];
+                const float4 h = reinterpret_cast<const float4*>(Hs)[e4], wv = reinterpret_cast<const float4*>(w2s)[m4];
+                float* dp = r < 28 ? a.dh1 + ((int64_t)b * 28 + r) * DH : a.dhe + ((int64_t)b * 24 + (r - 28)) * DH;
+                reinterpret_cast<float4*>(dp)[m4] = make_float4(h.x > 0.f ? g * wv.x * ks : 0.f, h.y > 0.f ? g * wv.y * ks : 0.f,
+                                                                 h.z > 0.f ? g * wv.z * ks : 0.f, h.w > 0.f ? g * wv.w * ks : 0.f);
+            }
+        }
+    }
+    // ---- this window's sums, then all windows': the workgroup that arrives last adds them up in window order ----
+    if (w == 0) {
+        const float loss_wg = wsum64(i < 52 ? loss_acc : 0.f), dal_wg = wsum64(i < 52 ? dal : 0.f), db2_wg = wsum64(i < 52 ? db2 : 0.f);
+        const float mine = i < 52 ? dws : (i == 52 ? loss_wg : (i == 53 ? dal_wg : (i == 54 ? db2_wg : 0.f)));
+        tot_s[i] = mine;
+        if (G > 1) {
+            a.part[(int64_t)b * 64 + i] = mine;
+            __threadfence();
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int last = 1;
+        if (G > 1) {
+            const unsigned arrived = atomicAdd(a.ctr, 1u);
+            last = arrived == (unsigned)G - 1u;
+            if (last) a.ctr[0] = 0u;
+        }
+        *last_s = last;
+    }
+    __syncthreads();
+    if (!*last_s) return;
+    if (w == 0) {
+        float v = tot_s[i];
+        if (G > 1) {
+            __threadfence();
+            v = 0.f;
+            for (int g = 0; g < G; ++g) v += a.part[(int64_t)g * 64 + i];
+        }
+        const float loss_t = __shfl(v, 52), dal_t = __shfl(v, 53), db2_t = __shfl(v, 54);
+        if (i == 0) {
+            a.loss[0] = loss_t;
+            a.d_alpha[0] = dal_t;
+            if (a.d_b2) a.d_b2[0] = db2_t;
+            if (a.drop_ctr) a.drop_ctr[0] += 1;
+        }
+        const float dws_t = i < 52 ? v : 0.f;
+        const float dm = wsum64(i < 52 ? 0.5f * dws_t * wm_i : 0.f), de = wsum64(i < 52 ? 0.5f * dws_t * we_i : 0.f);
+        if (i < 52) {
+            a.d_melw[i] = wm_i * (0.5f * dws_t - dm) / a.temperature;
+            a.d_emow[i] = we_i * (0.5f * dws_t - de) / a.temperature;
+        }
+    }
+}
+__host__ __device__ constexpr int train_tail_window_lds_floats(int DH) { return 52 * DH + DH + 64 * 3 + 136 + 64 + 4; }
