@@ -78,6 +78,7 @@ struct Options {
     int train_no_split = 0;        // 1: no split-K of the long gradient products of the phased training step (A/B)
     int train_dwce_parts = 0;      // > 0: partial sums of the channel-encoder gradient per step (a divisor of the batch; A/B)
     int train_split_min_k = 0;     // > 0: split gradient products longer than this many rows into chains of about this length (A/B; default 1024 / 640)
+    int train_attn_regs = 0;       // 1: the attention blocks of the training program as the register-staged blocks of round 3 (A/B of the LDS-DMA blocks)
     int train_no_dma = 0;          // 1: the products of the training program run on the register-staged tile only (A/B of the LDS-DMA tile, km_gemm_dma_dev.h)
     int train_op_per_launch = 0;   // 1: every operation of the training program is its own launch (timing aid: rocprofv3 then shows each operation)
     int train_bm32_below = 0;      // > 0: products with fewer 64-row tiles than this run on 32-row tiles (A/B; default 192)

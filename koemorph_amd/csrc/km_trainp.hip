@@ -43,6 +43,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #include "km_gemm_dev.h"
 #include "km_gemm_dma_dev.h"
 #include "km_train_tail.h"
+#include "km_train_attn_dev.h"
 
 // ---- operations of a phase ------------------------------------------------------------------------------------
 enum OpKind : int {
@@ -50,23 +51,6 @@ enum OpKind : int {
     OP_EMO_EXPAND, OP_EMO_REDUCE, OP_REDUCE4, OP_PADROWS
 };
 
-struct ElemArgs {
-    const float *p0, *p1, *p2, *p3, *p4;
-    float *q0, *q1, *q2, *q3;
-    const unsigned char* mask;
-    unsigned char* mask_out;
-    int64_t n0, n1;
-    int i0, i1, i2, i3;
-    float f0;
-    unsigned u0, u1;
-    LogParams lp;          // OP_LOGPACK
-    // OP_REDUCE4: up to four reductions out_j[c] (+)= sum_{y < rS[j]} p_j[y * rn[j] + c], c < rn[j] (p0..p3 -> q0..q3); the
-    // partial products of the split-K gradient GEMMs of the phase before
-    // (separate fields, read through select chains: an array indexed at run time would move the whole kernel argument into
-    // scratch memory -- 4 KB per thread and every phase six times slower)
-    int rn0, rn1, rn2, rn3, rS0, rS1, rS2, rS3, racc0, racc1, racc2, racc3;
-};
-static_assert(sizeof(ElemArgs) <= 208, "ElemArgs shares a union with GemmArgs");
 
 struct Op {
     int kind;
@@ -122,305 +106,6 @@ __device__ __forceinline__ void stage_to_lds(int n, Src src, Dst dst) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int i = i0 + 256 * u; if (i < n) dst(i, v[u]); }
     }
-}
-
-// ---- fused attention blocks of the training step, on the matrix pipe ----------------------------------------------------------
-// One (window, head) per 256-thread workgroup; every product is v_mfma_f32_16x16x4_f32 tiles fed from LDS images: the 28
-// query rows are padded to two 16-row tiles (rows 28..31 zero), the keys to ceil(NK / 16) 16-column tiles (80 keys: five;
-// padded keys are zero rows of K / V and get no softmax weight), a head is HD / 16 column tiles.  Operand fetches: lane (g = lane >> 4, j = lane & 15) supplies A[row j][k = 4 s + g] and
-// B[k = 4 s + g][col j] of MFMA step s.  A wave that owns a 16-row tile of scores holds all of its keys (five accumulator
-// tiles), so softmax and its backward are in-lane passes plus a reduction over the 16 lanes of a row.  Rounds 1 - 2 ran these
-// blocks as plain FMA loops reading two LDS values per multiply-add (20 - 28 us for the forward phase, 25 - 50 us for the
-// backward phase at 8 - 64 windows); here the products are a few hundred MFMAs per block and the block is bound by its staging.
-// (Both versions side by side in one kernel pushed the inlined code over a threshold beyond which the compiler copies the
-// 4 KB kernel argument into scratch memory -- every phase five times slower --, so the FMA blocks are gone, not optional.)
-__device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));
-    return v;
-}
-constexpr int kAttnMaxKT = 5;          // key tiles of 16: num_mel_channels <= 80 (with room for 128 the score / gradient tiles of a wave
-                                       // need 240 registers and every phase of the step drops to one wave per SIMD)
-__host__ __device__ constexpr int attn_mfma_lds_floats(int hd, int nk) {
-    // backward: Q, dA [32][hd+4], K, V [nkp][hd+4], P, Pd, dS [32][nkp+4]; nkp = keys padded to 16
-    return 2 * 32 * (hd + 4) + 2 * ((nk + 15) / 16 * 16) * (hd + 4) + 3 * 32 * ((nk + 15) / 16 * 16 + 4);
-}
-__host__ __device__ constexpr int attn_mfma_fwd_lds_floats(int hd, int nk) {
-    // forward: Q [32][hd+4], K, V [nkp][hd+4], Pd [32][nkp+4]
-    return 32 * (hd + 4) + 2 * ((nk + 15) / 16 * 16) * (hd + 4) + 32 * ((nk + 15) / 16 * 16 + 4);
-}
-
-template <int HD>
-__device__ __forceinline__ void attn_fwd_mfma_dev(const ElemArgs& a, int vb, float* smem) {
-    constexpr int hd = HD, QS = hd + 4, CT = hd / 16;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, j = lane & 15;
-    const int d = a.i0, NKk = a.i2, H = a.i3, NKT = (NKk + 15) / 16, NKp = 16 * NKT, SS = NKp + 4;
-    const int b = vb / H, h = vb - b * H;
-    float* Qs = smem;                         // [32][QS], rows 28..31 zero
-    float* Ks = Qs + 32 * QS;                 // [NK][QS]
-    float* Vs = Ks + NKp * QS;                // [NKp][QS], rows >= NK zero
-    float* Ss = Vs + NKp * QS;                // [32][SS]  Pd = P keep / (1 - p), rows 28..31 zero
-    const float scale = __uint_as_float(a.u0);
-    const float* kvb = a.p1 + (int64_t)b * NKk * 2 * d + h * hd;
-    // The dropout bytes of the score elements this lane will own (waves 0 and 1: row 16 wv + 4 g + r, key 16 t + j) are requested
-    // FIRST, with everything else of the block.  Round 3 loaded each byte inside the softmax loop, between the stores of P: a
-    // byte load may alias any store, so the compiler kept program order -- twenty dependent memory round trips per lane made
-    // this block (14 us alone on the chip) the longest operation of the forward pass.
-    unsigned char keepb[4][kAttnMaxKT];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int t = 0; t < kAttnMaxKT; ++t) {
-            const int row = 16 * (wv & 1) + 4 * g + r, k = 16 * t + j;
-            const int64_t pi = (((int64_t)b * H + h) * 28 + (row < 28 ? row : 27)) * NKk + (k < NKk ? k : 0);
-            keepb[r][t] = 1;
-            if (a.mask) keepb[r][t] = a.mask[pi];
-        }
-    // Staging: Q (32 rows, 28 real), K and V (NKp rows, NK real) are consecutive [row][QS] images, so a float4 unit of any of
-    // them is (row, c4) -> smem + row * QS + 4 c4.  ALL of a thread's loads are issued before its first LDS store: one memory
-    // round trip for the block (three dependent ones made the block as slow as its plain-FMA predecessor).  Padding rows load
-    // a real row and store zeros.
-    {
-        constexpr int C4 = hd / 4, MAXU = ((32 + 2 * 16 * kAttnMaxKT) * C4 + 255) / 256;
-        const int total = (32 + 2 * NKp) * C4;
-        float4 rv[MAXU];
-        unsigned livem = 0;
-#pragma unroll
-        for (int i = 0; i < MAXU; ++i) {
-            const int u = tid + 256 * i, uc = u < total ? u : 0;
-            const int row = uc / C4, c4 = uc - row * C4;
-            const int kk = row < 32 ? 0 : (row - 32 < NKp ? row - 32 : row - 32 - NKp);
-            const bool live = row < 32 ? row < 28 : kk < NKk;
-            const float* src = row < 32 ? a.p0 + (int64_t)(live ? row : 0) * d + h * hd
-                                        : kvb + (int64_t)(live ? kk : 0) * 2 * d + (row - 32 < NKp ? 0 : d);
-            rv[i] = *reinterpret_cast<const float4*>(src + 4 * c4);
-            livem |= (live && u < total ? 1u : 0u) << i;
-        }
-#pragma unroll
-        for (int i = 0; i < MAXU; ++i) {
-            const int u = tid + 256 * i;
-            if (u < total) {
-                const int row = u / C4, c4 = u - row * C4;
-                *reinterpret_cast<float4*>(smem + row * QS + 4 * c4) = (livem >> i) & 1 ? rv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    }
-    __syncthreads();
-    if (wv < 2) {                             // query rows 16 wv .. 16 wv + 15 against every key
-        f32x4 S[kAttnMaxKT];
-#pragma unroll
-        for (int t = 0; t < kAttnMaxKT; ++t) S[t] = f32x4{0, 0, 0, 0};
-#pragma unroll 2
-        for (int sk = 0; sk < hd / 4; ++sk) {
-            const float av = Qs[(16 * wv + j) * QS + 4 * sk + g];
-#pragma unroll
-            for (int t = 0; t < kAttnMaxKT; ++t)
-                if (t < NKT) S[t] = KM_MFMA(av, Ks[(16 * t + j) * QS + 4 * sk + g], S[t]);
-        }
-        // S[t][r] = score of (row 16 wv + 4 g + r, key 16 t + j): softmax over the keys = over t in the lane and over the 16 lanes j
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * wv + 4 * g + r;
-            float m = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < kAttnMaxKT; ++t)
-                if (t < NKT) { S[t][r] = 16 * t + j < NKk ? S[t][r] * scale : -INFINITY; m = fmaxf(m, S[t][r]); }
-            m = row16_max(m);
-            float sum = 0.f;
-#pragma unroll
-            for (int t = 0; t < kAttnMaxKT; ++t)
-                if (t < NKT) { S[t][r] = expf(S[t][r] - m); sum += S[t][r]; }
-            sum = row16_sum(sum);
-            const int64_t prow = (((int64_t)b * H + h) * 28 + row) * NKk;
-#pragma unroll
-            for (int t = 0; t < kAttnMaxKT; ++t)
-                if (t < NKT) {
-                    const int k = 16 * t + j;
-                    const float pv = S[t][r] / sum;
-                    const bool live = row < 28 && k < NKk;
-                    const float pd = a.mask ? (keepb[r][t] ? pv * a.f0 : 0.f) : pv;
-                    if (live) a.q0[prow + k] = pv;
-                    Ss[row * SS + k] = live ? pd : 0.f;
-                }
-        }
-    }
-    __syncthreads();
-    for (int tile = wv; tile < 2 * CT; tile += 4) {          // A_h = Pd V_h: 2 x CT tiles of 16 x 16, contraction over the keys
-        const int rt = tile / CT, ct = tile - rt * CT;
-        f32x4 acc = f32x4{0, 0, 0, 0};
-#pragma unroll 2
-        for (int sk = 0; sk < NKp / 4; ++sk)
-            acc = KM_MFMA(Ss[(16 * rt + j) * SS + 4 * sk + g], Vs[(4 * sk + g) * QS + 16 * ct + j], acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * rt + 4 * g + r;
-            if (row < 28) a.q1[((int64_t)b * 28 + row) * d + h * hd + 16 * ct + j] = acc[r];
-        }
-    }
-    __syncthreads();
-}
-
-template <int HD>
-__device__ __forceinline__ void attn_bwd_mfma_dev(const ElemArgs& a, int vb, float* smem) {
-    constexpr int hd = HD, QS = hd + 4, CT = hd / 16;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, j = lane & 15;
-    const int d = a.i0, NKk = a.i2, H = a.i3, NKT = (NKk + 15) / 16, NKp = 16 * NKT, SS = NKp + 4;
-    const int b = vb / H, h = vb - b * H;
-    float* Qs = smem;                         // [32][QS]  rows 28..31 zero
-    float* Gs = Qs + 32 * QS;                 // [32][QS]  dA_h, rows 28..31 zero
-    float* Ks = Gs + 32 * QS;                 // [NK][QS]
-    float* Vs = Ks + NKp * QS;                // [NKp][QS], rows >= NK zero
-    float* Ps = Vs + NKp * QS;                // [32][SS]  P, zero beyond row 27 / key NK - 1
-    float* Ds = Ps + 32 * SS;                 // [32][SS]  Pd = P keep / (1 - p), rows 28..31 zero
-    float* Es = Ds + 32 * SS;                 // [32][SS]  dS, rows 28..31 zero
-    const float scale = __uint_as_float(a.u0);
-    const int64_t prow0 = ((int64_t)b * H + h) * 28 * NKk;
-    const float* kvb = a.p1 + (int64_t)b * NKk * 2 * d + h * hd;
-    const float* gab = a.p3 + (int64_t)b * 28 * d + h * hd;
-    // dropout bytes of the lane's dP elements (waves 0 and 1), requested up front: see attn_fwd_mfma_dev
-    unsigned char keepb[4][kAttnMaxKT];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int t = 0; t < kAttnMaxKT; ++t) {
-            const int row = 16 * (wv & 1) + 4 * g + r, k = 16 * t + j;
-            keepb[r][t] = 1;
-            if (a.mask) keepb[r][t] = a.mask[prow0 + (int64_t)(row < 28 ? row : 27) * NKk + (k < NKk ? k : 0)];
-        }
-    // (rows 28..31: a real row is loaded and a zero selected -- a select between a load and a constant is compiled as a select
-    // of ADDRESSES with the constant in scratch memory, which drags the whole kernel argument there)
-    // Staging as in the forward block: Q, dA (32 rows each), K, V (NKp rows) are consecutive [row][QS] images; P and
-    // Pd = P keep / (1 - p) are [32][SS] images made from the same loads of P (+ the keep bytes); everything is requested
-    // before the first LDS store.
-    {
-        constexpr int C4 = hd / 4, MAXU = ((64 + 2 * 16 * kAttnMaxKT) * C4 + 255) / 256, MAXP = (32 * 4 * kAttnMaxKT + 255) / 256;
-        const int total = (64 + 2 * NKp) * C4, P4 = NKp / 4, totalp = 32 * P4;
-        float4 rv[MAXU], pvv[MAXP];
-        unsigned keepw[MAXP];
-        unsigned livem = 0, livep = 0;
-#pragma unroll
-        for (int i = 0; i < MAXU; ++i) {
-            const int u = tid + 256 * i, uc = u < total ? u : 0;
-            const int row = uc / C4, c4 = uc - row * C4;
-            const int qq = row < 32 ? row : row - 32;
-            const int kk = row < 64 ? 0 : (row - 64 < NKp ? row - 64 : row - 64 - NKp);
-            const bool live = row < 64 ? qq < 28 : kk < NKk;
-            const float* src = row < 32 ? a.p0 + (int64_t)(live ? qq : 0) * d + h * hd
-                             : row < 64 ? gab + (int64_t)(live ? qq : 0) * d
-                                        : kvb + (int64_t)(live ? kk : 0) * 2 * d + (row - 64 < NKp ? 0 : d);
-            rv[i] = *reinterpret_cast<const float4*>(src + 4 * c4);
-            livem |= (live && u < total ? 1u : 0u) << i;
-        }
-#pragma unroll
-        for (int i = 0; i < MAXP; ++i) {
-            const int u = tid + 256 * i, uc = u < totalp ? u : 0;
-            const int q = uc / P4, k4 = uc - q * P4;
-            const bool live = u < totalp && q < 28 && 4 * k4 < NKk;          // NK is a multiple of 4: a float4 of keys is all real or all padding
-            const int64_t off = prow0 + (live ? q * NKk + 4 * k4 : 0);
-            pvv[i] = *reinterpret_cast<const float4*>(a.p2 + off);
-            keepw[i] = a.mask ? *reinterpret_cast<const unsigned*>(a.mask + off) : 0x01010101u;
-            livep |= (live ? 1u : 0u) << i;
-        }
-#pragma unroll
-        for (int i = 0; i < MAXU; ++i) {
-            const int u = tid + 256 * i;
-            if (u < total) {
-                const int row = u / C4, c4 = u - row * C4;
-                *reinterpret_cast<float4*>(smem + row * QS + 4 * c4) = (livem >> i) & 1 ? rv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < MAXP; ++i) {
-            const int u = tid + 256 * i;
-            if (u < totalp) {
-                const int q = u / P4, k4 = u - q * P4;
-                const bool live = (livep >> i) & 1;
-                const float4 pz = live ? pvv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                const unsigned kw = keepw[i];
-                const float sc = a.mask ? a.f0 : 1.0f;
-                *reinterpret_cast<float4*>(Ps + q * SS + 4 * k4) = pz;
-                *reinterpret_cast<float4*>(Ds + q * SS + 4 * k4) =
-                    make_float4((kw & 0xffu) ? pz.x * sc : 0.f, (kw & 0xff00u) ? pz.y * sc : 0.f, (kw & 0xff0000u) ? pz.z * sc : 0.f,
-                                (kw & 0xff000000u) ? pz.w * sc : 0.f);
-            }
-        }
-    }
-    __syncthreads();
-    if (wv < 2) {
-        // dP = (dA_h V_h^T) keep / (1 - p) and dS = P (dP - sum_k dP P) for the query rows 16 wv .. + 15 (all keys in this wave)
-        f32x4 G[kAttnMaxKT];
-#pragma unroll
-        for (int t = 0; t < kAttnMaxKT; ++t) G[t] = f32x4{0, 0, 0, 0};
-#pragma unroll 2
-        for (int sk = 0; sk < hd / 4; ++sk) {
-            const float av = Gs[(16 * wv + j) * QS + 4 * sk + g];
-#pragma unroll
-            for (int t = 0; t < kAttnMaxKT; ++t)
-                if (t < NKT) G[t] = KM_MFMA(av, Vs[(16 * t + j) * QS + 4 * sk + g], G[t]);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * wv + 4 * g + r;
-            float pv[kAttnMaxKT], sacc = 0.f;
-#pragma unroll
-            for (int t = 0; t < kAttnMaxKT; ++t)
-                if (t < NKT) {
-                    const int k = 16 * t + j;
-                    pv[t] = Ps[row * SS + k];
-                    float gv = G[t][r];
-                    if (a.mask) gv = (row < 28 && k < NKk && keepb[r][t]) ? gv * a.f0 : 0.f;
-                    G[t][r] = gv;
-                    sacc += gv * pv[t];
-                }
-            sacc = row16_sum(sacc);
-#pragma unroll
-            for (int t = 0; t < kAttnMaxKT; ++t)
-                if (t < NKT) Es[row * SS + 16 * t + j] = row < 28 ? pv[t] * (G[t][r] - sacc) : 0.f;
-        }
-    } else {
-        // dV_h = Pd^T dA_h: NKT x CT tiles, contraction over the (padded) query rows; waves 2 and 3 share the key tiles
-        for (int tile = wv - 2; tile < NKT * CT; tile += 2) {
-            const int kt = tile / CT, ct = tile - kt * CT;
-            f32x4 acc = f32x4{0, 0, 0, 0};
-#pragma unroll 2
-            for (int sk = 0; sk < 8; ++sk)
-                acc = KM_MFMA(Ds[(4 * sk + g) * SS + 16 * kt + j], Gs[(4 * sk + g) * QS + 16 * ct + j], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (16 * kt + 4 * g + r < NKk) a.q0[((int64_t)b * NKk + 16 * kt + 4 * g + r) * 2 * d + d + h * hd + 16 * ct + j] = acc[r];
-        }
-    }
-    __syncthreads();
-    if (wv < 2) {
-        // dK_h = scale dS^T Q_h: NKT x CT tiles over the query rows; waves 0 and 1 share the key tiles
-        for (int tile = wv; tile < NKT * CT; tile += 2) {
-            const int kt = tile / CT, ct = tile - kt * CT;
-            f32x4 acc = f32x4{0, 0, 0, 0};
-#pragma unroll 2
-            for (int sk = 0; sk < 8; ++sk)
-                acc = KM_MFMA(Es[(4 * sk + g) * SS + 16 * kt + j], Qs[(4 * sk + g) * QS + 16 * ct + j], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (16 * kt + 4 * g + r < NKk) a.q0[((int64_t)b * NKk + 16 * kt + 4 * g + r) * 2 * d + h * hd + 16 * ct + j] = scale * acc[r];
-        }
-    } else {
-        // dQ_h of this window = scale dS K_h: 2 x CT tiles over the keys; waves 2 and 3 share them
-        for (int tile = wv - 2; tile < 2 * CT; tile += 2) {
-            const int rt = tile / CT, ct = tile - rt * CT;
-            f32x4 acc = f32x4{0, 0, 0, 0};
-#pragma unroll 2
-            for (int sk = 0; sk < NKp / 4; ++sk)
-                acc = KM_MFMA(Es[(16 * rt + j) * SS + 4 * sk + g], Ks[(4 * sk + g) * QS + 16 * ct + j], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * rt + 4 * g + r;
-                if (row < 28) a.q1[((int64_t)b * 28 + row) * d + h * hd + 16 * ct + j] = scale * acc[r];
-            }
-        }
-    }
-    __syncthreads();
 }
 
 // vb / tid: block and thread index of the operation's 256-thread block
@@ -597,6 +282,7 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
     }
     case OP_ATTN_FWD:
         if constexpr (!ATTN) break;
+        else if (a.i1 == 32 && a.u1 == 0 && a.i2 > 64 && a.i2 <= 80) attn_fwd_dma32_dev<5>(a, vb, smem);      // 80 mel channels; u1 != 0: option train_attn_regs (the register-staged block)
         else if (a.i1 == 32) attn_fwd_mfma_dev<32>(a, vb, smem); else if (a.i1 == 64) attn_fwd_mfma_dev<64>(a, vb, smem); else attn_fwd_mfma_dev<16>(a, vb, smem);
         break;
     case OP_ATTN_BWD:
@@ -620,7 +306,7 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
 #define KM_TRAINP_WAVES 4      /* waves per SIMD the phases without attention blocks are compiled for */
 #endif
 #ifndef KM_TRAINP_WAVES_ATTN
-#define KM_TRAINP_WAVES_ATTN 4
+#define KM_TRAINP_WAVES_ATTN 2
 #endif
 // The 4 KB Phase is never touched as a by-value object: its words are read through the kernel-argument segment pointer
 // (constant address space, uniform offsets: scalar loads).
@@ -1113,8 +799,12 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     {
         ElemArgs e{};
         e.p0 = Qb; e.p1 = KV; e.q0 = Pm; e.q1 = A; e.i0 = (int)d; e.i1 = (int)hd; e.i2 = (int)NKk; e.i3 = (int)H;
-        e.mask = m_mel; e.f0 = keep_scale; e.u0 = scale_bits;
-        pg.elem(OP_ATTN_FWD, e, B * H, (size_t)attn_mfma_fwd_lds_floats((int)hd, (int)NKk) * sizeof(float));
+        e.mask = m_mel; e.f0 = keep_scale; e.u0 = scale_bits; e.u1 = c->opt.train_attn_regs ? 1u : 0u;
+        {
+            size_t fl = (size_t)attn_mfma_fwd_lds_floats((int)hd, (int)NKk);
+            if (hd == 32 && (size_t)kAttnDmaFwdLdsFloats > fl) fl = kAttnDmaFwdLdsFloats;
+            pg.elem(OP_ATTN_FWD, e, B * H, fl * sizeof(float));
+        }
     }
     {
         ElemArgs e{};
