@@ -477,3 +477,173 @@ __device__ __forceinline__ void attn_bwd_mfma_dev(const ElemArgs& a, int vb, flo
     __syncthreads();
 }
 
+// ---- backward block for heads of 32 columns on LDS-DMA staged images (round 4) ------------------------------------------------
+// Same recipe as attn_fwd_dma32_dev.  Operands and the image form each product wants (MFMA: out[M][N] += A[M][k] B[k][N];
+// "k-contiguous" = the swizzled [row][8 chunks] image read with one ds_read_b128 per fragment, "row-contiguous" = [k][rows]
+// read with four ds_read_b32 at compile-time offsets):
+//   dP[q][key]  = dA V^T        A = dA k-contiguous, B = V k-contiguous                       (all four waves, as the scores)
+//   dS          = P (dP' - sum_key dP' P), dP' = dP keep / (1 - p): in registers; P and the dropout bytes of a lane's ten
+//                 elements come straight from memory into registers, requested with the operands
+//   dV[key][c]  = Pd^T dA       A = Pd^T: the [q][84] image of Pd read row-contiguous, B = dA row-contiguous
+//   dK[key][c]  = scale dS^T Q  A = dS^T: the [q][84] image of dS, B = Q row-contiguous
+//   dQ[q][c]    = scale dS K    A = dS k-contiguous (the SAME [q][84] image: a row stride of 84 floats is conflict-free for
+//                 both read forms), B = K row-contiguous
+// dA is staged twice (one image per form: 4 KB each).  53 KB of LDS against 64.5 for the register-staged block.
+constexpr int kAttnDmaBwdLdsFloats = 3 * 32 * 32 + 2 * 80 * 32 + 2 * 32 * 84;
+template <int NKT>
+__device__ __forceinline__ void attn_bwd_dma32_dev(const ElemArgs& a, int vb, float* smem) {
+    constexpr int hd = 32, PS = 84;
+    static_assert(NKT == 5, "the images below hold 80 keys");
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, j = lane & 15;
+    const int d = a.i0, NKk = a.i2, H = a.i3;
+    const int b = vb / H, h = vb - b * H;
+    float* G0 = smem;                  // dA, k-contiguous   [32][32]  rows 28 .. 31 zero
+    float* G1 = G0 + 32 * 32;          // dA, row-contiguous [32 q][32 cols]
+    float* Q1 = G1 + 32 * 32;          // Q,  row-contiguous [32 q][32 cols]
+    float* V0 = Q1 + 32 * 32;          // V,  k-contiguous   [80][32]
+    float* K1 = V0 + 80 * 32;          // K,  row-contiguous [80 keys][32 cols]
+    float* Dp = K1 + 80 * 32;          // Pd [32 q][84]
+    float* Es = Dp + 32 * PS;          // dS [32 q][84]
+    const float scale = __uint_as_float(a.u0);
+    const unsigned OOB = 0x80000000u;
+    const int rt = wv & 1, rh = wv >> 1;
+    {
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p0), 0, (unsigned)(28 * d * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p3 + (int64_t)b * 28 * d), 0, (unsigned)(28 * d * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p1 + (int64_t)b * NKk * 2 * d), 0,
+                                                                             (unsigned)(NKk * 2 * d * 4), 0x00020000);
+        {
+            const int row = tid >> 3, cp = tid & 7;
+            const int kg = cp ^ ((row >> 1) & 7);                           // k-contiguous image: chunk
+            const int grp = cp ^ (4 * ((row >> 2) & 1));                    // row-contiguous image [k = row][cols]: column group
+            const unsigned ok = row < 28 ? 0u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (km_attn_lds_ptr)(G0 + 64 * wv * 4), 16, ok | (unsigned)((row * d + h * hd + 4 * kg) * 4), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (km_attn_lds_ptr)(G1 + 64 * wv * 4), 16, ok | (unsigned)((row * d + h * hd + 4 * grp) * 4), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (km_attn_lds_ptr)(Q1 + 64 * wv * 4), 16, ok | (unsigned)((row * d + h * hd + 4 * grp) * 4), 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (i < 2 || wv < 2) {                                           // keys 64 .. 79: waves 0 and 1 (an image holds 80 rows)
+                const int s = i * 256 + tid, key = s >> 3;
+                const int kg = (s & 7) ^ ((key >> 1) & 7);
+                const int grp = (s & 7) ^ (4 * ((key >> 2) & 1));
+                const unsigned ov = key < NKk ? (unsigned)((key * 2 * d + d + h * hd + 4 * kg) * 4) : OOB;
+                const unsigned ok = key < NKk ? (unsigned)((key * 2 * d + h * hd + 4 * grp) * 4) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (km_attn_lds_ptr)(V0 + (i * 256 + 64 * wv) * 4), 16, ov, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (km_attn_lds_ptr)(K1 + (i * 256 + 64 * wv) * 4), 16, ok, 0, 0, 0);
+            }
+        }
+    }
+    // P and keep / (1 - p) of the ten elements this lane will finish (rows 16 rt + 4 g + 2 rh + {0, 1}, keys 16 t + j): rows
+    // 28 .. 31 lie beyond the descriptor's range (P = 0), keys past NK too
+    float pe[2][NKT], kf[2][NKT];
+    {
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.p2 + (int64_t)(b * H + h) * 28 * NKk), 0,
+                                                                             (unsigned)(28 * NKk * 4), 0x00020000);
+        const unsigned char* mh = a.mask ? a.mask + (int64_t)(b * H + h) * 28 * NKk : nullptr;
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+            for (int t = 0; t < NKT; ++t) {
+                const int row = 16 * rt + 4 * g + 2 * rh + r2, k = 16 * t + j;
+                const unsigned o = (row < 28 && k < NKk) ? (unsigned)((row * NKk + k) * 4) : OOB;
+                pe[r2][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rp, o, 0, 0));
+                unsigned char kb = 1;
+                if (mh) kb = mh[(row < 28 ? row : 27) * NKk + (k < NKk ? k : 0)];
+                kf[r2][t] = (row < 28 && k < NKk) ? (mh ? (kb ? a.f0 : 0.f) : 1.f) : 0.f;
+            }
+    }
+    KM_TILE_STAMP(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    KM_TILE_STAMP(2);
+    {   // dP for the row tile rt (both waves of a row tile), then dS and Pd of this wave's two rows per lane
+        f32x4 Gp[NKT];
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) Gp[t] = f32x4{0, 0, 0, 0};
+        const int arow = 16 * rt + j, asw = (arow >> 1) & 7, ksw = (j >> 1) & 7;
+        const float* ap = G0 + arow * 32;
+        const float* vp = V0 + j * 32;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(ap + (((4 * kb + g) ^ asw) << 2));
+            const int vo = ((4 * kb + g) ^ ksw) << 2;
+#pragma unroll
+            for (int t = 0; t < NKT; ++t) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(vp + vo + t * 16 * 32);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Gp[t] = KM_MFMA(av[q], bv[q], Gp[t]);
+            }
+        }
+        KM_TILE_STAMP(4);
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+            const int r = 2 * rh + r2, row = 16 * rt + 4 * g + r;
+            float gv[NKT], sacc = 0.f;
+#pragma unroll
+            for (int t = 0; t < NKT; ++t) { gv[t] = Gp[t][r] * kf[r2][t]; sacc += gv[t] * pe[r2][t]; }
+            sacc = row16_sum(sacc);
+#pragma unroll
+            for (int t = 0; t < NKT; ++t) {
+                Es[row * PS + 16 * t + j] = pe[r2][t] * (gv[t] - sacc);
+                Dp[row * PS + 16 * t + j] = pe[r2][t] * kf[r2][t];
+            }
+        }
+    }
+    __syncthreads();
+    KM_TILE_STAMP(3);
+    // dV, dK: ten 16 x 16 tiles each (key tile kt, column tile ct), contraction over the 32 queries; dQ: four tiles over the keys.
+    // Tiles are dealt to the waves round robin: 3 + 3 (or 2 + 2) + 1.
+    float* dkv = a.q0 + (int64_t)b * NKk * 2 * d + h * hd;
+    const int cb = 16 * (g & 1);                                              // the row-contiguous images' column swap for this lane group
+#pragma unroll
+    for (int ti = 0; ti < 3; ++ti) {
+        const int tile = wv + 4 * ti;
+        if (tile < 2 * NKT) {
+            const int kt = tile >> 1, ct = tile & 1;
+            f32x4 accv = f32x4{0, 0, 0, 0}, acck = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int q0 = 16 * kb + 4 * g;                                  // queries q0 .. q0 + 3 in MFMAs 0 .. 3
+                const float* pd = Dp + q0 * PS + 16 * kt + j;
+                const float* es = Es + q0 * PS + 16 * kt + j;
+                const float* ga = G1 + q0 * 32 + ((16 * ct + j) ^ cb);
+                const float* qa = Q1 + q0 * 32 + ((16 * ct + j) ^ cb);
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    accv = KM_MFMA(pd[s_ * PS], ga[s_ * 32], accv);
+                    acck = KM_MFMA(es[s_ * PS], qa[s_ * 32], acck);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * kt + 4 * g + r;
+                if (key < NKk) {
+                    dkv[(int64_t)key * 2 * d + d + 16 * ct + j] = accv[r];
+                    dkv[(int64_t)key * 2 * d + 16 * ct + j] = scale * acck[r];
+                }
+            }
+        }
+    }
+    {   // dQ tile (ot, ct) = (wv >> 1, wv & 1): contraction over the keys in blocks of 16
+        const int ot = wv >> 1, ct = wv & 1;
+        const float* er = Es + (16 * ot + j) * PS + 4 * g;
+        const float* kc = K1 + 4 * g * 32 + ((16 * ct + j) ^ cb);
+        f32x4 acc = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int kb = 0; kb < NKT; ++kb) {
+            const f32x4 ev = *reinterpret_cast<const f32x4*>(er + 16 * kb);
+            const float* kp = kc + 16 * kb * 32;
+            acc = KM_MFMA(ev[0], kp[0], acc);
+            acc = KM_MFMA(ev[1], kp[32], acc);
+            acc = KM_MFMA(ev[2], kp[64], acc);
+            acc = KM_MFMA(ev[3], kp[96], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ot + 4 * g + r;
+            if (row < 28) a.q1[((int64_t)b * 28 + row) * d + h * hd + 16 * ct + j] = scale * acc[r];
+        }
+    }
+    __syncthreads();
+}

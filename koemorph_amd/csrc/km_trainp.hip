@@ -287,6 +287,7 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
         break;
     case OP_ATTN_BWD:
         if constexpr (!ATTN) break;
+        else if (a.i1 == 32 && a.u1 == 0 && a.i2 > 64 && a.i2 <= 80) attn_bwd_dma32_dev<5>(a, vb, smem);
         else if (a.i1 == 32) attn_bwd_mfma_dev<32>(a, vb, smem); else if (a.i1 == 64) attn_bwd_mfma_dev<64>(a, vb, smem); else attn_bwd_mfma_dev<16>(a, vb, smem);
         break;
     default: break;
@@ -802,7 +803,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         e.mask = m_mel; e.f0 = keep_scale; e.u0 = scale_bits; e.u1 = c->opt.train_attn_regs ? 1u : 0u;
         {
             size_t fl = (size_t)attn_mfma_fwd_lds_floats((int)hd, (int)NKk);
-            if (hd == 32 && (size_t)kAttnDmaFwdLdsFloats > fl) fl = kAttnDmaFwdLdsFloats;
+            if (hd == 32 && !c->opt.train_attn_regs && NKk > 64 && NKk <= 80) fl = kAttnDmaFwdLdsFloats;
             pg.elem(OP_ATTN_FWD, e, B * H, fl * sizeof(float));
         }
     }
@@ -860,8 +861,9 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     {
         ElemArgs e{};
         e.p0 = Qb; e.p1 = KV; e.p2 = Pm; e.p3 = dA; e.q0 = dKV; e.q1 = dQ_part; e.i0 = (int)d; e.i1 = (int)hd; e.i2 = (int)NKk; e.i3 = (int)H;
-        e.mask = m_mel; e.f0 = keep_scale; e.u0 = scale_bits;
-        pg.elem(OP_ATTN_BWD, e, B * H, attn_lds);
+        e.mask = m_mel; e.f0 = keep_scale; e.u0 = scale_bits; e.u1 = c->opt.train_attn_regs ? 1u : 0u;
+        const bool dma_blk = hd == 32 && !c->opt.train_attn_regs && NKk > 64 && NKk <= 80;
+        pg.elem(OP_ATTN_BWD, e, B * H, dma_blk ? (size_t)kAttnDmaBwdLdsFloats * sizeof(float) : attn_lds);
     }
     {
         ElemArgs e{};
