@@ -379,8 +379,10 @@ constexpr int kTailMaxGroups = 1024;      // rows of Context::trp_tail_part
 // long serial chains on a few CUs -- at 64 windows K = 5120 is 160 k-steps on 32 of 256 CUs and sets the duration of its
 // phase.  Such a product is cut along K into S batch entries that write S partial outputs; the partials are summed in a
 // fixed order (OP_REDUCE4) by the NEXT phase, which is early enough: nothing but the optimizer reads a parameter gradient.
-// Products of up to kSplitMinK stay whole: the 8-window step (K <= 640) runs exactly as before.
-constexpr int kSplitMinK = 1024;
+// Products of up to kSplitMinK stay whole.  Round 4: 512 (1024 before) with chains of ~512 rows -- on the LDS-DMA tile a k-step is
+// short enough that the K = 640 products of the 8-window step are worth cutting in two (0.1339 -> 0.1322 ms), and the finer
+// cut helps at 64 windows too (0.2906 -> 0.2828 ms).
+constexpr int kSplitMinK = 512;
 struct PendingReduce { const float* part; float* out; int n, S, acc; };
 
 struct Program {
@@ -398,8 +400,9 @@ struct Program {
     int64_t scratch_left = 0;
     std::vector<PendingReduce> pend_prev, pend_cur;
     bool allow_split = true;
+    const float* leaf_lo = nullptr; const float* leaf_hi = nullptr;      // the gradient bucket: outputs inside it may be split along K
     // S for a product of K rows with `tiles` output tiles, or 1
-    int min_k = kSplitMinK, chain = 640;
+    int min_k = kSplitMinK, chain = 512;
     int bm32_below = 192;                // products with fewer 64-row tiles than this run on 32-row tiles
     bool op_per_launch = false; hipStream_t dbg_stream = nullptr;
     int split_factor(int64_t K, int tiles) const {
@@ -430,7 +433,11 @@ struct Program {
     void gemm(const GemmArgs& g_in, int batch) {
         GemmArgs g = g_in;
         const int tiles0 = ((g.N + 63) / 64) * ((g.M + 31) / 32);
-        const bool splittable = allow_split && batch == 1 && g.kb_count == 1 && g.bias_mode == 0 && g.relu == 0 && !g.drop && g.alpha == 1.f &&
+        // only a product whose output lies in the gradient bucket may be cut: nothing but the optimizer (and the next phase's
+        // reduction) reads it.  An activation of the backward chain -- dY = dKV Wkv has K = 2 d_model = 1024 at d_model 512 -- is
+        // read by the very next phase and must be whole when its own phase ends.
+        const bool leaf = g.C >= leaf_lo && g.C < leaf_hi;
+        const bool splittable = allow_split && leaf && batch == 1 && g.kb_count == 1 && g.bias_mode == 0 && g.relu == 0 && !g.drop && g.alpha == 1.f &&
                                 g.c_rs == g.N && (g.beta == 0.f || g.beta == 1.f);
         const int S = splittable ? split_factor(g.K, tiles0) : 1;
         // an output some pending reduction (of this or the previous phase) still has to write must not be touched directly:
@@ -689,6 +696,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     Program pg;
     pg.scratch = c->trp_split; pg.scratch_left = c->trp_split_floats;
     pg.allow_split = !c->opt.train_no_split;
+    pg.leaf_lo = flat_grad; pg.leaf_hi = flat_grad + c->tr_nparams;
     if (c->opt.train_bm32_below > 0) pg.bm32_below = c->opt.train_bm32_below;
     pg.op_per_launch = c->opt.train_op_per_launch != 0; pg.dbg_stream = st;
     pg.use_dma = !c->opt.train_no_dma;
@@ -710,8 +718,8 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     std::memcpy(&scale_bits, &scale, sizeof(scale_bits));
 
     // ================= P0: what the channel encoder waits for and nothing else: packed input, padded weight =================
-    // (the gradient bucket, the ones vector and the dropout masks are first read in P4 / P8: they are made in P2, beside the
-    // LayerNorm, where they cost nothing -- P0 7.6 -> 4.7 us at 8 windows)
+    // (the gradient bucket, the ones vector and the dropout masks are first read in P4 / P8: they are made in P3 / P4, behind
+    // those phases' own work, where they cost nothing -- P0 7.6 -> 5 us at 8 windows)
     if (asrc) {                                // from audio: the power-mel of the front end -> packed log-mel rows (read by P1)
         ElemArgs e{};
         e.p0 = asrc->melpow; e.p1 = reinterpret_cast<const float*>(asrc->melmax); e.q0 = const_cast<float*>(xp_dev); e.n0 = B;
@@ -752,7 +760,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     { GemmArgs g = G(Weo, d, 1, boe, 1, 0, t1e, 1, d, 1, d); g.bias = beo; g.bias_mode = 2; pg.gemm(g, 1); }
     pg.gemm(NT(emo, ED, P("emotion_encoder.weight"), ED, E0, d, B, d, P("emotion_encoder.bias"), 0), 1);
     RUN(pg.end_phase(st));
-    // ================= P2: LayerNorm (both streams); folds Wf = W1 T1; clean bucket, ones, dropout masks =================
+    // ================= P2: LayerNorm (both streams); folds Wf = W1 T1 =================
     {
         ElemArgs e{};
         e.p0 = Y0; e.q0 = Y; e.n0 = R; e.i0 = (int)d; e.p1 = P("mel_norm.weight"); e.p2 = P("mel_norm.bias"); e.q1 = mu; e.q2 = rs;
@@ -767,15 +775,11 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     pg.gemm(NN(W1, d, T1e, d, Wfe, d, DH, d, d), 1);
     { GemmArgs g = G(W1, d, 1, t1m, 1, 0, bfm, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }     // bf = W1 t1 + b1
     { GemmArgs g = G(W1, d, 1, t1e, 1, 0, bfe, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }
-    // (behind the phase's own work in dispatch order: workgroups are handed out in operation order)
-    {
-        ElemArgs e{};
-        e.q0 = flat_grad; e.n0 = c->tr_nparams;
-        pg.elem(OP_ZERO, e, (c->tr_nparams + 1023) / 1024);
-        ElemArgs f{};
-        f.q0 = ones; f.n0 = R; f.f0 = 1.0f;
-        pg.elem(OP_FILL, f, blocks256(R));
-    }
+    RUN(pg.end_phase(st));
+    // ================= P3: [K | V]; emotion value projection =================
+    pg.gemm(NT(Y, d, inw + d * d, d, KV, 2 * d, R, 2 * d, inb + d, 0), 1);
+    pg.gemm(NT(E, d, einw + 2 * d * d, d, Ve, d, B, d, einb + 2 * d, 0), 1);
+    // the dropout masks of the step (first read in P4), behind the phase's own work in dispatch order
     if (drop && c->tr_dropout_mode == 0) {
         int64_t nm, ne, nd;
         trainp_mask_sizes(c, B, &nm, &ne, &nd);
@@ -790,10 +794,6 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
             pg.elem(OP_MASKGEN, e, (sizes[r] + 1023) / 1024);
         }
     }
-    RUN(pg.end_phase(st));
-    // ================= P3: [K | V]; emotion value projection =================
-    pg.gemm(NT(Y, d, inw + d * d, d, KV, 2 * d, R, 2 * d, inb + d, 0), 1);
-    pg.gemm(NT(E, d, einw + 2 * d * d, d, Ve, d, B, d, einb + 2 * d, 0), 1);
     RUN(pg.end_phase(st));
     // ================= P4: attention (scores, softmax, dropout, P V) per (window, head); emotion attention (one key: weight 1,
     // dropped or kept per head and query) =================
@@ -811,6 +811,15 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         ElemArgs e{};
         e.p0 = Ve; e.q0 = Ae; e.n0 = B; e.i0 = (int)d; e.i1 = (int)hd; e.mask = m_emo; e.f0 = keep_scale;
         pg.elem(OP_EMO_EXPAND, e, blocks256(Re * d));
+    }
+    // clean gradient bucket and the ones vector (first touched in P8): they ride under the attention blocks
+    {
+        ElemArgs e{};
+        e.q0 = flat_grad; e.n0 = c->tr_nparams;
+        pg.elem(OP_ZERO, e, (c->tr_nparams + 1023) / 1024);
+        ElemArgs f{};
+        f.q0 = ones; f.n0 = R; f.f0 = 1.0f;
+        pg.elem(OP_FILL, f, blocks256(R));
     }
     RUN(pg.end_phase(st));
     // ================= P5: decoder hidden through the fold (+ ReLU + dropout), both streams; O1, Oe1 beside it =================

@@ -325,9 +325,9 @@ def test_train_step_from_audio_leaves_clean_window_maxima():
 
 
 def test_split_k_gradient_products_agree_with_the_unsplit_step():
-    """64 windows: the gradient products over all rows of the batch (K = 80 B, 28 B, 24 B > 1024) are cut along K into partial
+    """64 windows: the gradient products over all rows of the batch (K = 80 B, 28 B, 24 B > 512) are cut along K into partial
     products summed by the next phase (km_trainp.hip, Program::gemm).  Same gradients as the unsplit program (option
-    train_no_split) up to summation order, bit-reproducible from run to run, and the 8-window step is not affected."""
+    train_no_split) up to summation order, bit-reproducible from run to run."""
     params = synth.make_core_params(5, style="trained")
     B = 64
     mel, short, emo = synth.make_core_inputs(77, B, 257, style="mel01")
