@@ -834,40 +834,51 @@ __global__ __launch_bounds__(512) void kmmf_decode_kernel(DecArgs a) {
 // melmax != null: `mel` is the front end's POWER-mel (rows = (window, frame), Tm frames per window) and the dB / log conversion
 // against the window's maximum happens while a tile is staged (the same log_one() as mel_log_kernel: that launch and the
 // memset of the maxima behind it are gone from km_legacy_forward; legacy_attention_kernel, the next launch, re-zeroes them).
-__global__ __launch_bounds__(256) void legacy_encoder_kernel(const float* __restrict__ mel, const float* __restrict__ blob, int64_t rows,
+#ifndef KM_LEGACY_ENC_ROWS
+#define KM_LEGACY_ENC_ROWS 32       /* token rows per workgroup: 32 (four waves) or 64 (eight waves: two row blocks that fetch the same weight fragments) */
+#endif
+#ifndef KM_LEGACY_ENC_CT
+#define KM_LEGACY_ENC_CT 4          /* column tiles of 16 per wave: 4 (four waves per row block) or 2 (eight waves: twice the waves per SIMD) */
+#endif
+constexpr int LROWS = KM_LEGACY_ENC_ROWS, LCT = KM_LEGACY_ENC_CT, LCW = 16 / LCT, LNTH = 64 * LCW * (LROWS / 32), LIMG = LROWS * XS;
+__global__ __launch_bounds__(LNTH) void legacy_encoder_kernel(const float* __restrict__ mel, const float* __restrict__ blob, int64_t rows,
                                                             float* __restrict__ Kp, float* __restrict__ Vp,
                                                             const unsigned* __restrict__ melmax, int Tm, LogParams lp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* A = smem;
-    float* Bi = smem + EIMG;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all % LCW, rblk = wave_all / LCW;             // column block of 16 LCT, row block of 32
+    float* A0 = smem;
+    float* B0 = smem + LIMG;
+    float* A = A0 + rblk * 32 * XS;
+    float* Bi = B0 + rblk * 32 * XS;
     const int g = lane >> 4, j = lane & 15;
-    const int64_t r0 = (int64_t)blockIdx.x * EROWS;
-    const int col0 = 64 * wave;
-    for (int i = tid; i < EROWS * (LG_MEL / 4); i += ENTH) {
+    const int64_t r0w = (int64_t)blockIdx.x * LROWS;                     // first row of the workgroup
+    const int64_t r0 = r0w + 32 * rblk;                                  // first row of this wave's row block
+    const int col0 = 16 * LCT * wave;
+    for (int i = tid; i < LROWS * (LG_MEL / 4); i += LNTH) {
         const int r = i / (LG_MEL / 4), c4 = i - r * (LG_MEL / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r0 + r < rows) {
-            v = *reinterpret_cast<const float4*>(mel + (r0 + r) * LG_MEL + 4 * c4);
+        if (r0w + r < rows) {
+            v = *reinterpret_cast<const float4*>(mel + (r0w + r) * LG_MEL + 4 * c4);
             if (melmax) {
                 float ref_db, floor_db;
-                log_window_consts(lp, __uint_as_float(melmax[(r0 + r) / Tm]), ref_db, floor_db);
+                log_window_consts(lp, __uint_as_float(melmax[(r0w + r) / Tm]), ref_db, floor_db);
                 v = make_float4(log_one(lp, v.x, ref_db, floor_db), log_one(lp, v.y, ref_db, floor_db), log_one(lp, v.z, ref_db, floor_db),
                                 log_one(lp, v.w, ref_db, floor_db));
             }
         }
-        *reinterpret_cast<float4*>(A + r * XS + 4 * c4) = v;
+        *reinterpret_cast<float4*>(A0 + r * XS + 4 * c4) = v;
     }
     __syncthreads();
     auto layer = [&](const float* src, float* dst, int64_t w_off, int64_t b_off, int kbs) {     // dst = relu(src W^T + b)
-        f32x4 acc[2][4];
+        f32x4 acc[2][LCT];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0, 0, 0, 0};
-        mm_cols<2, 4, KM_LEGACY_ENC_PIN>(acc, src, blob + w_off, 4 * wave, kbs, 0, kbs, lane);
+            for (int nt = 0; nt < LCT; ++nt) acc[mt][nt] = f32x4{0, 0, 0, 0};
+        mm_cols<2, LCT, KM_LEGACY_ENC_PIN>(acc, src, blob + w_off, LCT * wave, kbs, 0, kbs, lane);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < LCT; ++nt) {
             const float bb = blob[b_off + col0 + 16 * nt + j];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -883,14 +894,14 @@ __global__ __launch_bounds__(256) void legacy_encoder_kernel(const float* __rest
     layer(Bi, A, LG_W3, LG_B3, KBD);
     __syncthreads();
     auto project = [&](int64_t w_off, int64_t b_off, float* out) {                                // out rows = A W^T + b
-        f32x4 acc[2][4];
+        f32x4 acc[2][LCT];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0, 0, 0, 0};
-        mm_cols<2, 4, KM_LEGACY_ENC_PIN>(acc, A, blob + w_off, 4 * wave, KBD, 0, KBD, lane);
+            for (int nt = 0; nt < LCT; ++nt) acc[mt][nt] = f32x4{0, 0, 0, 0};
+        mm_cols<2, LCT, KM_LEGACY_ENC_PIN>(acc, A, blob + w_off, LCT * wave, KBD, 0, KBD, lane);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < LCT; ++nt) {
             const float bb = blob[b_off + col0 + 16 * nt + j];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -1042,8 +1053,8 @@ int launch_legacy_encoder_fused(Context* c, const float* mel, int64_t rows, floa
     static PerDeviceOnce once;
     if (once.first(c->device))
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kf::legacy_encoder_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * kf::EIMG * 4));
-    hipLaunchKernelGGL(kf::legacy_encoder_kernel, dim3((unsigned)((rows + kf::EROWS - 1) / kf::EROWS)), dim3(kf::ENTH), 2 * kf::EIMG * 4,
+                                    2 * kf::LIMG * 4));
+    hipLaunchKernelGGL(kf::legacy_encoder_kernel, dim3((unsigned)((rows + kf::LROWS - 1) / kf::LROWS)), dim3(kf::LNTH), 2 * kf::LIMG * 4,
                        (hipStream_t)stream, mel, dvp(c, "lgf_enc"), rows, Kp, Vp, melmax, Tm, lp ? LogParams(*lp) : LogParams{});
     HIP_TRY(hipGetLastError());
     return KM_OK;

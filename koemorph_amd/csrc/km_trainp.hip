@@ -931,6 +931,10 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     // dWce (d x KT) = dY0^T XT over ALL rows (window, channel) of the batch: with the transposed input it is ONE product with a
     // uniform k stride (round 3: a contraction batch over the windows on the register tile, 19 us at 8 windows); split along K
     // like every other gradient product when the batch is large (partials summed by P13)
+    // (P12 is the last phase with work of its own: a product cut here needs a launch just for its reduction, which pays only for
+    // the long chains of large batches)
+    const int min_k_saved = pg.min_k;
+    if (pg.min_k < 1024) pg.min_k = 1024;
     pg.gemm(TN(dY0, d, X, KP, Gd("mel_channel_encoder.weight"), KT, d, KT, R), 1);
     colsum(dY0, R, d, d, Gd("mel_channel_encoder.bias"), 0, ones);
     colsum(Tm, R, d, d, Gd("mel_norm.weight"), 0, ones);
@@ -939,6 +943,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     colsum(dE, B, d, d, Gd("emotion_norm.bias"), 0, ones);
     pg.gemm(TN(dE0, d, emo, ED, Gd("emotion_encoder.weight"), ED, d, ED, B), 1);
     colsum(dE0, B, d, d, Gd("emotion_encoder.bias"), 0, ones);
+    pg.min_k = min_k_saved;
     RUN(pg.end_phase(st));
     // ================= P13: the partial sums of P12's split products (large batches) =================
     RUN(pg.end_phase(st));
