@@ -355,3 +355,34 @@ def test_split_k_gradient_products_agree_with_the_unsplit_step():
     for k in ("mel_attention.in_proj_weight", "mel_attention.out_proj.weight", "mel_output_proj.weight", "blendshape_decoder.0.weight",
               "blendshape_decoder.3.weight", "mel_channel_encoder.weight", "mel_norm.weight", "mel_attention.in_proj_bias"):
         np.testing.assert_allclose(g2[k], gref[k], atol=1e-8 + 2e-4 * np.abs(gref[k]).max(), rtol=2e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("B", [8, 5])
+def test_lds_dma_tiles_and_attention_blocks_agree_with_the_register_staged_ones(B):
+    """Round 4: the products of the program run on the LDS-DMA tile (km_gemm_dma_dev.h), the attention blocks on LDS-DMA staged
+    images (km_train_attn_dev.h).  Options train_no_dma / train_attn_regs select the register-staged code of round 3: the same
+    step, dropout masks included, must give the same loss and gradients -- the tile is bit-identical per product
+    (tools/micro/tile_bench.hip), the epilogue and the softmax (v_exp_f32 / v_rcp_f32) differ in the last bits.  B = 5: K = 80 B is
+    not a multiple of 32, so the gradient products over the batch fall back to the register tile inside the SAME program."""
+    params = synth.make_core_params(9, style="trained")
+    mel, short, emo = synth.make_core_inputs(91, B, 257, style="mel01")
+    target = synth.uniform(92, (B, 52), 0.0, 1.0)
+    c = dict(d=256, H=8, T=256, B=B)
+    e, tr = make(params, c, l1_weight=0.1, dropout=0.1, seed=3)
+    shapes = {k: v.shape for k, v in params.items()}
+    runs = {}
+    for name, opts in (("dma", {}), ("no_dma", {"train_no_dma": 1}), ("attn_regs", {"train_attn_regs": 1}),
+                       ("round3", {"train_no_dma": 1, "train_attn_regs": 1})):
+        for k in ("train_no_dma", "train_attn_regs"):
+            e.set_option(k, opts.get(k, 0))
+        tr.set_dropout(0.1, seed=3)                      # the same Philox masks in every run
+        check_step = tr._lib.km_train_set_dropout_step(tr._h, 0)
+        assert check_step == 0
+        loss = float(tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target)).item())
+        runs[name] = (loss, tr.grads(shapes))
+    l0, g0 = runs["round3"]
+    for name in ("dma", "no_dma", "attn_regs"):
+        l, g = runs[name]
+        assert abs(l - l0) < 2e-6 * max(1.0, abs(l0)), name
+        for k in g0:
+            np.testing.assert_allclose(g[k], g0[k], atol=1e-8 + 2e-5 * np.abs(g0[k]).max(), rtol=2e-4, err_msg=f"{name}: {k}")
