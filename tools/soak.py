@@ -28,7 +28,29 @@ bad_t = 0
 for _ in range(100):
     tr.forward_backward(audio[:8], emo[:8], tgt)
     bad_t += int(not torch.equal(tr.flat_grad, g0) or float(tr.loss.item()) != l0)
-print(f"train forward_backward (two streams): 100 repetitions, {bad_t} differ")
+print(f"train forward_backward: 100 repetitions, {bad_t} differ")
+# round 4: LDS-DMA tiles / attention blocks with dropout (the same Philox step every time), 8 and 64 windows, and 1000 optimiser steps
+import ctypes
+for Bt in (8, 64):
+    tr2 = Trainer(eng, max_windows=Bt, use_smoothing=False, dropout=0.1, seed=7)
+    tgt2 = torch.from_numpy(synth.uniform(5, (Bt, 52), 0, 1)).cuda()
+    def once():
+        assert tr2._lib.km_train_set_dropout_step(tr2._h, 0) == 0
+        tr2.forward_backward(audio[:Bt], emo[:Bt], tgt2)
+        return tr2.flat_grad.clone(), float(tr2.loss.item())
+    g0, l0 = once()
+    bad_d = 0
+    for _ in range(100):
+        g, l = once()
+        bad_d += int(not torch.equal(g, g0) or l != l0)
+    print(f"train forward_backward with dropout, {Bt} windows: 100 repetitions, {bad_d} differ")
+    bad_t += bad_d
+    if Bt == 8:
+        for _ in range(1000):
+            tr2.step(audio[:8], emo[:8], tgt2)
+        fin = float(tr2.loss.item())
+        print(f"1000 optimiser steps at 8 windows: final loss {fin:.6f} (finite: {fin == fin and abs(fin) < 1e9})")
+        bad_t += int(not (fin == fin and abs(fin) < 1e9))
 core_bad = bad or bad_s or bad_t
 
 # the fused legacy models: determinism of the multi-wave reductions (LayerNorm partials, online softmax)
