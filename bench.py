@@ -768,6 +768,8 @@ def run_c3(args, rk: Ranks):
     eng = Engine()
     eng.load_state_dict(synth.make_core_params(0))
     eng.finalize(rk.dev)
+    for kv in filter(None, os.environ.get("KM_BENCH_OPTIONS", "").split(",")):      # timing aids, e.g. train_op_per_launch=1
+        eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     kw = {}
     if "dropout" in Trainer.__init__.__code__.co_varnames:
         kw["dropout"] = args.dropout

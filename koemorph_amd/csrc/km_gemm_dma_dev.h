@@ -43,7 +43,13 @@ constexpr int stage_floats(int BM) { return (BM + BN) * BK; }
 constexpr int lds_floats(int BM, int NS) { return NS * stage_floats(BM); }
 // ring stages: 8 for the 32-row tiles of a phase whose workgroups are alone on their CUs (the 8-window step: the whole K = 256 is
 // requested at entry, 96 KB of LDS), else 4 (48 / 64 KB: several workgroups per CU hide each other's prologue and epilogue)
-constexpr int ring_stages(int BM, bool alone) { return BM == 32 && alone ? 8 : 4; }
+#ifndef KM_DMA_NS64
+#define KM_DMA_NS64 3
+#endif
+#ifndef KM_DMA_NS32
+#define KM_DMA_NS32 4
+#endif
+constexpr int ring_stages(int BM, bool alone) { return BM == 32 ? (alone ? 8 : KM_DMA_NS32) : KM_DMA_NS64; }
 }
 
 typedef __attribute__((address_space(3))) void* km_lds_ptr;
@@ -241,14 +247,14 @@ __device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int
     const int kt = g.K / BK;
     KM_TILE_STAMP(1);
     auto issue = [&](int j) {
-        float* img = smem + (j & (NS - 1)) * SF;
+        float* img = smem + (j % NS) * SF;
         const unsigned dead = j >= kt ? 0x80000000u : 0u;
         ta.issue(img, wave, j, dead);
         tb.issue(img + BM * BK, wave, j, dead);
     };
     // fragments of one stage: [tile][k block]
     auto fetch = [&](int j, f32x4 (&af)[MT][2], f32x4 (&bf)[2][2]) {
-        const float* As = smem + (j & (NS - 1)) * SF;
+        const float* As = smem + (j % NS) * SF;
         const float* Bs = As + BM * BK;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {

@@ -590,7 +590,15 @@ __device__ __forceinline__ void train_tail_window_dev(const TailArgs& a, float* 
         if (G > 1) {
             __threadfence();
             v = 0.f;
-            for (int g = 0; g < G; ++g) v += a.part[(int64_t)g * 64 + i];
+            // the windows' sums in window order, eight loads in flight at a time (one dependent load per window made this loop
+            // half of the tail at 64 windows: 25 us)
+            for (int g0 = 0; g0 < G; g0 += 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = a.part[(int64_t)(g0 + u < G ? g0 + u : g0) * 64 + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += g0 + u < G ? t[u] : 0.f;
+            }
         }
         const float loss_t = __shfl(v, 52), dal_t = __shfl(v, 53), db2_t = __shfl(v, 54);
         if (i == 0) {

@@ -109,6 +109,22 @@ __device__ __forceinline__ void stage_to_lds(int n, Src src, Dst dst) {
 }
 
 // vb / tid: block and thread index of the operation's 256-thread block
+// p[0] + p[stride] + ... in index order, eight loads in flight at a time (as a plain loop this is one dependent L2 round trip per
+// term: the 64 per-window parts of dQ took 17.5 us at 64 windows, more than any product of their phase)
+__device__ __forceinline__ float sum_rows_in_order(const float* p, int64_t stride, int n) {
+    float s = 0.f;
+    int y = 0;
+    for (; y + 8 <= n; y += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = p[(int64_t)(y + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; y < n; ++y) s += p[(int64_t)y * stride];
+    return s;
+}
+
 template <bool ATTN>
 __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* smem) {
     const ElemArgs& a = op.e;
@@ -230,9 +246,7 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
     case OP_REDUCE: {       // out[c] (+)= sum_y part[y][c], fixed order
         const int64_t c0 = (int64_t)vb * 256 + tid;
         if (c0 >= a.n0) break;
-        float s = 0.f;
-        for (int y = 0; y < a.i0; ++y) s += a.p0[(int64_t)y * a.n1 + c0];
-        a.q0[c0] = a.i1 ? a.q0[c0] + s : s;
+        a.q0[c0] = (a.i1 ? a.q0[c0] : 0.f) + sum_rows_in_order(a.p0 + c0, a.n1, a.i0);
         break;
     }
     case OP_REDUCE4: {      // the workgroup's blocks are dealt to the (up to four) reductions in order
@@ -246,9 +260,7 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
         const int acc = j == 0 ? a.racc0 : (j == 1 ? a.racc1 : (j == 2 ? a.racc2 : a.racc3));
         const int64_t c0 = (int64_t)(vb - base) * 256 + tid;
         if (c0 >= n) break;
-        float sacc = 0.f;
-        for (int y = 0; y < S; ++y) sacc += part[(int64_t)y * n + c0];
-        out[c0] = acc ? out[c0] + sacc : sacc;
+        out[c0] = (acc ? out[c0] : 0.f) + sum_rows_in_order(part + c0, n, S);
         break;
     }
     case OP_EMO_EXPAND: {   // Ae[(b, q), c] = Ve[b, c] * keep[b, c / hd, q] / (1 - p): the one-key attention of the emotion stream
@@ -306,6 +318,9 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
 #ifndef KM_TRAINP_WAVES
 #define KM_TRAINP_WAVES 4      /* waves per SIMD the phases without attention blocks are compiled for */
 #endif
+#ifndef KM_TRAINP_XCD_REMAP
+#define KM_TRAINP_XCD_REMAP 1
+#endif
 #ifndef KM_TRAINP_WAVES_ATTN
 #define KM_TRAINP_WAVES_ATTN 2
 #endif
@@ -327,11 +342,21 @@ __global__ __launch_bounds__(256, ATTN ? KM_TRAINP_WAVES_ATTN : KM_TRAINP_WAVES)
     const int vb = blockIdx.x, n_ops = (int)ka[W_NOPS];
     int i = 0;
     while (i + 1 < n_ops && vb >= (int)ka[W_END + i]) ++i;            // workgroup-uniform
-    const int local = vb - (i ? (int)ka[W_END + i - 1] : 0);
+    const int start = i ? (int)ka[W_END + i - 1] : 0;
+    int local = vb - start;
     // a generic pointer derived from the kernel-argument segment pointer: the address-space inference pass turns every access
     // through it back into a constant-address-space (scalar) load, and there is no local object the compiler could spill
     const Op& op = *(const Op*)(ka + W_OPS + i * W_OP);
     if (op.kind == OP_GEMM) {
+#if KM_TRAINP_XCD_REMAP
+        {   // workgroups are dealt round-robin over the 8 XCDs (observed, MI355X_MICROARCH.md "Workgroup dispatch"): blocks with the
+            // same id mod 8 share an L2.  Give each such group a CONTIGUOUS run of the product's tiles (column tiles of one row
+            // block, the tiles of one K chunk of a split product) so that the operands they share are fetched into one L2, once.
+            // Bijective for any tile count; which workgroup computes which tile changes, the results do not.
+            const int n = (int)ka[W_END + i] - start, q8 = n >> 3, r8 = n & 7, x = local & 7;
+            local = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (local >> 3);
+        }
+#endif
         const int per = op.gx * op.gy;
         const int bz = local / per, t = local - bz * per;
         const int tx = t % op.gx, ty = t / op.gx;
@@ -341,13 +366,13 @@ __global__ __launch_bounds__(256, ATTN ? KM_TRAINP_WAVES_ATTN : KM_TRAINP_WAVES)
                 else if (op.ma == 0) gemm_tile_dma_dev<32, 8, 0, 1>(op.g, tx, ty, bz, smem);
                 else gemm_tile_dma_dev<32, 8, 1, 1>(op.g, tx, ty, bz, smem);
             } else if (op.bm == 32) {
-                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<32, 4, 0, 0>(op.g, tx, ty, bz, smem);
-                else if (op.ma == 0) gemm_tile_dma_dev<32, 4, 0, 1>(op.g, tx, ty, bz, smem);
-                else gemm_tile_dma_dev<32, 4, 1, 1>(op.g, tx, ty, bz, smem);
+                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<32, KM_DMA_NS32, 0, 0>(op.g, tx, ty, bz, smem);
+                else if (op.ma == 0) gemm_tile_dma_dev<32, KM_DMA_NS32, 0, 1>(op.g, tx, ty, bz, smem);
+                else gemm_tile_dma_dev<32, KM_DMA_NS32, 1, 1>(op.g, tx, ty, bz, smem);
             } else {
-                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<64, 4, 0, 0>(op.g, tx, ty, bz, smem);
-                else if (op.ma == 0) gemm_tile_dma_dev<64, 4, 0, 1>(op.g, tx, ty, bz, smem);
-                else gemm_tile_dma_dev<64, 4, 1, 1>(op.g, tx, ty, bz, smem);
+                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<64, KM_DMA_NS64, 0, 0>(op.g, tx, ty, bz, smem);
+                else if (op.ma == 0) gemm_tile_dma_dev<64, KM_DMA_NS64, 0, 1>(op.g, tx, ty, bz, smem);
+                else gemm_tile_dma_dev<64, KM_DMA_NS64, 1, 1>(op.g, tx, ty, bz, smem);
             }
         } else
         // operand B of the channel encoder (rows of 259 floats) is the one product without 16-byte rows
