@@ -222,6 +222,7 @@ static int free_train(Context* c) {
     if (c->tr_red2) { HIP_TRY(hipFree(c->tr_red2)); c->tr_red2 = nullptr; }
     if (c->trp_act) { HIP_TRY(hipFree(c->trp_act)); c->trp_act = nullptr; c->trp_act_floats = 0; }
     if (c->trp_split) { HIP_TRY(hipFree(c->trp_split)); c->trp_split = nullptr; c->trp_split_floats = 0; }
+    if (c->trp_wcep) { HIP_TRY(hipFree(c->trp_wcep)); c->trp_wcep = nullptr; }
     if (c->trp_tail_part) { HIP_TRY(hipFree(c->trp_tail_part)); c->trp_tail_part = nullptr; }
     if (c->trp_tail_ctr) { HIP_TRY(hipFree(c->trp_tail_ctr)); c->trp_tail_ctr = nullptr; }
     if (c->trp_masks) { HIP_TRY(hipFree(c->trp_masks)); c->trp_masks = nullptr; }
@@ -240,6 +241,7 @@ static int upload_train_params(Context* c, void* stream) {
         std::memcpy(flat.data() + c->tr_offset.at(k), hp.data.data(), hp.data.size() * sizeof(float));
     }
     HIP_TRY(hipMemcpyAsync(c->tr_params, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    if (int rc = train_refresh_padded_weights(c, stream)) return rc;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return KM_OK;
 }
@@ -300,8 +302,11 @@ int km_train_init(km_handle h, int64_t max_windows, void* stream) {
         int64_t fixed = 0;
         const int64_t per = trainp_act_floats(c, &fixed);
         const int64_t KP = trainp_kp(c);
-        c->trp_act_floats = max_windows * (per + KP * c->NK) + fixed + 4096;
+        c->trp_act_floats = max_windows * (per + 2 * KP * c->NK) + fixed + 4096;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_act), (size_t)c->trp_act_floats * sizeof(float)));
+        // the packed input's columns beyond T + 3 are written by nobody when the front end packs: zeros (they meet zero weights)
+        HIP_TRY(hipMemsetAsync(c->trp_act, 0, (size_t)c->trp_act_floats * sizeof(float), (hipStream_t)stream));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_wcep), (size_t)c->d * KP * sizeof(float)));
         // split-K partials: up to 16 partial outputs of every weight / bias gradient that is a product over the rows of the batch
         c->trp_split_floats = 16 * (5 * (int64_t)c->d * c->d + 2 * (int64_t)c->DH * c->d + 16 * (int64_t)c->d + (int64_t)c->d * c->KT) + 1024;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->trp_split), (size_t)c->trp_split_floats * sizeof(float)));
@@ -360,10 +365,15 @@ int km_train_step_audio(km_handle h, const float* audio_dev, int64_t B, int64_t 
     if (!c->opt.train_chain) {
         // front end -> power-mel; phase 0 of the program converts and packs it into the encoder input (B, KP, n_mels) at the
         // head of the phased workspace
-        if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, L, stream)) return rc;
-        c->melmax_dirty = true;      // until phase 1 has re-zeroed the maxima
+        // (round 4: the front end writes the packed dB input itself -- MelPack -- where it can; option train_no_fe_pack)
+        const bool fe_packs = !c->opt.train_no_fe_pack && !c->opt.train_no_dma && !c->opt.train_op_per_launch &&
+                              mel_packs(c, c->mel_plans[0], n_frames, c->T) && c->mel_plans[0]->cfg.n_mels == c->NK;
+        const MelPack pack{c->trp_act, (int)c->T, (int)trainp_kp(c)};
+        if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, L, stream, 0, 0, 0, 1, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                      fe_packs ? &pack : nullptr)) return rc;
+        c->melmax_dirty = true;      // until phase 1 / 2 has re-zeroed the maxima
         const LogParams lp = plan_log_params(c->mel_plans[0]);
-        const TrainAudioSrc asrc{c->ws_melpow, c->ws_melmax, (int)n_frames, &lp};
+        const TrainAudioSrc asrc{c->ws_melpow, c->ws_melmax, (int)n_frames, &lp, fe_packs};
         return train_forward_backward_phased(c, nullptr, B, n_frames, nullptr, c->trp_act, &asrc, emotion_dev, target_dev, mse_weight,
                                              l1_weight, flat_grad_dev, loss_dev, out_dev, ema_state_dev, ema_first, stream);
     }
@@ -472,6 +482,8 @@ int km_train_set_params(km_handle h, const float* flat_host, int64_t n) {
     if (int rc = need_train(h, 1)) return rc;
     if (!flat_host || n != h->tr_nparams) return fail(KM_ERR_INVALID_ARG, "km_train_set_params: size mismatch");
     HIP_TRY(hipMemcpy(h->tr_params, flat_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    if (int rc = train_refresh_padded_weights(h, nullptr)) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
     return KM_OK;
 }
 

@@ -78,6 +78,7 @@ struct Options {
     int train_no_split = 0;        // 1: no split-K of the long gradient products of the phased training step (A/B)
     int train_dwce_parts = 0;      // > 0: partial sums of the channel-encoder gradient per step (a divisor of the batch; A/B)
     int train_split_min_k = 0;     // > 0: split gradient products longer than this many rows into chains of about this length (A/B; default 1024 / 640)
+    int train_no_fe_pack = 0;      // 1: km_train_step_audio converts and packs the power-mel in phase 0 of the program (round 3/4 form) instead of inside the front-end launch
     int train_attn_regs = 0;       // 1: the attention blocks of the training program as the register-staged blocks of round 3 (A/B of the LDS-DMA blocks)
     int train_no_dma = 0;          // 1: the products of the training program run on the register-staged tile only (A/B of the LDS-DMA tile, km_gemm_dma_dev.h)
     int train_op_per_launch = 0;   // 1: every operation of the training program is its own launch (timing aid: rocprofv3 then shows each operation)
@@ -151,6 +152,7 @@ struct Context {
     bool tr_early_recorded = false;
     std::map<std::string, int64_t> tr_offset;
     float* tr_params = nullptr; float* tr_m = nullptr; float* tr_v = nullptr;
+    float* trp_wcep = nullptr;     // (d, KP) the channel encoder weight with rows padded to KP floats (zeros): written with tr_params (upload, AdamW)
     float* tr_act = nullptr; float* tr_q = nullptr; float* tr_dq = nullptr; float* tr_part = nullptr; float* tr_gnorm = nullptr;
     float* tr_loss = nullptr;
     float* tr_red = nullptr;         // split-reduction partials
@@ -217,6 +219,7 @@ int64_t train_act_floats(Context* c);
 int train_forward_backward(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short, const float* emo,
                            const float* target, float mse_w, float l1_w, float* flat_grad, float* loss_dev, float* out_dev,
                            float* ema_state, int ema_first, void* stream);
+int train_refresh_padded_weights(Context* c, void* stream);
 int train_adamw(Context* c, const float* flat_grad, float lr, float b1, float b2, float eps, float wd, float max_norm,
                 int64_t step, void* stream);
 
@@ -228,7 +231,8 @@ int trainp_mask_sizes(Context* c, int64_t B, int64_t* mel, int64_t* emo, int64_t
 int trainp_copy_masks(Context* c, int64_t B, unsigned char* mel, unsigned char* emo, unsigned char* dec, int to_device, void* stream);
 // from-audio training step: the front end's power-mel + window maxima, converted and packed by phase 0 of the program
 struct LogParams;
-struct TrainAudioSrc { const float* melpow; const unsigned* melmax; int n_frames; const LogParams* lp; };
+// packed: the front end wrote 10 log10(power) into the packed input itself (MelPack); the readers finish the dB conversion
+struct TrainAudioSrc { const float* melpow; const unsigned* melmax; int n_frames; const LogParams* lp; bool packed; };
 int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64_t T_in, const float* mel_short, const float* xp_dev,
                                   const TrainAudioSrc* asrc,
                                   const float* emo, const float* target, float mse_w, float l1_w, float* flat_grad, float* loss_dev,
@@ -265,10 +269,14 @@ struct SeqFrames {
     int64_t n_rows;
     int frame_mul;
 };
+// packed training input written by the front end itself (MelArgs::pack_*): xt (B, n_mels, KP), T long frames per row
+struct MelPack { float* xt; int T, KP; };
 int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, void* stream,
                      int64_t clip_len = 0, int64_t win_step = 0, int64_t win0 = 0, int wins_per_clip = 1,
                      const int* ring_start = nullptr, const unsigned char* ready = nullptr,
-                     const float* emotion = nullptr, float* zemo = nullptr, const SeqFrames* seq = nullptr);
+                     const float* emotion = nullptr, float* zemo = nullptr, const SeqFrames* seq = nullptr,
+                     const MelPack* pack = nullptr);
+bool mel_packs(Context* c, MelPlan* p, int64_t n_frames, int64_t T);
 bool mel_fuses_emotion(Context* c, MelPlan* p);
 int ensure_chunk_counters(Context* c, int64_t windows, void* stream);
 int launch_ring_push(Context* c, const float* samples, int64_t n_per_stream, void* stream);

@@ -28,6 +28,21 @@ __device__ __forceinline__ void log_window_consts(const LogParams& p, float ref,
     floor_db = (db10(ref, p.amin) - ref_db) - p.top_db;
 }
 
+// the part of librosa.power_to_db(ref=np.max) + affine that needs the window's reference, applied to a stored 10 log10(max(amin, s))
+// (the training step's front end stores that; its readers finish the conversion: MelArgs::pack_*, DbXform)
+__device__ __forceinline__ float db_finish(const LogParams& p, float dbs, float ref_db, float floor_db) {
+    float v = dbs - ref_db;
+    v = clamp_lo(v, floor_db);
+    return (v + p.db_add) * p.db_scale;
+}
+// The same in two instructions, for top_db == db_add (the floor then maps to exactly 0): max(t, -A) + A == max(t + A, 0) and the
+// positive scale commutes with the max, so x = max(dbs * scale + (A - ref_db) * scale, 0) -- one fma + one max per value, within
+// an ulp or two of db_finish (the front end's own log is good to 3e-7 of the feature range).  c1 = db_fast_c1().
+__device__ __forceinline__ float db_fast_c1(const LogParams& p, float ref_db) { return (p.db_add - ref_db) * p.db_scale; }
+__device__ __forceinline__ float db_finish_fast(float dbs, float scale, float c1) { return fmaxf(fmaf(dbs, scale, c1), 0.f); }
+// operand transform of a product whose A rows hold 10 log10(power): batch entry z uses the reference ref_bits[z] (float bits)
+struct DbXform { LogParams lp; const unsigned* ref_bits; };
+
 template <int MODE>
 __device__ __forceinline__ float log_one_t(const LogParams& p, float s, float ref_db, float floor_db) {
     if (MODE == KM_LOG_LN_EPS) return 0.693147180559945309f * __builtin_amdgcn_logf(s + p.log_eps);   // src/features/stft.py:123

@@ -35,6 +35,7 @@
 // Included inside namespace km after km_gemm_dev.h.
 #pragma once
 
+#include "km_device.h"
 #include "km_gemm_dev.h"
 
 namespace gdma {
@@ -223,8 +224,10 @@ struct DmaEpilogue {
 };
 
 // tile (bx, by) of output batch bz; smem = gdma::lds_floats(BM, NS) floats, 16-byte aligned; NS = 4 or 8 ring stages
-template <int BM, int NS, int MA, int MB>
-__device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int by, int bz, float* smem) {
+// XFA (xf != null): operand A holds 10 log10(power) rows and every fragment is taken through db_finish() with the reference of
+// output batch entry z1 (km_device.h: DbXform) on its way to the MFMAs
+template <int BM, int NS, int MA, int MB, bool XFA = false>
+__device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int by, int bz, float* smem, const DbXform* xf = nullptr) {
     using namespace gdma;
     constexpr int MT = BM / 32, SF = stage_floats(BM), L = BM / 32 + 2;      // L: DMA instructions per thread and stage
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: it enters LDS-DMA destinations
@@ -245,6 +248,7 @@ __device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int
 #pragma unroll
     for (int i = 0; i < MT; ++i) { acc[i][0] = f32x4{0, 0, 0, 0}; acc[i][1] = f32x4{0, 0, 0, 0}; }
     const int kt = g.K / BK;
+    float xscale = 0.f, xc1 = 0.f;      // XFA: set behind the prologue's DMA requests
     KM_TILE_STAMP(1);
     auto issue = [&](int j) {
         float* img = smem + (j % NS) * SF;
@@ -266,14 +270,24 @@ __device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int
     };
     auto mfmas = [&](const f32x4 (&af)[MT][2], const f32x4 (&bf)[2][2]) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x4 at[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                at[i] = af[i][kb];
+                if constexpr (XFA) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) at[i][q] = db_finish_fast(at[i][q], xscale, xc1);
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    acc[i][0] = KM_MFMA(af[i][kb][q], bf[0][kb][q], acc[i][0]);
-                    acc[i][1] = KM_MFMA(af[i][kb][q], bf[1][kb][q], acc[i][1]);
+                    acc[i][0] = KM_MFMA(at[i][q], bf[0][kb][q], acc[i][0]);
+                    acc[i][1] = KM_MFMA(at[i][q], bf[1][kb][q], acc[i][1]);
                 }
+        }
     };
     // one step: stage it + 1 has landed everywhere, the buffer of stage it - 1 is free; request stage it + NS - 1 into it, fetch
     // the fragments of stage it + 1 (they arrive under the MFMAs of stage it, whose fragments were fetched a step earlier)
@@ -292,6 +306,15 @@ __device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int
     ep.prefetch(g, m0 + 16 * MT * wm, n0 + 32 * wn, lg, lj);
 #pragma unroll
     for (int j = 0; j < NS - 1; ++j) issue(j);
+    // XFA: the A fragments are 10 log10(power) values; the rest of the dB conversion (reference of batch entry z1, top_db floor,
+    // affine) is applied to them in registers, ahead of the MFMAs that consume them (db_finish_fast: 2 vector instructions per
+    // value under the matrix pipe) instead of a conversion pass (and a launch) ahead of the product.  The reference is read here, behind the DMA
+    // requests: its round trip runs beside the first stage's.
+    if constexpr (XFA) {
+        float ref_db, floor_db;
+        log_window_consts(xf->lp, __uint_as_float(xf->ref_bits[z1]), ref_db, floor_db);
+        xscale = xf->lp.db_scale; xc1 = db_fast_c1(xf->lp, ref_db);
+    }
     km_wait_vmcnt<(NS - 2) * L>();                 // stage 0 of this thread has landed
     __builtin_amdgcn_s_barrier();                  // ... and everyone's
     KM_TILE_STAMP(2);

@@ -129,6 +129,14 @@ struct MelArgs {
     // order they ask for them: chunk_ctr[window] counts the requests, is zero on entry and is put back to zero by the last
     // request of the launch
     unsigned* chunk_ctr;
+    // training from audio (km_train_step_audio; PACK instantiation of mel_power_rp_kernel): instead of melpow the kernel writes
+    // 10 log10(max(amin, power)) straight into the channel encoder's packed input xt (B, n_mels, KP) -- row m of a window: T long
+    // frames, then the last three computed frames (dual_stream_attention.py:189-211) -- and the rest of librosa.power_to_db, which
+    // needs the WINDOW's maximum (simplified_dual_stream_model.py:199-200), is applied by the readers: the channel encoder's tile
+    // on its operand fragments, OP_DBCONV beside it for the backward pass (km_trainp.hip).  No conversion launch in between.
+    float* pack_xt;
+    int pack_T, pack_KP;
+    float pack_amin;
 };
 
 // raw samples of the frame pair (fa, fa+1) into z[i] = (x_a[lane + 64 i], x_b[lane + 64 i]); wave-uniform fa
@@ -727,7 +735,7 @@ __device__ __forceinline__ int mel_lane_of(int slot, int frame) {
     return 32 * (slot >> 1) + m;
 }
 
-template <bool RING>
+template <bool RING, bool PACK = false>
 __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
     using namespace melrp;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -968,6 +976,25 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
             const float4* prow = reinterpret_cast<const float4*>(pw + flm * NFS);
             const float4* wbase = reinterpret_cast<const float4*>(fbw);
             float* dst = a.melpow + ((int64_t)b * a.n_frames + f0 + flm) * a.n_mels + slot;
+            // PACK: filter m of frame f is element (m, f) of the window's packed rows -- the 16 frame lanes of a filter write 64
+            // contiguous bytes -- and the last three computed frames are stored a second time behind the T long ones
+            const int fr = f0 + flm, qs = a.n_frames >= 3 ? fr - (a.n_frames - 3) : fr;
+            const bool st_long = fvalid && fr < a.pack_T, st_short = fvalid && qs >= 0 && qs < 3;
+            float* dst_long = nullptr; float* dst_short = nullptr;
+            if constexpr (PACK) {
+                dst_long = a.pack_xt + ((int64_t)b * a.n_mels + slot) * a.pack_KP + fr;
+                dst_short = a.pack_xt + ((int64_t)b * a.n_mels + slot) * a.pack_KP + a.pack_T + qs;
+            }
+            auto store_mel = [&](int gid, float r) {
+                if (4 * gid + slot >= a.n_mels) return;
+                if constexpr (PACK) {
+                    const float db = db10(r, a.pack_amin);
+                    if (st_long) dst_long[(int64_t)4 * gid * a.pack_KP] = db;
+                    if (st_short) dst_short[(int64_t)4 * gid * a.pack_KP] = db;
+                } else {
+                    if (fvalid) dst[4 * gid] = r;
+                }
+            };
             float fmx = 0.f;
 #if KM_MEL_FLAT
             // One chain of steps over all groups of the wave: the operands of a step are requested one step ahead, and the
@@ -999,7 +1026,7 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
                 r = fvalid ? r : 0.f;
                 asm("v_max_f32 %0, %0, %1" : "+v"(vmax) : "v"(r));
                 asm("v_max_f32 %0, %0, %1" : "+v"(fmx) : "v"(r));
-                if (fvalid && 4 * my_gid[i] + slot < a.n_mels) dst[4 * my_gid[i]] = r;
+                store_mel(my_gid[i], r);
             }
 #else
 #pragma unroll
@@ -1023,7 +1050,7 @@ __global__ __launch_bounds__(512, 4) void mel_power_rp_kernel(MelArgs a) {
                 r = fvalid ? r : 0.f;
                 asm("v_max_f32 %0, %0, %1" : "+v"(vmax) : "v"(r));
                 asm("v_max_f32 %0, %0, %1" : "+v"(fmx) : "v"(r));
-                if (fvalid && 4 * my_gid[i] + slot < a.n_mels) dst[4 * my_gid[i]] = r;
+                store_mel(my_gid[i], r);
             }
 #endif
             if (a.frame_max) {                                             // this wave's filters of frame f0 + flm
@@ -1198,9 +1225,18 @@ bool mel_fuses_emotion(Context* c, MelPlan* p) {
     return use_rp && p->cfg.n_fft == 1024 && c->kind == 0 && c->ED <= 256 && (d256 || (generic_ok && pow2(c->d) && pow2(c->DH)));
 }
 
+// true when launch_mel_power can write the training step's packed input itself (MelPack): the 1024-point kernel with a grouped
+// filter image, librosa's dB conversion with top_db == db_add (the floor maps to exactly 0), and at least T frames (every slot
+// of a row is then written by the launch: short clips take the conversion operation of phase 0)
+bool mel_packs(Context* c, MelPlan* p, int64_t n_frames, int64_t T) {
+    const km_mel_config& m = p->cfg;
+    return m.n_fft == 1024 && !c->opt.mel_two_frame && p->d_fbg_gid != nullptr && m.log_mode == KM_LOG_DB_MAX && m.top_db == m.db_add &&
+           n_frames >= T && n_frames >= 3;
+}
+
 int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int64_t L, void* stream,
                      int64_t clip_len, int64_t win_step, int64_t win0, int wins_per_clip, const int* ring_start,
-                     const unsigned char* ready, const float* emotion, float* zemo, const SeqFrames* seq) {
+                     const unsigned char* ready, const float* emotion, float* zemo, const SeqFrames* seq, const MelPack* pack) {
     const km_mel_config& m = p->cfg;
     const int64_t n_frames = seq ? seq->n_rows : 1 + L / m.hop_length;
     if (m.pad_mode == KM_PAD_REFLECT && L <= m.n_fft / 2)
@@ -1227,6 +1263,8 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_rp_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mel_power_rp_kernel<false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     hipStream_t st = (hipStream_t)stream;
     if (int rc = ensure_chunk_counters(c, B, stream)) return rc;
@@ -1248,6 +1286,12 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     a.fbg_gid = p->d_fbg_gid; a.fbg_desc = p->d_fbg_desc; a.fbg_weight = p->d_fbg_weight; a.fbg_nw = (int)p->fbg_weight.size();
     a.melpow = c->ws_melpow; a.melmax = c->ws_melmax;
     a.frame_mul = 1; a.frame_max = nullptr; a.chunk_ctr = c->ws_chunkctr;
+    a.pack_xt = nullptr; a.pack_T = a.pack_KP = 0; a.pack_amin = m.amin;
+    if (pack) {
+        if (!mel_packs(c, p, n_frames, pack->T) || seq || ring_start || wins_per_clip > 1 || pack->KP < pack->T + 3)
+            return fail(KM_ERR_UNSUPPORTED, "launch_mel_power: packed output requested for an unsupported configuration");
+        a.pack_xt = pack->xt; a.pack_T = pack->T; a.pack_KP = pack->KP;
+    }
     if (seq) { a.melpow = seq->pow; a.frame_max = seq->fmax; a.frame_mul = seq->frame_mul; a.melmax = nullptr; }
     if (emotion) {
         if (!mel_fuses_emotion(c, p) || !zemo || wins_per_clip > 1)
@@ -1268,7 +1312,8 @@ int launch_mel_power(Context* c, MelPlan* p, const float* audio, int64_t B, int6
     const bool use_rp = !c->opt.mel_two_frame;   // A/B switch: the two-frames-per-wave kernel
     if (m.n_fft == 1024 && use_rp && p->d_fbg_gid) {     // (more than 128 filters have no grouped image: the kernel below)
         const size_t ldsrp = melrp_lds_bytes(a.fbg_nw);      // 74 KB: two workgroups per CU
-        if (!ring_start) hipLaunchKernelGGL((mel_power_rp_kernel<false>), grid, dim3(melrp::NT), ldsrp, st, a);
+        if (pack) hipLaunchKernelGGL((mel_power_rp_kernel<false, true>), grid, dim3(melrp::NT), ldsrp, st, a);
+        else if (!ring_start) hipLaunchKernelGGL((mel_power_rp_kernel<false>), grid, dim3(melrp::NT), ldsrp, st, a);
         else hipLaunchKernelGGL((mel_power_rp_kernel<true>), grid, dim3(melrp::NT), ldsrp, st, a);
         HIP_TRY(hipGetLastError());
         return KM_OK;

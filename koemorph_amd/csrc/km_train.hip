@@ -258,6 +258,17 @@ __global__ void adamw_tick_kernel(int* __restrict__ steps, int alpha_live) {
 }
 
 // torch.nn.utils.clip_grad_norm_(max_norm) + torch.optim.AdamW (decoupled weight decay, bias correction)
+// The channel encoder weight is read by the training program as rows of KP floats (16-byte rows for the LDS-DMA tile, zeros
+// beyond the KT = T + 3 columns).  The copy is kept beside the master parameters -- rewritten wherever they are: here, and by
+// train_refresh_padded_weights after an upload -- instead of being rebuilt by an operation of every step.
+struct PaddedCopy {
+    float* dst; int64_t off; int64_t n; int kt, kp;      // parameters [off, off + n) are (n / kt) rows of kt floats
+    __device__ __forceinline__ void put(int64_t i, float v) const {
+        const int64_t j = i - off;
+        if (dst && j >= 0 && j < n) { const int64_t r = j / kt; dst[r * kp + (j - r * kt)] = v; }
+    }
+};
+
 // smoothing_alpha is outside the autograd graph whenever the EMA passes its input through (first call / batch-size
 // change / smoothing off): torch leaves its .grad as None and AdamW then skips it entirely (no decay, no moment
 // update, its own step counter).  alpha_idx / alpha_live / (abc1, abc2) reproduce that.
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     const float* __restrict__ g, int64_t n, const float* __restrict__ part,
                                                     float* __restrict__ gnorm_out, float max_norm, float lr, float b1, float b2,
                                                     float eps, float wd, const int* __restrict__ steps, int64_t alpha_idx,
-                                                    int alpha_live) {
+                                                    int alpha_live, PaddedCopy pc) {
     // global gradient norm from the 256 partial sums: every block runs the same fixed-order tree (a butterfly inside each
     // wave, then the four wave sums in wave order), so all blocks agree bit for bit
     __shared__ float sh[8];
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
         *reinterpret_cast<float4*>(p + i0) = p4;
         *reinterpret_cast<float4*>(m + i0) = m4;
         *reinterpret_cast<float4*>(v + i0) = v4;
+        pc.put(i0, p4.x); pc.put(i0 + 1, p4.y); pc.put(i0 + 2, p4.z); pc.put(i0 + 3, p4.w);
         return;
     }
     for (int64_t i = i0; i < n && i < i0 + 4; ++i) {
@@ -327,7 +339,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
         float pi = p[i], mi = m[i], vi = v[i];
         update(pi, mi, vi, g[i], bc1, bc2);
         p[i] = pi; m[i] = mi; v[i] = vi;
+        pc.put(i, pi);
     }
+}
+
+// dst (rows x kp) <- src (rows x kt), columns kt .. kp zero: the padded copy from scratch (parameter upload)
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t rows, int kt, int kp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * kp) return;
+    const int64_t r = i / kp; const int t = (int)(i - r * kp);
+    dst[i] = t < kt ? src[r * kt + t] : 0.f;
 }
 
 // ---- host orchestration ----------------------------------------------------------------------------------------
@@ -624,7 +645,18 @@ int train_adamw(Context* c, const float* flat_grad, float lr, float b1, float b2
     (void)step;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, c->tr_params, c->tr_m, c->tr_v, flat_grad, n,
                        c->tr_part, c->tr_gnorm, max_norm, lr, b1, b2, eps, wd, c->tr_steps, c->tr_offset.at("smoothing_alpha"),
-                       c->tr_alpha_live ? 1 : 0);
+                       c->tr_alpha_live ? 1 : 0,
+                       PaddedCopy{c->trp_wcep, c->tr_offset.at("mel_channel_encoder.weight"), (int64_t)c->d * c->KT, (int)c->KT, (int)trainp_kp(c)});
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+// after the master parameters were written from outside (km_train_init, km_train_set_params): the padded copy from scratch
+int train_refresh_padded_weights(Context* c, void* stream) {
+    if (!c->trp_wcep) return KM_OK;
+    const int64_t KP = trainp_kp(c);
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((c->d * KP + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       c->tr_params + c->tr_offset.at("mel_channel_encoder.weight"), c->trp_wcep, (int64_t)c->d, (int)c->KT, (int)KP);
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }

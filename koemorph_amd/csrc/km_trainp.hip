@@ -47,7 +47,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- operations of a phase ------------------------------------------------------------------------------------
 enum OpKind : int {
-    OP_GEMM = 0, OP_ZERO, OP_FILL, OP_MASKGEN, OP_PACKX, OP_LOGPACK, OP_LN_FWD, OP_LN_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_RELU_OUTER, OP_REDUCE,
+    OP_GEMM = 0, OP_ZERO, OP_FILL, OP_MASKGEN, OP_PACKX, OP_LOGPACK, OP_DBCONV, OP_LN_FWD, OP_LN_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_RELU_OUTER, OP_REDUCE,
     OP_EMO_EXPAND, OP_EMO_REDUCE, OP_REDUCE4, OP_PADROWS
 };
 
@@ -71,6 +71,7 @@ struct Phase {
     int n_ops;
     int block_end[kMaxOps];
     Op ops[kMaxOps];
+    DbXform xf;            // operand transform of the products with Op::dma == 2 (the channel encoder on the front end's packed rows)
 };
 static_assert(sizeof(Phase) <= 4096, "Phase is passed by value: 4 KB of kernel arguments");
 
@@ -186,6 +187,31 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
             if (F >= 3) f = F - 3 + q; else if (q < F) f = q;
         }
         a.q0[(b * NKk + m) * KP + r] = f >= 0 ? log_one(a.lp, a.p0[(b * F + f) * NKk + m], ref_db, floor_db) : 0.f;
+        break;
+    }
+    case OP_DBCONV: {       // q0 (B, NK, KP) <- p0: the front end's 10 log10(power) rows finished into dB features (db_finish with the
+        // window's reference p1[b]; columns >= T + 3 zero) for the readers of the backward pass; the channel encoder beside this
+        // operation converts its own fragments (DbXform).  Four values per thread.
+        // i3 workgroups per window, 16 values per thread: the window (hence its reference) is workgroup-uniform and all index
+        // arithmetic is 32-bit (as one flat 64-bit index with a division per value this operation took 3.5 us at 64 windows)
+        const unsigned NKk = a.i0, KP = a.i1, T = a.i2, kp4 = KP >> 2, n4 = NKk * kp4;
+        const unsigned b = (unsigned)vb / (unsigned)a.i3, e0 = ((unsigned)vb - b * a.i3) * 1024u + tid;
+        const float4* src = reinterpret_cast<const float4*>(a.p0) + (int64_t)b * n4;
+        float4* dst = reinterpret_cast<float4*>(a.q0) + (int64_t)b * n4;
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = src[e0 + u * 256 < n4 ? e0 + u * 256 : 0];
+        float ref_db, floor_db;
+        log_window_consts(a.lp, __uint_as_float(reinterpret_cast<const unsigned*>(a.p1)[b]), ref_db, floor_db);
+        const float c1 = db_fast_c1(a.lp, ref_db);       // the channel encoder's own transform, bit for bit
+        auto one = [&](float x, unsigned rr) { return rr < T + 3 ? db_finish_fast(x, a.lp.db_scale, c1) : 0.f; };
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned e = e0 + u * 256;
+            if (e >= n4) break;
+            const unsigned r = (e % kp4) * 4;
+            dst[e] = make_float4(one(v[u].x, r), one(v[u].y, r + 1), one(v[u].z, r + 2), one(v[u].w, r + 3));
+        }
         break;
     }
     case OP_PADROWS: {      // q0 (n0 rows x i1) <- p0 (n0 rows x i0), zeros beyond column i0: the channel encoder weight with rows of KP
@@ -360,7 +386,12 @@ __global__ __launch_bounds__(256, ATTN ? KM_TRAINP_WAVES_ATTN : KM_TRAINP_WAVES)
         const int per = op.gx * op.gy;
         const int bz = local / per, t = local - bz * per;
         const int tx = t % op.gx, ty = t / op.gx;
-        if (op.dma) {
+        if (op.dma == 2) {       // the channel encoder on the front end's 10 log10(power) rows (host: operand modes (0, 0))
+            const DbXform* xf = (const DbXform*)(ka + offsetof(Phase, xf) / 4);
+            if (op.bm == 32 && op.ns == 8) gemm_tile_dma_dev<32, 8, 0, 0, true>(op.g, tx, ty, bz, smem, xf);
+            else if (op.bm == 32) gemm_tile_dma_dev<32, KM_DMA_NS32, 0, 0, true>(op.g, tx, ty, bz, smem, xf);
+            else gemm_tile_dma_dev<64, KM_DMA_NS64, 0, 0, true>(op.g, tx, ty, bz, smem, xf);
+        } else if (op.dma) {
             if (op.bm == 32 && op.ns == 8) {
                 if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<32, 8, 0, 0>(op.g, tx, ty, bz, smem);
                 else if (op.ma == 0) gemm_tile_dma_dev<32, 8, 0, 1>(op.g, tx, ty, bz, smem);
@@ -425,6 +456,7 @@ struct Program {
     int64_t scratch_left = 0;
     std::vector<PendingReduce> pend_prev, pend_cur;
     bool allow_split = true;
+    DbXform xf{};                 // copied into every phase's arguments (Phase::xf)
     const float* leaf_lo = nullptr; const float* leaf_hi = nullptr;      // the gradient bucket: outputs inside it may be split along K
     // S for a product of K rows with `tiles` output tiles, or 1
     int min_k = kSplitMinK, chain = 512;
@@ -455,7 +487,7 @@ struct Program {
         ++cur.n_ops;
         if (op_per_launch) { if (int r = launch_cur(dbg_stream)) rc = r; }      // timing aid (option train_op_per_launch): every operation is its own launch, in program order
     }
-    void gemm(const GemmArgs& g_in, int batch) {
+    void gemm(const GemmArgs& g_in, int batch, bool xfa = false) {
         GemmArgs g = g_in;
         const int tiles0 = ((g.N + 63) / 64) * ((g.M + 31) / 32);
         // only a product whose output lies in the gradient bucket may be cut: nothing but the optimizer (and the next phase's
@@ -500,6 +532,13 @@ struct Program {
             return;
         }
         { int ma = 0, mb = 0; op.dma = (use_dma && gemm_dma_ok(g, &ma, &mb)) ? 1 : 0; op.ma = (signed char)ma; op.mb = (signed char)mb; }
+        if (xfa) {
+            if (!(op.dma && op.ma == 0 && op.mb == 0)) {
+                rc = fail(KM_ERR_UNSUPPORTED, "training program: the operand transform needs the LDS-DMA tile with k-contiguous operands");
+                return;
+            }
+            op.dma = 2;
+        }
         op.va = gemm_operand_vec(g.A, g.a_rs, g.a_cs, g.a_bs1, g.a_bs2, g.a_kbs) ? 1 : 0;
         op.vb = gemm_operand_vec(g.B, g.b_cs, g.b_rs, g.b_bs1, g.b_bs2, g.b_kbs) ? 1 : 0;
         if (!op.va) op.vb = 0;                   // three instantiations: (vec, vec), (vec, scalar), (scalar, scalar)
@@ -544,6 +583,7 @@ struct Program {
                 o.ns = (signed char)gdma::ring_stages(o.bm, alone);
                 need_lds((size_t)gdma::lds_floats(o.bm, o.ns) * sizeof(float));
             }
+            cur.xf = xf;
             if (has_attn) hipLaunchKernelGGL(phase_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, cur);
             else hipLaunchKernelGGL(phase_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, st, cur);
             HIP_TRY(hipGetLastError());
@@ -664,12 +704,13 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     float* w = c->trp_act;
     auto take = [&](int64_t n) { float* p = w; w += (n + 3) / 4 * 4; return p; };
     float* xp = take(c->tr_windows * KP * NKk);            // first: km_train_step_audio writes the packed input here
+    float* x2 = take(c->tr_windows * KP * NKk);            // ... as 10 log10(power) when the front end packs (asrc->packed): the finished features
     // fixed part
     float* Qb = take(28 * d); float* dQb = take(28 * d);
     float* T1m = take(d * d); float* T1e = take(d * d); float* Wfm = take(DH * d); float* Wfe = take(DH * d);
     float* t1m = take(d); float* t1e = take(d); float* bfm = take(DH); float* bfe = take(DH);
     float* ones = take(c->tr_windows * NKk);
-    float* WceP = take(d * KP);                             // channel encoder weight with rows padded to KP (zeros), rebuilt every step
+    float* WceP = c->trp_wcep;                             // channel encoder weight with rows padded to KP (zeros), kept beside the parameters (PaddedCopy, km_train.hip)
     // per-window part
     float* Y0 = take(R * d); float* Y = take(R * d); float* mu = take(R); float* rs = take(R);
     float* KV = take(R * 2 * d);
@@ -695,7 +736,6 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     const unsigned char* m_emo = drop ? ms.emo : nullptr;
     const unsigned char* m_dec = drop ? ms.dec : nullptr;
 
-    const float* Wce = P("mel_channel_encoder.weight");
     const float* inw = P("mel_attention.in_proj_weight"); const float* inb = P("mel_attention.in_proj_bias");
     const float* einw = P("emotion_attention.in_proj_weight"); const float* einb = P("emotion_attention.in_proj_bias");
     const float* Wo = P("mel_attention.out_proj.weight"); const float* bo = P("mel_attention.out_proj.bias");
@@ -745,7 +785,11 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     // ================= P0: what the channel encoder waits for and nothing else: packed input, padded weight =================
     // (the gradient bucket, the ones vector and the dropout masks are first read in P4 / P8: they are made in P3 / P4, behind
     // those phases' own work, where they cost nothing -- P0 7.6 -> 5 us at 8 windows)
-    if (asrc) {                                // from audio: the power-mel of the front end -> packed log-mel rows (read by P1)
+    if (asrc && asrc->packed) {
+        // the front end wrote 10 log10(power) into the packed rows itself (MelArgs::pack_*); the channel encoder finishes the
+        // conversion on its operand fragments (DbXform).  With the padded weight kept beside the parameters (PaddedCopy) phase 0
+        // is empty: one launch less per step
+    } else if (asrc) {                         // from audio: the power-mel of the front end -> packed log-mel rows (read by P1)
         ElemArgs e{};
         e.p0 = asrc->melpow; e.p1 = reinterpret_cast<const float*>(asrc->melmax); e.q0 = const_cast<float*>(xp_dev); e.n0 = B;
         e.i0 = (int)NKk; e.i1 = (int)KP; e.i2 = (int)T; e.i3 = asrc->n_frames; e.lp = *asrc->lp;
@@ -755,17 +799,14 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         e.p0 = mel; e.p1 = mel_short; e.q0 = xp; e.n0 = B; e.i0 = (int)NKk; e.i1 = (int)KP; e.i2 = (int)T; e.i3 = (int)T_in;
         pg.elem(OP_PACKX, e, blocks256(B * KP * (NKk / 4)));
     }
-    {
-        ElemArgs w{};
-        w.p0 = Wce; w.q0 = WceP; w.n0 = d; w.i0 = (int)KT; w.i1 = (int)KP;
-        pg.elem(OP_PADROWS, w, blocks256(d * KP));
-    }
     const float* X = xp_dev ? xp_dev : xp;
+    const bool xf = asrc && asrc->packed;
+    if (xf) pg.xf = DbXform{*asrc->lp, asrc->melmax};
     RUN(pg.end_phase(st));
     // ================= P1: channel encoder; beside it the input-independent products (Q, T1 = Wmo Wo) and E0 =================
     // (round 4: they used to sit in P0, whose K = 256 tile chains made that phase as long as a product phase for nothing the
     // channel encoder waits for; the emotion chain and the folds run one phase later than before, still ahead of their readers)
-    if (asrc) {       // the window maxima were read in P0: clean slots for the next front-end launch (no memset)
+    if (asrc && !asrc->packed) {       // the window maxima were read in P0: clean slots for the next front-end launch (no memset)
         ElemArgs z{};
         z.q0 = reinterpret_cast<float*>(c->ws_melmax); z.n0 = c->ws_windows;
         pg.elem(OP_ZERO, z, (c->ws_windows + 1023) / 1024);
@@ -776,7 +817,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         // floats on the register tile (scalar loads): 12 us of the 8-window step
         GemmArgs g = NT(X, KP, WceP, KP, Y0, d, NKk, d, P("mel_channel_encoder.bias"), 0);
         g.a_bs1 = KP * NKk; g.c_bs1 = NKk * d;
-        pg.gemm(g, (int)B);
+        pg.gemm(g, (int)B, xf);       // xf: X holds 10 log10(power), finished on the fragments
     }
     pg.gemm(NT(P("mouth_queries"), d, inw, d, Qb, d, 28, d, inb, 0), 1);                                  // Q = mq Wq^T + bq
     pg.gemm(NN(Wmo, d, Wo, d, T1m, d, d, d, d), 1);                                                        // T1 = Wmo Wo
@@ -786,6 +827,14 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     pg.gemm(NT(emo, ED, P("emotion_encoder.weight"), ED, E0, d, B, d, P("emotion_encoder.bias"), 0), 1);
     RUN(pg.end_phase(st));
     // ================= P2: LayerNorm (both streams); folds Wf = W1 T1 =================
+    if (xf) {      // the packed rows once more, finished into x2 for the channel encoder's weight gradient (phase 12).  Here, not beside the
+        // channel encoder in phase 1: its workgroups held tile slots (the phase's LDS size) while they streamed -- +3.2 us at 64 windows
+        ElemArgs e{};
+        e.p0 = X; e.p1 = reinterpret_cast<const float*>(asrc->melmax); e.q0 = x2; e.n0 = B; e.i0 = (int)NKk; e.i1 = (int)KP; e.i2 = (int)T;
+        e.lp = *asrc->lp;
+        e.i3 = (int)((NKk * (KP / 4) + 1023) / 1024);
+        pg.elem(OP_DBCONV, e, B * e.i3);
+    }
     {
         ElemArgs e{};
         e.p0 = Y0; e.q0 = Y; e.n0 = R; e.i0 = (int)d; e.p1 = P("mel_norm.weight"); e.p2 = P("mel_norm.bias"); e.q1 = mu; e.q2 = rs;
@@ -802,6 +851,12 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     { GemmArgs g = G(W1, d, 1, t1e, 1, 0, bfe, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }
     RUN(pg.end_phase(st));
     // ================= P3: [K | V]; emotion value projection =================
+    if (xf) {          // the window maxima were read by phases 1 and 2 (DbXform, OP_DBCONV): clean slots for the next front-end launch
+        ElemArgs z{};
+        z.q0 = reinterpret_cast<float*>(c->ws_melmax); z.n0 = c->ws_windows;
+        pg.elem(OP_ZERO, z, (c->ws_windows + 1023) / 1024);
+        c->melmax_dirty = false;
+    }
     pg.gemm(NT(Y, d, inw + d * d, d, KV, 2 * d, R, 2 * d, inb + d, 0), 1);
     pg.gemm(NT(E, d, einw + 2 * d * d, d, Ve, d, B, d, einb + 2 * d, 0), 1);
     // the dropout masks of the step (first read in P4), behind the phase's own work in dispatch order
@@ -960,7 +1015,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     // the long chains of large batches)
     const int min_k_saved = pg.min_k;
     if (pg.min_k < 1024) pg.min_k = 1024;
-    pg.gemm(TN(dY0, d, X, KP, Gd("mel_channel_encoder.weight"), KT, d, KT, R), 1);
+    pg.gemm(TN(dY0, d, xf ? x2 : X, KP, Gd("mel_channel_encoder.weight"), KT, d, KT, R), 1);
     colsum(dY0, R, d, d, Gd("mel_channel_encoder.bias"), 0, ones);
     colsum(Tm, R, d, d, Gd("mel_norm.weight"), 0, ones);
     colsum(dY, R, d, d, Gd("mel_norm.bias"), 0, ones);

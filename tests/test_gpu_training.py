@@ -324,6 +324,40 @@ def test_train_step_from_audio_leaves_clean_window_maxima():
     assert torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("B,L", [(8, 136448), (5, 136000), (3, 20000), (2, 1200)])
+def test_front_end_packed_input_agrees_with_the_phase_0_conversion(B, L):
+    """Round 4: km_train_step_audio's front-end launch writes 10 log10(power) straight into the channel encoder's packed input
+    (MelArgs::pack_*), the channel encoder's tile finishes the dB conversion on its operand fragments (DbXform) and the padded
+    channel-encoder weight is kept beside the parameters by AdamW (PaddedCopy) -- phase 0 of the program is gone.  Option
+    train_no_fe_pack brings the phase-0 conversion back: same power-mel, same operations in the same order, but the compiler
+    contracts 10 log10(s) - ref into one fma where both sit in one function -- the two paths differ in the last bit of some
+    features (observed: gradients to 3e-7 of their maximum, losses equal).  Also after three optimizer steps (PaddedCopy).
+    L = 136000: 256 frames (no 257th); 20000 / 1200: fewer frames than the window -- those take the phase-0 path in both runs."""
+    params = synth.make_core_params(31, style="trained")
+    shapes = {k: v.shape for k, v in params.items()}
+    audio = [dev(synth.make_audio(300 + i, B, L)) for i in range(3)]
+    emo = dev(synth.normal(310, (B, 256)))
+    target = dev(synth.uniform(311, (B, 52), 0, 1))
+    res = []
+    for no_pack in (0, 1):
+        e = Engine()
+        e.load_state_dict(params)
+        e.finalize()
+        e.set_option("train_no_fe_pack", no_pack)
+        tr = Trainer(e, max_windows=8, lr=1e-3, dropout=0.1)
+        tr.set_dropout(0.1, seed=5)
+        losses = [float(tr.step(a, emo, target).item()) for a in audio]
+        loss = float(tr.forward_backward(audio[0], emo, target).item())
+        res.append((losses, loss, tr.flat_grad.clone(), tr.params(shapes)))
+    np.testing.assert_allclose(res[0][0] + [res[0][1]], res[1][0] + [res[1][1]], rtol=2e-6)
+    g0, g1 = res[0][2].cpu().numpy(), res[1][2].cpu().numpy()
+    assert np.abs(g0 - g1).max() <= 2e-5 * np.abs(g1).max()
+    for k in shapes:          # three AdamW steps at lr 1e-3: a sign-like update, so compare to a fraction of the step
+        assert np.abs(res[0][3][k] - res[1][3][k]).max() <= 3e-4, k
+    if L < 136000:
+        assert torch.equal(res[0][2], res[1][2])
+
+
 def test_split_k_gradient_products_agree_with_the_unsplit_step():
     """64 windows: the gradient products over all rows of the batch (K = 80 B, 28 B, 24 B > 512) are cut along K into partial
     products summed by the next phase (km_trainp.hip, Program::gemm).  Same gradients as the unsplit program (option
