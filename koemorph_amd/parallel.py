@@ -39,6 +39,15 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def collectives_active() -> bool:
+    """A process group with more than one rank -- or with ONE rank and KM_COLLECTIVES_AT_WORLD_1=1: the bring-up switch that
+    sends the step's collectives through the backend anyway, so that a 1-GPU box runs RCCL's all-reduce / all-gather on the
+    step's own tensors and streams (tests/test_gpu_parallel.py; a sum over one rank leaves every bit as it was)."""
+    if not dist.is_initialized():
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("KM_COLLECTIVES_AT_WORLD_1", "0") == "1"
+
+
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [lo, hi) of n items for `rank`: sizes differ by at most one, earlier ranks get the extras."""
     base, extra = divmod(n, world)
@@ -97,7 +106,7 @@ def sequence_apply(engine, audio: torch.Tensor, emotion: torch.Tensor, stride_fr
     a first-order recurrence along the frame axis -- runs once over the gathered (B, N, 52).  Every rank returns the full
     sequence; it is bit-identical to the single-rank result because every window is computed by the same kernels from the same
     samples whichever sub-clip it is addressed in."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not collectives_active():
         return engine.sequence_forward(audio, emotion, stride_frames, smooth=smooth)
     rank, world = dist.get_rank(), dist.get_world_size()
     B, L = audio.shape
@@ -189,7 +198,7 @@ def allreduce_gradients(flat_grad: torch.Tensor, average: bool = True, weight: O
     without it the ranks are assumed to hold equal shares and the sum is divided by the world size."""
     if weight is not None:
         flat_grad.mul_(float(weight))
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if collectives_active():
         _sum_over_ranks(flat_grad)
         if average and weight is None:
             flat_grad.div_(dist.get_world_size())

@@ -277,7 +277,7 @@ class Trainer:
     def optimizer_step(self, weight: Optional[float] = None):
         """All-reduce + clip + AdamW.  ``weight`` = this rank's windows / windows of the global batch when the ranks'
         shares differ (see parallel.allreduce_gradients); None = equal shares."""
-        if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        if parallel.collectives_active():
             self._allreduce_two_piece(weight, overlap=self._last_was_step)  # the ONE exchange of the training step
         elif weight is not None:
             self.flat_grad.mul_(float(weight))

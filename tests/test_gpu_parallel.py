@@ -217,3 +217,50 @@ def test_two_rank_sequence_mode_is_bit_identical_to_one_rank():
     for rank, res in out:
         assert res[1] == ((2, 10, 52), True), (rank, res)
         assert res[3] == ((2, 7, 52), True), (rank, res)
+
+
+def _worker_rccl(q, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      KM_COLLECTIVES_AT_WORLD_1="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from koemorph_amd import parallel
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    assert parallel.collectives_active() and dist.get_backend() == "nccl"
+    synth, eng, tr, audio, emo, target = _setup(8)
+    losses = [float(tr.step(audio, emo, target).item()) for _ in range(3)]          # two-piece all-reduce, first piece on the side stream
+    shapes = {k: v.shape for k, v in synth.make_core_params(3, style="trained").items()}
+    params = tr.params(shapes)
+    # the opt-in exchange (all_to_all_single + all_gather_into_tensor) on a bucket-sized device tensor
+    t = torch.arange(tr.n_params, dtype=torch.float32, device="cuda")
+    parallel.allreduce_sum_direct(t)
+    direct_ok = bool(torch.equal(t, torch.arange(tr.n_params, dtype=torch.float32, device="cuda")))
+    # sequence mode: chunk + all_gather + one EMA scan
+    clip = torch.from_numpy(synth.make_audio(9, 1, 136448 + 40 * 533)).cuda()
+    seq = parallel.sequence_apply(eng, clip, emo[:1], stride_frames=4).cpu().numpy()
+    q.put((losses, params, direct_ok, seq))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_group_runs_the_steps_collectives_on_the_gpu():
+    """RCCL itself (backend "nccl"), on the one GPU of this box: a process group of ONE rank with KM_COLLECTIVES_AT_WORLD_1=1
+    sends the training step's two-piece gradient all-reduce (first piece on the side stream behind km_train_wait_early), the
+    direct all-to-all form and sequence mode's all_gather through the library on the step's own device tensors.  A sum over one
+    rank changes nothing: losses, weights and frames must be the bits of a run without a process group."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl, args=(q, _free_port()))
+    p.start()
+    losses, params, direct_ok, seq = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0
+    assert direct_ok
+    synth, eng, tr, audio, emo, target = _setup(8)
+    ref_losses = [float(tr.step(audio, emo, target).item()) for _ in range(3)]
+    assert losses == ref_losses
+    ref = tr.params({k: v.shape for k, v in synth.make_core_params(3, style="trained").items()})
+    for k in ref:
+        assert np.array_equal(params[k], ref[k]), k
+    clip = torch.from_numpy(synth.make_audio(9, 1, 136448 + 40 * 533)).cuda()
+    ref_seq = eng.sequence_forward(clip, emo[:1], 4).cpu().numpy()
+    assert np.array_equal(seq, ref_seq)
