@@ -110,6 +110,88 @@ __device__ __forceinline__ void stage_to_lds(int n, Src src, Dst dst) {
 }
 
 // vb / tid: block and thread index of the operation's 256-thread block
+// LayerNorm of one row by one wave.  NP = d / 64 values per lane held in registers: every load of the row is in flight at once
+// (as three loops over the row with a run-time trip count the first one was d / 64 dependent L2 round trips); NP = 0: any d,
+// the loops.  Lane l owns elements l, l + 64, ... and adds them in that order either way: the same bits.
+template <int NP>
+__device__ __forceinline__ void ln_fwd_row(const ElemArgs& a, int64_t row, int lane) {
+    const int d = a.i0;
+    const float* p = a.p0 + row * d;
+    constexpr int NR = NP > 0 ? NP : 1;
+    float x[NR], gm[NR], bt[NR];
+    float s = 0.f;
+    if constexpr (NP > 0) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) { x[u] = p[lane + 64 * u]; gm[u] = a.p1[lane + 64 * u]; bt[u] = a.p2[lane + 64 * u]; }
+#pragma unroll
+        for (int u = 0; u < NP; ++u) s += x[u];
+    } else {
+        for (int i = lane; i < d; i += 64) s += p[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / d;
+    float v = 0.f;
+    if constexpr (NP > 0) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) { const float t = x[u] - mean; v += t * t; }
+    } else {
+        for (int i = lane; i < d; i += 64) { const float t = p[i] - mean; v += t * t; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float rstd = 1.0f / sqrtf(v / d + 1e-5f);
+    if constexpr (NP > 0) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) a.q0[row * d + lane + 64 * u] = (x[u] - mean) * rstd * gm[u] + bt[u];
+    } else {
+        for (int i = lane; i < d; i += 64) a.q0[row * d + i] = (p[i] - mean) * rstd * a.p1[i] + a.p2[i];
+    }
+    if (lane == 0) { a.q1[row] = mean; a.q2[row] = rstd; }
+}
+
+template <int NP>
+__device__ __forceinline__ void ln_bwd_row(const ElemArgs& a, int64_t row, int lane) {
+    const int d = a.i0;
+    const float mu = a.p3[row], rs = a.p4[row];
+    constexpr int NR = NP > 0 ? NP : 1;
+    float dy[NR], xh[NR], gm[NR];
+    float s1 = 0.f, s2 = 0.f;
+    if constexpr (NP > 0) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) { dy[u] = a.p0[row * d + lane + 64 * u]; xh[u] = a.p1[row * d + lane + 64 * u]; gm[u] = a.p2[lane + 64 * u]; }
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            xh[u] = (xh[u] - mu) * rs;
+            const float dxh = dy[u] * gm[u];
+            s1 += dxh; s2 += dxh * xh[u];
+        }
+    } else {
+        for (int i = lane; i < d; i += 64) {
+            const float x = (a.p1[row * d + i] - mu) * rs, dxh = a.p0[row * d + i] * a.p2[i];
+            s1 += dxh; s2 += dxh * x;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    s1 /= d; s2 /= d;
+    if constexpr (NP > 0) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const float dxh = dy[u] * gm[u];
+            a.q0[row * d + lane + 64 * u] = rs * (dxh - s1 - xh[u] * s2);
+            a.q1[row * d + lane + 64 * u] = dy[u] * xh[u];                     // column sums of this image = d gamma (a GEMM with a ones vector)
+        }
+    } else {
+        for (int i = lane; i < d; i += 64) {
+            const float dyv = a.p0[row * d + i];
+            const float x = (a.p1[row * d + i] - mu) * rs, dxh = dyv * a.p2[i];
+            a.q0[row * d + i] = rs * (dxh - s1 - x * s2);
+            a.q1[row * d + i] = dyv * x;
+        }
+    }
+}
+
 // p[0] + p[stride] + ... in index order, eight loads in flight at a time (as a plain loop this is one dependent L2 round trip per
 // term: the 64 per-window parts of dQ took 17.5 us at 64 windows, more than any product of their phase)
 __device__ __forceinline__ float sum_rows_in_order(const float* p, int64_t stride, int n) {
@@ -225,40 +307,16 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
         const int64_t row = (int64_t)vb * 4 + wv;
         const int d = a.i0;
         if (row >= a.n0) break;
-        const float* p = a.p0 + row * d;
-        float s = 0.f;
-        for (int i = lane; i < d; i += 64) s += p[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        const float mean = s / d;
-        float v = 0.f;
-        for (int i = lane; i < d; i += 64) { const float t = p[i] - mean; v += t * t; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        const float rstd = 1.0f / sqrtf(v / d + 1e-5f);
-        for (int i = lane; i < d; i += 64) a.q0[row * d + i] = (p[i] - mean) * rstd * a.p1[i] + a.p2[i];
-        if (lane == 0) { a.q1[row] = mean; a.q2[row] = rstd; }
+        if (d == 256) ln_fwd_row<4>(a, row, lane); else if (d == 512) ln_fwd_row<8>(a, row, lane);
+        else if (d == 64) ln_fwd_row<1>(a, row, lane); else ln_fwd_row<0>(a, row, lane);
         break;
     }
     case OP_LN_BWD: {       // dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)), dxhat = dy gamma; out of place
         const int64_t row = (int64_t)vb * 4 + wv;
         const int d = a.i0;
         if (row >= a.n0) break;
-        const float mu = a.p3[row], rs = a.p4[row];
-        float s1 = 0.f, s2 = 0.f;
-        for (int i = lane; i < d; i += 64) {
-            const float xh = (a.p1[row * d + i] - mu) * rs, dxh = a.p0[row * d + i] * a.p2[i];
-            s1 += dxh; s2 += dxh * xh;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-        s1 /= d; s2 /= d;
-        for (int i = lane; i < d; i += 64) {
-            const float dyv = a.p0[row * d + i];
-            const float xh = (a.p1[row * d + i] - mu) * rs, dxh = dyv * a.p2[i];
-            a.q0[row * d + i] = rs * (dxh - s1 - xh * s2);
-            a.q1[row * d + i] = dyv * xh;                     // column sums of this image = d gamma (a GEMM with a ones vector)
-        }
+        if (d == 256) ln_bwd_row<4>(a, row, lane); else if (d == 512) ln_bwd_row<8>(a, row, lane);
+        else if (d == 64) ln_bwd_row<1>(a, row, lane); else ln_bwd_row<0>(a, row, lane);
         break;
     }
     case OP_RELU_OUTER: {   // dHpre[r][m] = g[r] w2[m] scale [H[r][m] > 0]; H is post-ReLU, post-dropout (H > 0 <=> kept and active)
