@@ -1031,8 +1031,6 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     pg.gemm(TN(dOe1, d, Ae, d, Gd("emotion_attention.out_proj.weight"), d, d, d, Re), 1);
     colsum(dO1, Rm, d, d, Gd("mel_attention.out_proj.bias"), 0, ones);
     colsum(dOe1, Re, d, d, Gd("emotion_attention.out_proj.bias"), 0, ones);
-    pg.gemm(TN(dVe, d, E, d, gein_w + 2 * d * d, d, d, d, B), 1);                                           // only the V third of in_proj
-    colsum(dVe, B, d, d, gein_b + 2 * d, 0, ones);
     pg.gemm(NN(dVe, d, einw + 2 * d * d, d, dE, d, B, d, d), 1);
     // (the parameter gradients of the output projections and of decoder[0]'s emotion rows need nothing of P9: they sit here (behind the products the next phase waits for), where
     // a CU takes five tile workgroups -- the attention blocks' 64 KB of LDS leave room for two in P9)
@@ -1056,6 +1054,11 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     // (with train_split_min_k < 256 or d_model > 1024 the K = d products here would otherwise split)
     const bool allow_split_saved = pg.allow_split;
     pg.allow_split = false;
+    // the emotion value projection's parameter gradients (K = B: never split): moved here from P10, whose 17 operations plus the
+    // reductions of P9's split products (large batches) overflowed the phase's argument block into a second launch (5.8 us at 64
+    // windows)
+    pg.gemm(TN(dVe, d, E, d, gein_w + 2 * d * d, d, d, d, B), 1);                                           // only the V third of in_proj
+    colsum(dVe, B, d, d, gein_b + 2 * d, 0, ones);
     pg.gemm(NN(dQb, d, inw, d, Gd("mouth_queries"), d, 28, d, d), 1);
     pg.gemm(TN(dQb, d, P("mouth_queries"), d, gin_w, d, d, d, 28), 1);       // query rows of in_proj: dWq = dQ^T mq, dbq = column sums of dQ
     colsum(dQb, 28, d, d, gin_b, 0, ones);
