@@ -393,7 +393,10 @@ __device__ __forceinline__ void attend(const f32x4 (&qT)[2][QT], const f32x4 (&k
 #pragma unroll
             for (int kt = 0; kt < KW; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { S[kt][qt][r] = expf(S[kt][qt][r] - m); sum += S[kt][qt][r]; }
+                for (int r = 0; r < 4; ++r) {       // v_exp_f32 (arguments <= 0; a column without keys: -inf - -inf = NaN, as in torch)
+                    S[kt][qt][r] = __builtin_amdgcn_exp2f((S[kt][qt][r] - m) * 1.44269504088896341f);
+                    sum += S[kt][qt][r];
+                }
             sum += __shfl_xor(sum, 16);
             sum += __shfl_xor(sum, 32);
             const float inv = 1.0f / sum;
