@@ -78,6 +78,7 @@ struct Options {
     int train_no_split = 0;        // 1: no split-K of the long gradient products of the phased training step (A/B)
     int train_dwce_parts = 0;      // > 0: partial sums of the channel-encoder gradient per step (a divisor of the batch; A/B)
     int train_split_min_k = 0;     // > 0: split gradient products longer than this many rows into chains of about this length (A/B; default 1024 / 640)
+    int train_colsum_gemm = 0;     // 1: column sums of the training program as products with a ones vector on the matrix pipe (rounds 2-4a) instead of OP_COLSUM
     int train_no_fe_pack = 0;      // 1: km_train_step_audio converts and packs the power-mel in phase 0 of the program (round 3/4 form) instead of inside the front-end launch
     int train_attn_regs = 0;       // 1: the attention blocks of the training program as the register-staged blocks of round 3 (A/B of the LDS-DMA blocks)
     int train_no_dma = 0;          // 1: the products of the training program run on the register-staged tile only (A/B of the LDS-DMA tile, km_gemm_dma_dev.h)

@@ -47,7 +47,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- operations of a phase ------------------------------------------------------------------------------------
 enum OpKind : int {
-    OP_GEMM = 0, OP_ZERO, OP_FILL, OP_MASKGEN, OP_PACKX, OP_LOGPACK, OP_DBCONV, OP_LN_FWD, OP_LN_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_RELU_OUTER, OP_REDUCE,
+    OP_GEMM = 0, OP_ZERO, OP_FILL, OP_MASKGEN, OP_PACKX, OP_LOGPACK, OP_DBCONV, OP_COLSUM, OP_LN_FWD, OP_LN_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_RELU_OUTER, OP_REDUCE,
     OP_EMO_EXPAND, OP_EMO_REDUCE, OP_REDUCE4, OP_PADROWS
 };
 
@@ -293,6 +293,39 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
             if (e >= n4) break;
             const unsigned r = (e % kp4) * 4;
             dst[e] = make_float4(one(v[u].x, r), one(v[u].y, r + 1), one(v[u].z, r + 2), one(v[u].w, r + 3));
+        }
+        break;
+    }
+    case OP_COLSUM: {       // q0[chunk][c] (+)= sum over the chunk's rows r of w[r] m[r][c]: 16 columns x 16 row groups per workgroup, eight
+        // loads in flight per thread, a fixed-order sum over the row groups.  The bias / LayerNorm-parameter / w2 gradients used to be
+        // products with a ones (or per-row weight) vector on the matrix pipe: 32-row tiles for ONE useful row, 8.6 % of P10's MFMA
+        // time at 64 windows
+        const int n = a.i0, ncg = (n + 15) >> 4, S = a.i2;
+        const int chunk = vb / ncg, cg = vb - chunk * ncg;
+        const int c = 16 * cg + (tid & 15), rg = tid >> 4;
+        const int64_t rows = a.n0, rs = a.i1;
+        const int64_t rpc = (rows + S - 1) / S, lo = chunk * rpc, hi = lo + rpc < rows ? lo + rpc : rows;
+        const int cc = c < n ? c : n - 1;
+        float s = 0.f;
+        for (int64_t r = lo + rg; r < hi; r += 128) {
+            float t[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t rr = r + 16 * u < hi ? r + 16 * u : hi - 1;
+                t[u] = a.p0[rr * rs + cc];
+                w[u] = a.p1 ? a.p1[rr] : 1.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += r + 16 * u < hi ? t[u] * w[u] : 0.f;
+        }
+        smem[tid] = s;
+        __syncthreads();
+        if (rg == 0 && c < n) {
+            float tot = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) tot += smem[16 * g + (tid & 15)];
+            float* o = a.q0 + (int64_t)chunk * n + c;
+            *o = a.i3 ? *o + tot : tot;
         }
         break;
     }
@@ -545,6 +578,40 @@ struct Program {
         ++cur.n_ops;
         if (op_per_launch) { if (int r = launch_cur(dbg_stream)) rc = r; }      // timing aid (option train_op_per_launch): every operation is its own launch, in program order
     }
+    // out (n) (+)= sum_r w[r] m[r][.] (w null: ones) as OP_COLSUM; long sums into the gradient bucket are cut into row chunks whose
+    // partial rows the next phase adds up (the split-K machinery of the products)
+    void colsum(const float* m, int64_t rows, int64_t rs, int64_t n, float* out, int accumulate, const float* w) {
+        const bool leaf = out >= leaf_lo && out < leaf_hi;
+        int S = 1;
+        if (allow_split && leaf && rows > min_k) { S = (int)((rows + chain / 2 - 1) / (chain / 2)); S = S > 16 ? 16 : S; }
+        bool conflict = false;
+        for (const auto& r : pend_prev) conflict = conflict || r.out == out;
+        for (const auto& r : pend_cur) conflict = conflict || r.out == out;
+        if (conflict && !(allow_split && leaf)) { rc = fail(KM_ERR_UNSUPPORTED, "training program: a column sum writes an output with a pending reduction"); return; }
+        ElemArgs e{};
+        e.p0 = m; e.p1 = w; e.q0 = out; e.n0 = rows; e.i0 = (int)n; e.i1 = (int)rs; e.i2 = S; e.i3 = accumulate;
+        if (S > 1 || conflict) {
+            if ((int64_t)S * n + 4 > scratch_left) {
+                if (conflict) { rc = fail(KM_ERR_WORKSPACE, "training program: no room for the partial of a column sum whose output has a pending reduction"); return; }
+                S = 1; e.i2 = 1;
+            } else {
+                float* part = scratch;
+                scratch += ((int64_t)S * n + 3) / 4 * 4; scratch_left -= ((int64_t)S * n + 3) / 4 * 4;
+                pend_cur.push_back({part, out, (int)n, S, accumulate ? 1 : 0});
+                e.q0 = part; e.i3 = 0;
+            }
+        }
+        // behind the phase's products in dispatch order: these short, latency-bound workgroups hold a tile slot each (the phase's
+        // LDS size is every workgroup's) -- in the middle of P10 they made the phase 3 us LONGER at 64 windows, at its end they fill the
+        // drain of the last tiles
+        deferred.push_back({e, (int)(((n + 15) / 16) * S)});
+    }
+    struct DeferredElem { ElemArgs e; int nblocks; };
+    std::vector<DeferredElem> deferred;
+    void flush_deferred() {
+        for (const auto& d : deferred) elem(OP_COLSUM, d.e, d.nblocks, 256 * sizeof(float));
+        deferred.clear();
+    }
     void gemm(const GemmArgs& g_in, int batch, bool xfa = false) {
         GemmArgs g = g_in;
         const int tiles0 = ((g.N + 63) / 64) * ((g.M + 31) / 32);
@@ -653,6 +720,7 @@ struct Program {
         return KM_OK;
     }
     int end_phase(hipStream_t st) {
+        flush_deferred();
         add_pending_reduces();
         pend_prev.swap(pend_cur);
         return launch_cur(st);
@@ -827,7 +895,9 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     auto blocks4 = [](int64_t rows) { return (rows + 3) / 4; };            // one wave per row, 4 rows per block
     auto blocks256 = [](int64_t n) { return (n + 255) / 256; };
     // column sums as products with a vector: out (1 x n) (+)= w^T (1 x rows) M (rows x n); w = ones, or per-row loss gradients
+    const bool colsum_valu = !c->opt.train_colsum_gemm;
     auto colsum = [&](const float* m, int64_t rows, int64_t rs_, int64_t n, float* out, int accumulate, const float* wvec) {
+        if (colsum_valu) { pg.colsum(m, rows, rs_, n, out, accumulate, wvec == ones ? nullptr : wvec); return; }
         GemmArgs g = G(wvec, 0, 1, m, rs_, 1, out, n, 1, n, rows);
         g.beta = accumulate ? 1.f : 0.f;
         pg.gemm(g, 1);
