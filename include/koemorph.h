@@ -456,7 +456,9 @@ int km_linear(const float* x_dev, const float* w_dev, const float* b_dev, int64_
  * "legacy_no_enc_fusion" / "legacy_no_attn_fusion" / "legacy_no_tail_fusion" (km_legacy_forward's three fused kernels back to GEMM-chain launches), "train_op_per_launch" (timing aid:
  * every operation of the training program as its own launch), "train_bm32_below", "train_tail_groups", "train_split_min_k",
  * "train_no_dma" (the products of the training program on the register-staged tile instead of the LDS-DMA tile),
- * "train_attn_regs" (its attention blocks register-staged as in round 3).  A handle's switches start from the environment
+ * "train_attn_regs" (its attention blocks register-staged as in round 3), "train_no_fe_pack" (km_train_step_audio converts and
+ * packs the front end's power-mel in phase 0 of the program instead of inside the front-end launch + on the channel encoder's
+ * operand fragments), "train_colsum_gemm" (its column sums as ones-vector products on the matrix pipe).  A handle's switches start from the environment
  * variables KM_<NAME> read ONCE in km_create; no launch path reads the environment.  Unknown name: KM_ERR_INVALID_ARG. */
 int km_set_option(km_handle h, const char* name, int64_t value);
 
