@@ -955,14 +955,12 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     pg.gemm(NT(emo, ED, P("emotion_encoder.weight"), ED, E0, d, B, d, P("emotion_encoder.bias"), 0), 1);
     RUN(pg.end_phase(st));
     // ================= P2: LayerNorm (both streams); folds Wf = W1 T1 =================
-    if (xf) {      // the packed rows once more, finished into x2 for the channel encoder's weight gradient (phase 12).  Here, not beside the
-        // channel encoder in phase 1: its workgroups held tile slots (the phase's LDS size) while they streamed -- +3.2 us at 64 windows
-        ElemArgs e{};
-        e.p0 = X; e.p1 = reinterpret_cast<const float*>(asrc->melmax); e.q0 = x2; e.n0 = B; e.i0 = (int)NKk; e.i1 = (int)KP; e.i2 = (int)T;
-        e.lp = *asrc->lp;
-        e.i3 = (int)((NKk * (KP / 4) + 1023) / 1024);
-        pg.elem(OP_DBCONV, e, B * e.i3);
-    }
+    // (the folds first: their K = d tile chains are the longest thing in the phase and should not wait in the dispatch order behind
+    // the hundreds of row workgroups of the LayerNorm and the conversion)
+    pg.gemm(NN(W1, d, T1m, d, Wfm, d, DH, d, d), 1);                                                        // Wf = W1 T1
+    pg.gemm(NN(W1, d, T1e, d, Wfe, d, DH, d, d), 1);
+    { GemmArgs g = G(W1, d, 1, t1m, 1, 0, bfm, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }     // bf = W1 t1 + b1
+    { GemmArgs g = G(W1, d, 1, t1e, 1, 0, bfe, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }
     {
         ElemArgs e{};
         e.p0 = Y0; e.q0 = Y; e.n0 = R; e.i0 = (int)d; e.p1 = P("mel_norm.weight"); e.p2 = P("mel_norm.bias"); e.q1 = mu; e.q2 = rs;
@@ -973,10 +971,14 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         e.p0 = E0; e.q0 = E; e.n0 = B; e.i0 = (int)d; e.p1 = P("emotion_norm.weight"); e.p2 = P("emotion_norm.bias"); e.q1 = emu; e.q2 = ers;
         pg.elem(OP_LN_FWD, e, blocks4(B));
     }
-    pg.gemm(NN(W1, d, T1m, d, Wfm, d, DH, d, d), 1);                                                        // Wf = W1 T1
-    pg.gemm(NN(W1, d, T1e, d, Wfe, d, DH, d, d), 1);
-    { GemmArgs g = G(W1, d, 1, t1m, 1, 0, bfm, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }     // bf = W1 t1 + b1
-    { GemmArgs g = G(W1, d, 1, t1e, 1, 0, bfe, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }
+    if (xf) {      // the packed rows once more, finished into x2 for the channel encoder's weight gradient (phase 12).  Here, not beside the
+        // channel encoder in phase 1: its workgroups held tile slots (the phase's LDS size) while they streamed -- +3.2 us at 64 windows
+        ElemArgs e{};
+        e.p0 = X; e.p1 = reinterpret_cast<const float*>(asrc->melmax); e.q0 = x2; e.n0 = B; e.i0 = (int)NKk; e.i1 = (int)KP; e.i2 = (int)T;
+        e.lp = *asrc->lp;
+        e.i3 = (int)((NKk * (KP / 4) + 1023) / 1024);
+        pg.elem(OP_DBCONV, e, B * e.i3);
+    }
     RUN(pg.end_phase(st));
     // ================= P3: [K | V]; emotion value projection =================
     if (xf) {          // the window maxima were read by phases 1 and 2 (DbXform, OP_DBCONV): clean slots for the next front-end launch
