@@ -213,10 +213,13 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
     const ElemArgs& a = op.e;
     const int lane = tid & 63, wv = tid >> 6;
     switch (op.kind) {
-    case OP_ZERO: {
-        const int64_t i = ((int64_t)vb * 256 + tid) * 4;
-        if (i + 3 < a.n0) *reinterpret_cast<float4*>(a.q0 + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-        else for (int64_t k = i; k < a.n0; ++k) a.q0[k] = 0.f;
+    case OP_ZERO: {         // 4096 floats per workgroup (four 16-byte stores per thread, each a contiguous 4 KB run of the workgroup)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = ((int64_t)vb * 1024 + u * 256 + tid) * 4;
+            if (i + 3 < a.n0) *reinterpret_cast<float4*>(a.q0 + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            else for (int64_t k = i; k < a.n0; ++k) a.q0[k] = 0.f;
+        }
         break;
     }
     case OP_FILL: {
@@ -381,13 +384,13 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
         break;
     }
     case OP_EMO_EXPAND: {   // Ae[(b, q), c] = Ve[b, c] * keep[b, c / hd, q] / (1 - p): the one-key attention of the emotion stream
-        const int64_t i = (int64_t)vb * 256 + tid;
-        const int d = a.i0, hd = a.i1, H = d / hd;
-        if (i >= a.n0 * 24 * d) break;
-        const int64_t r = i / d; const int cidx = (int)(i - r * d);
-        const int64_t b = r / 24; const int q = (int)(r - b * 24);
-        const float v = a.p0[b * d + cidx];
-        a.q0[i] = a.mask ? (a.mask[(b * H + cidx / hd) * 24 + q] ? v * a.f0 : 0.f) : v;
+        // a workgroup = 256 columns of one (window, query) row: the row is workgroup-uniform (two 64-bit divisions per element before)
+        const int d = a.i0, hd = a.i1, H = d / hd, bpr = (d + 255) >> 8;
+        const int r = vb / bpr, cidx = (vb - r * bpr) * 256 + tid;
+        if (cidx >= d) break;
+        const int b = r / 24, q = r - b * 24;
+        const float v = a.p0[(int64_t)b * d + cidx];
+        a.q0[(int64_t)r * d + cidx] = a.mask ? (a.mask[((int64_t)b * H + cidx / hd) * 24 + q] ? v * a.f0 : 0.f) : v;
         break;
     }
     case OP_EMO_REDUCE: {   // dVe[b, c] = sum_q dAe[(b, q), c] * keep / (1 - p)
@@ -937,7 +940,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     if (asrc && !asrc->packed) {       // the window maxima were read in P0: clean slots for the next front-end launch (no memset)
         ElemArgs z{};
         z.q0 = reinterpret_cast<float*>(c->ws_melmax); z.n0 = c->ws_windows;
-        pg.elem(OP_ZERO, z, (c->ws_windows + 1023) / 1024);
+        pg.elem(OP_ZERO, z, (c->ws_windows + 4095) / 4096);
         c->melmax_dirty = false;
     }
     {   // Y0[b] (NK x d) = XT_b (NK x KP) WceP^T + b: both operands k-contiguous with K = KP a multiple of 32 (zeros beyond KT on
@@ -984,7 +987,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     if (xf) {          // the window maxima were read by phases 1 and 2 (DbXform, OP_DBCONV): clean slots for the next front-end launch
         ElemArgs z{};
         z.q0 = reinterpret_cast<float*>(c->ws_melmax); z.n0 = c->ws_windows;
-        pg.elem(OP_ZERO, z, (c->ws_windows + 1023) / 1024);
+        pg.elem(OP_ZERO, z, (c->ws_windows + 4095) / 4096);
         c->melmax_dirty = false;
     }
     pg.gemm(NT(Y, d, inw + d * d, d, KV, 2 * d, R, 2 * d, inb + d, 0), 1);
@@ -1020,13 +1023,13 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     {
         ElemArgs e{};
         e.p0 = Ve; e.q0 = Ae; e.n0 = B; e.i0 = (int)d; e.i1 = (int)hd; e.mask = m_emo; e.f0 = keep_scale;
-        pg.elem(OP_EMO_EXPAND, e, blocks256(Re * d));
+        pg.elem(OP_EMO_EXPAND, e, Re * ((d + 255) / 256));
     }
     // clean gradient bucket and the ones vector (first touched in P8): they ride under the attention blocks
     {
         ElemArgs e{};
         e.q0 = flat_grad; e.n0 = c->tr_nparams;
-        pg.elem(OP_ZERO, e, (c->tr_nparams + 1023) / 1024);
+        pg.elem(OP_ZERO, e, (c->tr_nparams + 4095) / 4096);
         ElemArgs f{};
         f.q0 = ones; f.n0 = R; f.f0 = 1.0f;
         pg.elem(OP_FILL, f, blocks256(R));
@@ -1077,6 +1080,16 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     colsum(dH1, Rm, DH, DH, Gd("blendshape_decoder.0.bias"), 0, ones);
     RUN(pg.end_phase(st));
     // ================= P9: attention backward per (window, head); emotion value gradient; output projections; decoder[0] weight =================
+    // Dispatch order: with fewer attention blocks than CUs (8 windows) they go first -- they are the phase's longest workgroups; from
+    // 256 blocks on they would take every LDS slot of the chip (53 KB each, three per CU) and the products would run BEHIND them instead
+    // of beside them: products first (64 windows: 0.2311 -> 0.2292 ms; 8 windows the other way round: 0.1289 against 0.1296)
+    const bool p9_products_first = B * H >= 256;
+    auto p9_products = [&]() {
+        pg.gemm(NN(dO2, d, Wmo, d, dO1, d, Rm, d, d), 1);
+        pg.gemm(NN(dOe2, d, Weo, d, dOe1, d, Re, d, d), 1);
+        pg.gemm(TN(dH1, DH, O2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, Rm), 1);
+    };
+    if (p9_products_first) p9_products();
     {
         ElemArgs e{};
         e.p0 = Qb; e.p1 = KV; e.p2 = Pm; e.p3 = dA; e.q0 = dKV; e.q1 = dQ_part; e.i0 = (int)d; e.i1 = (int)hd; e.i2 = (int)NKk; e.i3 = (int)H;
@@ -1089,9 +1102,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         e.p0 = dAe; e.q0 = dVe; e.n0 = B; e.i0 = (int)d; e.i1 = (int)hd; e.mask = m_emo; e.f0 = keep_scale;
         pg.elem(OP_EMO_REDUCE, e, blocks256(B * d));
     }
-    pg.gemm(NN(dO2, d, Wmo, d, dO1, d, Rm, d, d), 1);
-    pg.gemm(NN(dOe2, d, Weo, d, dOe1, d, Re, d, d), 1);
-    pg.gemm(TN(dH1, DH, O2, d, Gd("blendshape_decoder.0.weight"), d, DH, d, Rm), 1);
+    if (!p9_products_first) p9_products();
     colsum(He, Re, DH, DH, Gd("blendshape_decoder.3.weight"), 1, grow + Rm);
     RUN(pg.end_phase(st));
     // ================= P10: dY; in_proj [K | V] gradients; dQ; out_proj gradients; emotion value projection backward =================
