@@ -1,6 +1,7 @@
 // Loss tail of the training step (decoder output -> prediction -> KoeMorphLoss -> dL/dz), shared by the launch-per-op
 // chain (km_train.hip) and the phased step (km_trainp.hip).  Included inside namespace km of a .hip translation unit.
 #pragma once
+#include "km_gridsync.h"
 
 __device__ __forceinline__ int tr_mouth_slot(int i) { return (i >= 14 && i <= 40) ? i - 14 : (i == 51 ? 27 : -1); }
 // blendshape index -> expression query slot 0..23 (EXPRESSION_INDICES = 0..13, 41..50; dual_stream_attention.py:14-45)
@@ -569,8 +570,10 @@ __device__ __forceinline__ void train_tail_window_dev(const TailArgs& a, float* 
         const float mine = i < 52 ? dws : (i == 52 ? loss_wg : (i == 53 ? dal_wg : (i == 54 ? db2_wg : 0.f)));
         tot_s[i] = mine;
         if (G > 1) {
-            a.part[(int64_t)b * 64 + i] = mine;
-            __threadfence();
+            // write-through store + drain instead of a release fence (the fence writes the L2 back; km_gridsync.h has the protocol):
+            // the last workgroup acquires below
+            kmsync::st_wt(a.part + (int64_t)b * 64 + i, mine);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
     __syncthreads();
@@ -588,7 +591,7 @@ __device__ __forceinline__ void train_tail_window_dev(const TailArgs& a, float* 
     if (w == 0) {
         float v = tot_s[i];
         if (G > 1) {
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             v = 0.f;
             // the windows' sums in window order, eight loads in flight at a time (one dependent load per window made this loop
             // half of the tail at 64 windows: 25 us)
