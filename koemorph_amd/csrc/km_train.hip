@@ -281,6 +281,24 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     // wave, then the four wave sums in wave order), so all blocks agree bit for bit
     __shared__ float sh[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // One group of four consecutive parameters per thread (818 workgroups for the 837 744 parameters: 8.3 us; four groups per thread --
+    // 205 workgroups, one round of the chip -- measured 11.1 us: the kernel is bound by the square root + two divisions per parameter,
+    // not by its workgroup count).  Parameters, moments and gradients are requested FIRST: their round trip runs beside the norm's
+    // (partials -> butterfly -> barrier) instead of behind it.
+    constexpr int GR = 1;
+    int64_t i0[GR];
+    bool whole[GR];
+    float4 p4[GR], m4[GR], v4[GR], g4[GR];
+#pragma unroll
+    for (int u = 0; u < GR; ++u) {
+        i0[u] = ((int64_t)blockIdx.x * (256 * GR) + u * 256 + tid) * 4;
+        whole[u] = i0[u] + 3 < n && (alpha_idx < i0[u] || alpha_idx > i0[u] + 3) && (reinterpret_cast<uintptr_t>(g) & 15) == 0;
+        p4[u] = m4[u] = v4[u] = g4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (whole[u]) {
+            p4[u] = *reinterpret_cast<const float4*>(p + i0[u]); m4[u] = *reinterpret_cast<const float4*>(m + i0[u]);
+            v4[u] = *reinterpret_cast<const float4*>(v + i0[u]); g4[u] = *reinterpret_cast<const float4*>(g + i0[u]);
+        }
+    }
     float s = part[tid];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -302,8 +320,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
         scale = c < 1.f ? c : 1.f;
     }
     const float bc1_all = sh[4], bc2_all = sh[5];
-    const int64_t i0 = ((int64_t)blockIdx.x * 256 + tid) * 4;      // four consecutive parameters per thread
-    if (i0 >= n) return;
     auto update = [&](float& pi, float& mi, float& vi, float gi, float bc1, float bc2) {
         gi *= scale;
         pi *= (1.0f - lr * wd);
@@ -312,34 +328,34 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
         const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
         pi -= (lr / bc1) * mi / denom;
     };
-    const bool whole = i0 + 3 < n && (alpha_idx < i0 || alpha_idx > i0 + 3) && (reinterpret_cast<uintptr_t>(g) & 15) == 0;
-    if (whole) {
-        float4 p4 = *reinterpret_cast<const float4*>(p + i0), m4 = *reinterpret_cast<const float4*>(m + i0);
-        float4 v4 = *reinterpret_cast<const float4*>(v + i0);
-        const float4 g4 = *reinterpret_cast<const float4*>(g + i0);
-        update(p4.x, m4.x, v4.x, g4.x, bc1_all, bc2_all);
-        update(p4.y, m4.y, v4.y, g4.y, bc1_all, bc2_all);
-        update(p4.z, m4.z, v4.z, g4.z, bc1_all, bc2_all);
-        update(p4.w, m4.w, v4.w, g4.w, bc1_all, bc2_all);
-        *reinterpret_cast<float4*>(p + i0) = p4;
-        *reinterpret_cast<float4*>(m + i0) = m4;
-        *reinterpret_cast<float4*>(v + i0) = v4;
-        pc.put(i0, p4.x); pc.put(i0 + 1, p4.y); pc.put(i0 + 2, p4.z); pc.put(i0 + 3, p4.w);
-        return;
-    }
-    for (int64_t i = i0; i < n && i < i0 + 4; ++i) {
-        float bc1 = bc1_all, bc2 = bc2_all;
-        if (i == alpha_idx) {
-            // smoothing_alpha is outside the autograd graph whenever the EMA passes its input through: no decay, no moment
-            // update, its own step counter
-            if (!alpha_live) continue;
-            const int t = steps[1];
-            bc1 = 1.0f - powf(b1, (float)t); bc2 = 1.0f - powf(b2, (float)t);
+#pragma unroll
+    for (int u = 0; u < GR; ++u) {
+        if (i0[u] >= n) continue;
+        if (whole[u]) {
+            update(p4[u].x, m4[u].x, v4[u].x, g4[u].x, bc1_all, bc2_all);
+            update(p4[u].y, m4[u].y, v4[u].y, g4[u].y, bc1_all, bc2_all);
+            update(p4[u].z, m4[u].z, v4[u].z, g4[u].z, bc1_all, bc2_all);
+            update(p4[u].w, m4[u].w, v4[u].w, g4[u].w, bc1_all, bc2_all);
+            *reinterpret_cast<float4*>(p + i0[u]) = p4[u];
+            *reinterpret_cast<float4*>(m + i0[u]) = m4[u];
+            *reinterpret_cast<float4*>(v + i0[u]) = v4[u];
+            pc.put(i0[u], p4[u].x); pc.put(i0[u] + 1, p4[u].y); pc.put(i0[u] + 2, p4[u].z); pc.put(i0[u] + 3, p4[u].w);
+            continue;
         }
-        float pi = p[i], mi = m[i], vi = v[i];
-        update(pi, mi, vi, g[i], bc1, bc2);
-        p[i] = pi; m[i] = mi; v[i] = vi;
-        pc.put(i, pi);
+        for (int64_t i = i0[u]; i < n && i < i0[u] + 4; ++i) {
+            float bc1 = bc1_all, bc2 = bc2_all;
+            if (i == alpha_idx) {
+                // smoothing_alpha is outside the autograd graph whenever the EMA passes its input through: no decay, no moment
+                // update, its own step counter
+                if (!alpha_live) continue;
+                const int t = steps[1];
+                bc1 = 1.0f - powf(b1, (float)t); bc2 = 1.0f - powf(b2, (float)t);
+            }
+            float pi = p[i], mi = m[i], vi = v[i];
+            update(pi, mi, vi, g[i], bc1, bc2);
+            p[i] = pi; m[i] = mi; v[i] = vi;
+            pc.put(i, pi);
+        }
     }
 }
 
