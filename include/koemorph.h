@@ -458,7 +458,8 @@ int km_linear(const float* x_dev, const float* w_dev, const float* b_dev, int64_
  * "train_no_dma" (the products of the training program on the register-staged tile instead of the LDS-DMA tile),
  * "train_attn_regs" (its attention blocks register-staged as in round 3), "train_no_fe_pack" (km_train_step_audio converts and
  * packs the front end's power-mel in phase 0 of the program instead of inside the front-end launch + on the channel encoder's
- * operand fragments), "train_colsum_gemm" (its column sums as ones-vector products on the matrix pipe).  A handle's switches start from the environment
+ * operand fragments), "train_colsum_gemm" (its column sums as ones-vector products on the matrix pipe), "train_no_ln_fuse" (a LayerNorm phase
+ * instead of LayerNorm in the readers of the channel encoder's output) / "train_ln_fuse_rows" (the batch size, in key rows, up to which the readers do it).  A handle's switches start from the environment
  * variables KM_<NAME> read ONCE in km_create; no launch path reads the environment.  Unknown name: KM_ERR_INVALID_ARG. */
 int km_set_option(km_handle h, const char* name, int64_t value);
 

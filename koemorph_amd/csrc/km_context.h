@@ -78,6 +78,8 @@ struct Options {
     int train_no_split = 0;        // 1: no split-K of the long gradient products of the phased training step (A/B)
     int train_dwce_parts = 0;      // > 0: partial sums of the channel-encoder gradient per step (a divisor of the batch; A/B)
     int train_split_min_k = 0;     // > 0: split gradient products longer than this many rows into chains of about this length (A/B; default 1024 / 640)
+    int train_ln_fuse_rows = 0;    // > 0: LayerNorm by the reader up to this many key rows per step (default 1600 = 20 windows of 80 channels)
+    int train_no_ln_fuse = 0;      // 1: the training program keeps its LayerNorm phase (P2) instead of normalising in the readers of Y0 / E0 (LnXform)
     int train_colsum_gemm = 0;     // 1: column sums of the training program as products with a ones vector on the matrix pipe (rounds 2-4a) instead of OP_COLSUM
     int train_no_fe_pack = 0;      // 1: km_train_step_audio converts and packs the power-mel in phase 0 of the program (round 3/4 form) instead of inside the front-end launch
     int train_attn_regs = 0;       // 1: the attention blocks of the training program as the register-staged blocks of round 3 (A/B of the LDS-DMA blocks)

@@ -43,6 +43,23 @@ __device__ __forceinline__ float db_finish_fast(float dbs, float scale, float c1
 // operand transform of a product whose A rows hold 10 log10(power): batch entry z uses the reference ref_bits[z] (float bits)
 struct DbXform { LogParams lp; const unsigned* ref_bits; };
 
+// LayerNorm applied by the READER of a product's output rows (km_trainp.hip, round 4): the producing tiles leave, per row and per 32
+// columns, the mean of those 32 values and their sum of squared deviations from it (`stats`: float2 [row][npart], npart = d / 32);
+// the reader combines the parts (Chan et al.: exact pooling of means and M2, no E[x^2] - mean^2 cancellation), and takes every value
+// through ln_apply on its way to the MFMAs -- or, OP_LNAPPLY, into the stored Y.  Both use these two functions: the same bits.
+struct LnXform { const float* stats; const float* gamma; const float* beta; int npart; float eps; };
+__device__ __forceinline__ void ln_combine(const float2* __restrict__ st, int npart, float eps, float& rs, float& nmurs, float* mean_out = nullptr) {
+    float msum = 0.f;
+    for (int p = 0; p < npart; ++p) msum += st[p].x;
+    const float mean = msum / (float)npart;
+    float m2 = 0.f;
+    for (int p = 0; p < npart; ++p) { const float dm = st[p].x - mean; m2 += st[p].y + 32.0f * dm * dm; }
+    rs = 1.0f / sqrtf(m2 / (float)(32 * npart) + eps);
+    nmurs = -mean * rs;
+    if (mean_out) *mean_out = mean;
+}
+__device__ __forceinline__ float ln_apply(float x, float rs, float nmurs, float gam, float bet) { return fmaf(fmaf(x, rs, nmurs), gam, bet); }
+
 template <int MODE>
 __device__ __forceinline__ float log_one_t(const LogParams& p, float s, float ref_db, float floor_db) {
     if (MODE == KM_LOG_LN_EPS) return 0.693147180559945309f * __builtin_amdgcn_logf(s + p.log_eps);   // src/features/stft.py:123

@@ -168,7 +168,10 @@ struct DmaEpilogue {
                 }
         }
     }
-    __device__ __forceinline__ void finish(const GemmArgs& g, float* C, const f32x4 (&acc)[MT][2], int mw, int nw, int lg, int lj) const {
+    // stats != null: per output row and per 32 columns (this wave's), the mean of the stored values and their sum of squared
+    // deviations from it go to stats[(row_base + row) * npart + nw / 32] (float2) for the rows' reader (km_device.h: LnXform); N % 32 == 0
+    __device__ __forceinline__ void finish(const GemmArgs& g, float* C, const f32x4 (&acc)[MT][2], int mw, int nw, int lg, int lj,
+                                           float* stats = nullptr, int64_t row_base = 0) const {
         const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(C, 0, (unsigned)(((int64_t)(g.M - 1) * g.c_rs + g.N) * 4), 0x00020000);
         const int n_a = nw + lj, n_b = nw + 16 + lj;
         const unsigned oob_a = n_a < g.N ? 0u : 0x80000000u, oob_b = n_b < g.N ? 0u : 0x80000000u;
@@ -220,14 +223,32 @@ struct DmaEpilogue {
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(va[i][r]), rc, o | oob_a, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vb[i][r]), rc, (o + 64u) | oob_b, 0, 0);
             }
+        if (stats) {        // workgroup-uniform
+            const int npart = g.N >> 5;
+            float2* st = reinterpret_cast<float2*>(stats) + row_base * npart + (nw >> 5);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float mean = row16_sum(va[i][r] + vb[i][r]) * (1.0f / 32.0f);      // the 16 lanes of a DPP row hold one output row
+                    const float da = va[i][r] - mean, db = vb[i][r] - mean;
+                    const float m2 = row16_sum(da * da + db * db);
+                    const int row = mw + 16 * i + 4 * lg + r;
+                    if (lj == 0 && row < g.M) st[(int64_t)row * npart] = make_float2(mean, m2);
+                }
+        }
     }
 };
 
 // tile (bx, by) of output batch bz; smem = gdma::lds_floats(BM, NS) floats, 16-byte aligned; NS = 4 or 8 ring stages
 // XFA (xf != null): operand A holds 10 log10(power) rows and every fragment is taken through db_finish() with the reference of
 // output batch entry z1 (km_device.h: DbXform) on its way to the MFMAs
-template <int BM, int NS, int MA, int MB, bool XFA = false>
-__device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int by, int bz, float* smem, const DbXform* xf = nullptr) {
+// XFA == 2 (ln != null): operand A holds rows whose LayerNorm the product reads: the row statistics are pooled from the producer's
+// parts (ln->stats, DmaEpilogue), gamma / beta sit in LDS behind the ring (2 K floats), and every fragment goes through ln_apply().
+// stats != null: this product leaves such parts for ITS output rows (row r of batch entry z1 = row z1 M + r).
+template <int BM, int NS, int MA, int MB, int XFA = 0>
+__device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int by, int bz, float* smem, const DbXform* xf = nullptr,
+                                                  const LnXform* ln = nullptr, float* stats = nullptr) {
     using namespace gdma;
     constexpr int MT = BM / 32, SF = stage_floats(BM), L = BM / 32 + 2;      // L: DMA instructions per thread and stage
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: it enters LDS-DMA destinations
@@ -248,7 +269,9 @@ __device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int
 #pragma unroll
     for (int i = 0; i < MT; ++i) { acc[i][0] = f32x4{0, 0, 0, 0}; acc[i][1] = f32x4{0, 0, 0, 0}; }
     const int kt = g.K / BK;
-    float xscale = 0.f, xc1 = 0.f;      // XFA: set behind the prologue's DMA requests
+    float xscale = 0.f, xc1 = 0.f;      // XFA == 1: set behind the prologue's DMA requests
+    float lrs[MT], lnm[MT];             // XFA == 2: rstd and -mean rstd of this lane's fragment rows
+    float* gb = smem + NS * SF;         //           gamma [K], beta [K]
     KM_TILE_STAMP(1);
     auto issue = [&](int j) {
         float* img = smem + (j % NS) * SF;
@@ -268,17 +291,26 @@ __device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int
             for (int jn = 0; jn < 2; ++jn) bf[jn][kb] = fb.read(Bs, jn, kb);
         }
     };
-    auto mfmas = [&](const f32x4 (&af)[MT][2], const f32x4 (&bf)[2][2]) {
+    auto mfmas = [&](int it, const f32x4 (&af)[MT][2], const f32x4 (&bf)[2][2]) {
+        (void)it;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x4 at[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 at[i] = af[i][kb];
-                if constexpr (XFA) {
+                if constexpr (XFA == 1) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) at[i][q] = db_finish_fast(at[i][q], xscale, xc1);
                 }
+            }
+            if constexpr (XFA == 2) {
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(gb + 32 * it + 16 * kb + 4 * lg);
+                const f32x4 bt = *reinterpret_cast<const f32x4*>(gb + g.K + 32 * it + 16 * kb + 4 * lg);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) at[i][q] = ln_apply(at[i][q], lrs[i], lnm[i], gm[q], bt[q]);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -296,7 +328,7 @@ __device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int
         __builtin_amdgcn_s_barrier();
         issue(it + NS - 1);
         fetch(it + 1, af_n, bf_n);
-        mfmas(af, bf);
+        mfmas(it, af, bf);
         // (measured and dropped: sched_group_barrier patterns pinning one MFMA, one DMA request, one fragment read in turn -- the
         // waits and the barrier cut the step into scheduling regions of their own: 13.4 us against 13.3 at K = 1024)
     };
@@ -310,7 +342,19 @@ __device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int
     // affine) is applied to them in registers, ahead of the MFMAs that consume them (db_finish_fast: 2 vector instructions per
     // value under the matrix pipe) instead of a conversion pass (and a launch) ahead of the product.  The reference is read here, behind the DMA
     // requests: its round trip runs beside the first stage's.
-    if constexpr (XFA) {
+    if constexpr (XFA == 2) {
+        // behind the DMA requests of the prologue: the parts' round trip runs beside the first stage's (ahead of them it was one more
+        // memory round trip in front of every tile)
+        for (int k = tid; k < g.K; k += 256) { gb[k] = ln->gamma[k]; gb[g.K + k] = ln->beta[k]; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // in LDS before the prologue's (raw) barrier
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = m0 + 16 * MT * wm + 16 * i + lj;
+            const int64_t rr = (int64_t)z1 * g.M + (row < g.M ? row : g.M - 1);
+            ln_combine(reinterpret_cast<const float2*>(ln->stats) + rr * ln->npart, ln->npart, ln->eps, lrs[i], lnm[i]);
+        }
+    }
+    if constexpr (XFA == 1) {
         float ref_db, floor_db;
         log_window_consts(xf->lp, __uint_as_float(xf->ref_bits[z1]), ref_db, floor_db);
         xscale = xf->lp.db_scale; xc1 = db_fast_c1(xf->lp, ref_db);
@@ -328,6 +372,6 @@ __device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int
     if (it < kt) step(it, af0, bf0, af1, bf1);
     km_wait_vmcnt<0>();           // the out-of-range stages behind the last one are still writing zeros into the ring
     KM_TILE_STAMP(3);
-    ep.finish(g, C, acc, m0 + 16 * MT * wm, n0 + 32 * wn, lg, lj);
+    ep.finish(g, C, acc, m0 + 16 * MT * wm, n0 + 32 * wn, lg, lj, stats, (int64_t)z1 * g.M);
     __syncthreads();              // the caller may reuse smem (another tile of the same workgroup)
 }

@@ -23,9 +23,9 @@ struct ElemArgs {
     // partial products of the split-K gradient GEMMs of the phase before
     // (separate fields, read through select chains: an array indexed at run time would move the whole kernel argument into
     // scratch memory -- 4 KB per thread and every phase six times slower)
-    int rn0, rn1, rn2, rn3, rS0, rS1, rS2, rS3, racc0, racc1, racc2, racc3;
+    int rn0, rn1, rn2, rn3, rS0, rS1, rS2, rS3, racc;      // racc: bit j = reduction j accumulates into its output
 };
-static_assert(sizeof(ElemArgs) <= 208, "ElemArgs shares a union with GemmArgs");
+static_assert(sizeof(ElemArgs) <= 200, "ElemArgs shares a union with GemmArgs (200 bytes): 17 operations + the phase's shared arguments in 4 KB");
 
 // ---- fused attention blocks of the training step, on the matrix pipe ----------------------------------------------------------
 // One (window, head) per 256-thread workgroup; every product is v_mfma_f32_16x16x4_f32 tiles fed from LDS images: the 28

@@ -48,7 +48,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---- operations of a phase ------------------------------------------------------------------------------------
 enum OpKind : int {
     OP_GEMM = 0, OP_ZERO, OP_FILL, OP_MASKGEN, OP_PACKX, OP_LOGPACK, OP_DBCONV, OP_COLSUM, OP_LN_FWD, OP_LN_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_RELU_OUTER, OP_REDUCE,
-    OP_EMO_EXPAND, OP_EMO_REDUCE, OP_REDUCE4, OP_PADROWS
+    OP_EMO_EXPAND, OP_EMO_REDUCE, OP_REDUCE4, OP_PADROWS, OP_LNAPPLY
 };
 
 
@@ -56,7 +56,8 @@ struct Op {
     int kind;
     int gx, gy;            // OP_GEMM: tiles along N and M (blocks = gx * gy * batch)
     int bm;                // OP_GEMM: tile rows (32 when the product would leave most of the chip idle with 64)
-    short va, vb;          // OP_GEMM: 16-byte loads are legal for operand A / B
+    signed char va, vb;    // OP_GEMM: 16-byte loads are legal for operand A / B
+    signed char ln, pad_;  //          k > 0: the tiles leave LayerNorm parts for their output rows in Phase::ln[k - 1].stats; k < 0: operand A is read through the LayerNorm of Phase::ln[-k - 1] (LnXform, km_device.h)
     signed char dma, ns;   // OP_GEMM: the product runs on the LDS-DMA tile (km_gemm_dma_dev.h) with a ring of ns stages
     signed char ma, mb;    //          its operand modes (0 k-contiguous, 1 row-contiguous)
     union {
@@ -66,12 +67,13 @@ struct Op {
 };
 
 constexpr int kMaxOps = 17;     // 8 + 17 * 4 + 17 * sizeof(Op) stays under the 4 KB kernel-argument limit
-static_assert(sizeof(GemmArgs) <= 208, "Phase has to stay under the 4 KB kernel-argument limit");
+static_assert(sizeof(GemmArgs) <= 200, "Phase has to stay under the 4 KB kernel-argument limit");
 struct Phase {
     int n_ops;
     int block_end[kMaxOps];
     Op ops[kMaxOps];
     DbXform xf;            // operand transform of the products with Op::dma == 2 (the channel encoder on the front end's packed rows)
+    LnXform ln[2];         // LayerNorm-by-the-reader slots (Op::ln): mel rows, emotion rows
 };
 static_assert(sizeof(Phase) <= 4096, "Phase is passed by value: 4 KB of kernel arguments");
 
@@ -339,6 +341,17 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
         a.q0[i] = t < a.i0 ? a.p0[r * a.i0 + t] : 0.f;
         break;
     }
+    case OP_LNAPPLY: {      // y = LayerNorm(x) from the producer's per-row parts (p3: float2 [row][i1]), statistics saved; one wave per row.
+        // The readers that normalise on the fly (gemm_tile_dma_dev XFA == 2) use the same ln_combine / ln_apply: the same bits.
+        const int64_t row = (int64_t)vb * 4 + wv;
+        const int d = a.i0;
+        if (row >= a.n0) break;
+        float rs, nmurs, mean;
+        ln_combine(reinterpret_cast<const float2*>(a.p3) + row * a.i1, a.i1, a.f0, rs, nmurs, &mean);
+        for (int i = lane; i < d; i += 64) a.q0[row * d + i] = ln_apply(a.p0[row * d + i], rs, nmurs, a.p1[i], a.p2[i]);
+        if (lane == 0) { a.q1[row] = mean; a.q2[row] = rs; }
+        break;
+    }
     case OP_LN_FWD: {       // y = LayerNorm(x), statistics saved; one wave per row
         const int64_t row = (int64_t)vb * 4 + wv;
         const int d = a.i0;
@@ -377,7 +390,7 @@ __device__ __forceinline__ void op_elem(const Op& op, int vb, int tid, float* sm
         float* out = j == 0 ? a.q0 : (j == 1 ? a.q1 : (j == 2 ? a.q2 : a.q3));
         const int n = j == 0 ? a.rn0 : (j == 1 ? a.rn1 : (j == 2 ? a.rn2 : a.rn3));
         const int S = j == 0 ? a.rS0 : (j == 1 ? a.rS1 : (j == 2 ? a.rS2 : a.rS3));
-        const int acc = j == 0 ? a.racc0 : (j == 1 ? a.racc1 : (j == 2 ? a.racc2 : a.racc3));
+        const int acc = (a.racc >> j) & 1;
         const int64_t c0 = (int64_t)(vb - base) * 256 + tid;
         if (c0 >= n) break;
         out[c0] = (acc ? out[c0] : 0.f) + sum_rows_in_order(part + c0, n, S);
@@ -480,22 +493,28 @@ __global__ __launch_bounds__(256, ATTN ? KM_TRAINP_WAVES_ATTN : KM_TRAINP_WAVES)
         const int per = op.gx * op.gy;
         const int bz = local / per, t = local - bz * per;
         const int tx = t % op.gx, ty = t / op.gx;
+        const LnXform* lnx = op.ln ? (const LnXform*)(ka + offsetof(Phase, ln) / 4) + ((op.ln < 0 ? -op.ln : op.ln) - 1) : nullptr;
+        float* stats = op.ln > 0 ? const_cast<float*>(lnx->stats) : nullptr;
         if (op.dma == 2) {       // the channel encoder on the front end's 10 log10(power) rows (host: operand modes (0, 0))
             const DbXform* xf = (const DbXform*)(ka + offsetof(Phase, xf) / 4);
-            if (op.bm == 32 && op.ns == 8) gemm_tile_dma_dev<32, 8, 0, 0, true>(op.g, tx, ty, bz, smem, xf);
-            else if (op.bm == 32) gemm_tile_dma_dev<32, KM_DMA_NS32, 0, 0, true>(op.g, tx, ty, bz, smem, xf);
-            else gemm_tile_dma_dev<64, KM_DMA_NS64, 0, 0, true>(op.g, tx, ty, bz, smem, xf);
+            if (op.bm == 32 && op.ns == 8) gemm_tile_dma_dev<32, 8, 0, 0, 1>(op.g, tx, ty, bz, smem, xf, nullptr, stats);
+            else if (op.bm == 32) gemm_tile_dma_dev<32, KM_DMA_NS32, 0, 0, 1>(op.g, tx, ty, bz, smem, xf, nullptr, stats);
+            else gemm_tile_dma_dev<64, KM_DMA_NS64, 0, 0, 1>(op.g, tx, ty, bz, smem, xf, nullptr, stats);
+        } else if (op.dma && op.ln < 0) {       // a reader of LayerNorm rows (host: operand modes (0, 0))
+            if (op.bm == 32 && op.ns == 8) gemm_tile_dma_dev<32, 8, 0, 0, 2>(op.g, tx, ty, bz, smem, nullptr, lnx);
+            else if (op.bm == 32) gemm_tile_dma_dev<32, KM_DMA_NS32, 0, 0, 2>(op.g, tx, ty, bz, smem, nullptr, lnx);
+            else gemm_tile_dma_dev<64, KM_DMA_NS64, 0, 0, 2>(op.g, tx, ty, bz, smem, nullptr, lnx);
         } else if (op.dma) {
             if (op.bm == 32 && op.ns == 8) {
-                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<32, 8, 0, 0>(op.g, tx, ty, bz, smem);
+                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<32, 8, 0, 0>(op.g, tx, ty, bz, smem, nullptr, nullptr, stats);
                 else if (op.ma == 0) gemm_tile_dma_dev<32, 8, 0, 1>(op.g, tx, ty, bz, smem);
                 else gemm_tile_dma_dev<32, 8, 1, 1>(op.g, tx, ty, bz, smem);
             } else if (op.bm == 32) {
-                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<32, KM_DMA_NS32, 0, 0>(op.g, tx, ty, bz, smem);
+                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<32, KM_DMA_NS32, 0, 0>(op.g, tx, ty, bz, smem, nullptr, nullptr, stats);
                 else if (op.ma == 0) gemm_tile_dma_dev<32, KM_DMA_NS32, 0, 1>(op.g, tx, ty, bz, smem);
                 else gemm_tile_dma_dev<32, KM_DMA_NS32, 1, 1>(op.g, tx, ty, bz, smem);
             } else {
-                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<64, KM_DMA_NS64, 0, 0>(op.g, tx, ty, bz, smem);
+                if (op.ma == 0 && op.mb == 0) gemm_tile_dma_dev<64, KM_DMA_NS64, 0, 0>(op.g, tx, ty, bz, smem, nullptr, nullptr, stats);
                 else if (op.ma == 0) gemm_tile_dma_dev<64, KM_DMA_NS64, 0, 1>(op.g, tx, ty, bz, smem);
                 else gemm_tile_dma_dev<64, KM_DMA_NS64, 1, 1>(op.g, tx, ty, bz, smem);
             }
@@ -551,6 +570,7 @@ struct Program {
     std::vector<PendingReduce> pend_prev, pend_cur;
     bool allow_split = true;
     DbXform xf{};                 // copied into every phase's arguments (Phase::xf)
+    LnXform ln[2] = {};           // ... (Phase::ln)
     const float* leaf_lo = nullptr; const float* leaf_hi = nullptr;      // the gradient bucket: outputs inside it may be split along K
     // S for a product of K rows with `tiles` output tiles, or 1
     int min_k = kSplitMinK, chain = 512;
@@ -615,7 +635,9 @@ struct Program {
         for (const auto& d : deferred) elem(OP_COLSUM, d.e, d.nblocks, 256 * sizeof(float));
         deferred.clear();
     }
-    void gemm(const GemmArgs& g_in, int batch, bool xfa = false) {
+    // ln: k > 0 the tiles leave LayerNorm parts for their output rows in slot k - 1 (Phase::ln), k < 0 operand A is read through the
+    // LayerNorm of slot -k - 1
+    void gemm(const GemmArgs& g_in, int batch, bool xfa = false, int ln_slot = 0) {
         GemmArgs g = g_in;
         const int tiles0 = ((g.N + 63) / 64) * ((g.M + 31) / 32);
         // only a product whose output lies in the gradient bucket may be cut: nothing but the optimizer (and the next phase's
@@ -660,6 +682,13 @@ struct Program {
             return;
         }
         { int ma = 0, mb = 0; op.dma = (use_dma && gemm_dma_ok(g, &ma, &mb)) ? 1 : 0; op.ma = (signed char)ma; op.mb = (signed char)mb; }
+        if (ln_slot) {
+            if (!(op.dma && op.ma == 0 && op.mb == 0) || S > 1 || g.N % 32 != 0 || (ln_slot > 0 && (g.c_rs != g.N || (batch > 1 && g.c_bs1 != (int64_t)g.M * g.N)))) {
+                rc = fail(KM_ERR_UNSUPPORTED, "training program: LayerNorm by the reader needs the LDS-DMA tile with k-contiguous operands and dense output rows");
+                return;
+            }
+            op.ln = (signed char)ln_slot;
+        }
         if (xfa) {
             if (!(op.dma && op.ma == 0 && op.mb == 0)) {
                 rc = fail(KM_ERR_UNSUPPORTED, "training program: the operand transform needs the LDS-DMA tile with k-contiguous operands");
@@ -686,11 +715,10 @@ struct Program {
             float** qs[4] = {&e.q0, &e.q1, &e.q2, &e.q3};
             int* ns[4] = {&e.rn0, &e.rn1, &e.rn2, &e.rn3};
             int* Ss[4] = {&e.rS0, &e.rS1, &e.rS2, &e.rS3};
-            int* as[4] = {&e.racc0, &e.racc1, &e.racc2, &e.racc3};
             int nblocks = 0;
             for (size_t j = 0; j < 4 && i + j < pend_prev.size(); ++j) {
                 const PendingReduce& r = pend_prev[i + j];
-                *ps[j] = r.part; *qs[j] = r.out; *ns[j] = r.n; *Ss[j] = r.S; *as[j] = r.acc;
+                *ps[j] = r.part; *qs[j] = r.out; *ns[j] = r.n; *Ss[j] = r.S; e.racc |= (r.acc ? 1 : 0) << j;
                 nblocks += (r.n + 255) / 256;
             }
             elem(OP_REDUCE4, e, nblocks);
@@ -709,9 +737,9 @@ struct Program {
                 Op& o = cur.ops[i];
                 if (o.kind != OP_GEMM || !o.dma) continue;
                 o.ns = (signed char)gdma::ring_stages(o.bm, alone);
-                need_lds((size_t)gdma::lds_floats(o.bm, o.ns) * sizeof(float));
+                need_lds((size_t)(gdma::lds_floats(o.bm, o.ns) + (o.ln < 0 ? 2 * o.g.K : 0)) * sizeof(float));
             }
-            cur.xf = xf;
+            cur.xf = xf; cur.ln[0] = ln[0]; cur.ln[1] = ln[1];
             if (has_attn) hipLaunchKernelGGL(phase_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, cur);
             else hipLaunchKernelGGL(phase_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, st, cur);
             HIP_TRY(hipGetLastError());
@@ -770,7 +798,7 @@ int64_t trainp_act_floats(Context* c, int64_t* fixed) {
     const int64_t per = KP * NKk + 2 * NKk * d + 2 * NKk + 2 * NKk * d /* KV */ + 3 * H * 28 * NKk /* P, Pd, dP */ + H * 28 * NKk /* dS */ +
                         3 * 28 * d + 28 * DH + 3 * 24 * d + 24 * DH + 64 /* z */ + (28 + 24) * DH /* dH */ + 6 * (28 + 24) * d / 2 /* dA dO2 dO1 x2 */ +
                         2 * NKk * d /* dKV */ + 2 * NKk * d /* dY dY0 */ + 8 * d + 8 + 5 * 52 + 4 + d * c->KT /* dWce partial */ + 28 * d /* dQ partial */ +
-                        (trainp_mask_bytes(c) + 3) / 4 + 64;
+                        (trainp_mask_bytes(c) + 3) / 4 + 64 + 2 * (NKk + 1) * (d / 32 + 1) /* LayerNorm parts */;
     if (fixed) *fixed = 2 * 28 * d + 2 * d * d + 2 * DH * d + 2 * d + 2 * DH + 64 /* folds */ + d * KP /* channel encoder weight, rows of KP */ + 32 * (4 * d + 2 * DH + 4 * d) /* split partials */ + 1024;
     return per;
 }
@@ -855,6 +883,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     float* emu = take(B); float* ers = take(B);
     float* bs = take(B * 52); float* outb = take(B * 52); float* dz = take(B * 52); float* tfac = take(B * 52); float* txp = take(B * 52);
     float* dQ_part = take(B * 28 * d);
+    float* statsY = take(2 * R * (d / 32 + 1)); float* statsE = take(2 * B * (d / 32 + 1));      // LayerNorm parts of Y0 / E0 rows (float2 [row][d / 32])
     if ((w - c->trp_act) > c->trp_act_floats) return fail(KM_ERR_WORKSPACE, "phased training workspace too small (internal)");
 
     const float p_drop = c->tr_dropout_p;
@@ -933,6 +962,16 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     const float* X = xp_dev ? xp_dev : xp;
     const bool xf = asrc && asrc->packed;
     if (xf) pg.xf = DbXform{*asrc->lp, asrc->melmax};
+    // LayerNorm by the reader (option train_no_ln_fuse switches back to the LayerNorm phase): every product involved on the LDS-DMA tile
+    // -- and a small batch: the reader pays two vector instructions per operand value, two LDS reads per k block and a pooling
+    // prologue per tile, which the launch it saves outweighs up to ~20 windows (8 windows 0.1288-0.1301 -> 0.125 ms, 16: 0.1459 ->
+    // 0.1433, 32: equal, 64: 0.229 -> 0.238: there the K / V product is bound by the matrix pipe and the LayerNorm phase is cheap beside it)
+    const int ln_fuse_rows = c->opt.train_ln_fuse_rows > 0 ? c->opt.train_ln_fuse_rows : 1600;
+    const bool fuse_ln = pg.use_dma && !c->opt.train_no_ln_fuse && !c->opt.train_op_per_launch && d % 32 == 0 && ED % 32 == 0 && R <= ln_fuse_rows;
+    if (fuse_ln) {
+        pg.ln[0] = LnXform{statsY, P("mel_norm.weight"), P("mel_norm.bias"), (int)(d / 32), 1e-5f};
+        pg.ln[1] = LnXform{statsE, P("emotion_norm.weight"), P("emotion_norm.bias"), (int)(d / 32), 1e-5f};
+    }
     RUN(pg.end_phase(st));
     // ================= P1: channel encoder; beside it the input-independent products (Q, T1 = Wmo Wo) and E0 =================
     // (round 4: they used to sit in P0, whose K = 256 tile chains made that phase as long as a product phase for nothing the
@@ -948,22 +987,37 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         // floats on the register tile (scalar loads): 12 us of the 8-window step
         GemmArgs g = NT(X, KP, WceP, KP, Y0, d, NKk, d, P("mel_channel_encoder.bias"), 0);
         g.a_bs1 = KP * NKk; g.c_bs1 = NKk * d;
-        pg.gemm(g, (int)B, xf);       // xf: X holds 10 log10(power), finished on the fragments
+        pg.gemm(g, (int)B, xf, fuse_ln ? 1 : 0);       // xf: X holds 10 log10(power), finished on the fragments; fuse_ln: LayerNorm parts of Y0's rows
     }
     pg.gemm(NT(P("mouth_queries"), d, inw, d, Qb, d, 28, d, inb, 0), 1);                                  // Q = mq Wq^T + bq
     pg.gemm(NN(Wmo, d, Wo, d, T1m, d, d, d, d), 1);                                                        // T1 = Wmo Wo
     pg.gemm(NN(Weo, d, Woe, d, T1e, d, d, d, d), 1);
     { GemmArgs g = G(Wmo, d, 1, bo, 1, 0, t1m, 1, d, 1, d); g.bias = bmo; g.bias_mode = 2; pg.gemm(g, 1); }   // t1 = Wmo bo + bmo
     { GemmArgs g = G(Weo, d, 1, boe, 1, 0, t1e, 1, d, 1, d); g.bias = beo; g.bias_mode = 2; pg.gemm(g, 1); }
-    pg.gemm(NT(emo, ED, P("emotion_encoder.weight"), ED, E0, d, B, d, P("emotion_encoder.bias"), 0), 1);
+    pg.gemm(NT(emo, ED, P("emotion_encoder.weight"), ED, E0, d, B, d, P("emotion_encoder.bias"), 0), 1, false, fuse_ln ? 2 : 0);
     RUN(pg.end_phase(st));
+    // The folds Wf = W1 T1 (operands of P5) and the finished features x2 (operand of P12): with fuse_ln they ride in P3
+    auto folds = [&]() {
+        pg.gemm(NN(W1, d, T1m, d, Wfm, d, DH, d, d), 1);                                                        // Wf = W1 T1
+        pg.gemm(NN(W1, d, T1e, d, Wfe, d, DH, d, d), 1);
+        { GemmArgs g = G(W1, d, 1, t1m, 1, 0, bfm, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }     // bf = W1 t1 + b1
+        { GemmArgs g = G(W1, d, 1, t1e, 1, 0, bfe, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }
+    };
+    auto dbconv = [&]() {
+        if (!xf) return;
+        // the packed rows once more, finished into x2 for the channel encoder's weight gradient (phase 12).  Not beside the channel
+        // encoder in phase 1: its workgroups held tile slots (the phase's LDS size) while they streamed -- +3.2 us at 64 windows
+        ElemArgs e{};
+        e.p0 = X; e.p1 = reinterpret_cast<const float*>(asrc->melmax); e.q0 = x2; e.n0 = B; e.i0 = (int)NKk; e.i1 = (int)KP; e.i2 = (int)T;
+        e.lp = *asrc->lp;
+        e.i3 = (int)((NKk * (KP / 4) + 1023) / 1024);
+        pg.elem(OP_DBCONV, e, B * e.i3);
+    };
+    if (!fuse_ln) {
     // ================= P2: LayerNorm (both streams); folds Wf = W1 T1 =================
     // (the folds first: their K = d tile chains are the longest thing in the phase and should not wait in the dispatch order behind
     // the hundreds of row workgroups of the LayerNorm and the conversion)
-    pg.gemm(NN(W1, d, T1m, d, Wfm, d, DH, d, d), 1);                                                        // Wf = W1 T1
-    pg.gemm(NN(W1, d, T1e, d, Wfe, d, DH, d, d), 1);
-    { GemmArgs g = G(W1, d, 1, t1m, 1, 0, bfm, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }     // bf = W1 t1 + b1
-    { GemmArgs g = G(W1, d, 1, t1e, 1, 0, bfe, 1, DH, 1, d); g.bias = b1; g.bias_mode = 2; pg.gemm(g, 1); }
+    folds();
     {
         ElemArgs e{};
         e.p0 = Y0; e.q0 = Y; e.n0 = R; e.i0 = (int)d; e.p1 = P("mel_norm.weight"); e.p2 = P("mel_norm.bias"); e.q1 = mu; e.q2 = rs;
@@ -974,24 +1028,35 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         e.p0 = E0; e.q0 = E; e.n0 = B; e.i0 = (int)d; e.p1 = P("emotion_norm.weight"); e.p2 = P("emotion_norm.bias"); e.q1 = emu; e.q2 = ers;
         pg.elem(OP_LN_FWD, e, blocks4(B));
     }
-    if (xf) {      // the packed rows once more, finished into x2 for the channel encoder's weight gradient (phase 12).  Here, not beside the
-        // channel encoder in phase 1: its workgroups held tile slots (the phase's LDS size) while they streamed -- +3.2 us at 64 windows
-        ElemArgs e{};
-        e.p0 = X; e.p1 = reinterpret_cast<const float*>(asrc->melmax); e.q0 = x2; e.n0 = B; e.i0 = (int)NKk; e.i1 = (int)KP; e.i2 = (int)T;
-        e.lp = *asrc->lp;
-        e.i3 = (int)((NKk * (KP / 4) + 1023) / 1024);
-        pg.elem(OP_DBCONV, e, B * e.i3);
-    }
+    dbconv();
     RUN(pg.end_phase(st));
+    }
     // ================= P3: [K | V]; emotion value projection =================
-    if (xf) {          // the window maxima were read by phases 1 and 2 (DbXform, OP_DBCONV): clean slots for the next front-end launch
+    auto zero_maxima = [&]() {          // the window maxima were read by DbXform and OP_DBCONV: clean slots for the next front-end launch
+        if (!xf) return;
         ElemArgs z{};
         z.q0 = reinterpret_cast<float*>(c->ws_melmax); z.n0 = c->ws_windows;
         pg.elem(OP_ZERO, z, (c->ws_windows + 4095) / 4096);
         c->melmax_dirty = false;
+    };
+    if (!fuse_ln) zero_maxima();          // (with fuse_ln OP_DBCONV reads them in THIS phase: they are cleaned in P4)
+    // fuse_ln (round 4): there is no LayerNorm phase.  The tiles of Y0 and E0 (P1) left per-row parts of the statistics; the two
+    // products here read Y0 / E0 and normalise their operand fragments on the way to the MFMAs (LnXform), OP_LNAPPLY beside them
+    // writes Y, E, mu, rstd for the backward pass with the same two functions (ln_combine, ln_apply: the same bits)
+    pg.gemm(NT(fuse_ln ? Y0 : Y, d, inw + d * d, d, KV, 2 * d, R, 2 * d, inb + d, 0), 1, false, fuse_ln ? -1 : 0);
+    pg.gemm(NT(fuse_ln ? E0 : E, d, einw + 2 * d * d, d, Ve, d, B, d, einb + 2 * d, 0), 1, false, fuse_ln ? -2 : 0);
+    if (fuse_ln) {
+        folds();
+        ElemArgs e{};
+        e.p0 = Y0; e.p1 = P("mel_norm.weight"); e.p2 = P("mel_norm.bias"); e.p3 = statsY; e.q0 = Y; e.q1 = mu; e.q2 = rs;
+        e.n0 = R; e.i0 = (int)d; e.i1 = (int)(d / 32); e.f0 = 1e-5f;
+        pg.elem(OP_LNAPPLY, e, blocks4(R));
+        ElemArgs f{};
+        f.p0 = E0; f.p1 = P("emotion_norm.weight"); f.p2 = P("emotion_norm.bias"); f.p3 = statsE; f.q0 = E; f.q1 = emu; f.q2 = ers;
+        f.n0 = B; f.i0 = (int)d; f.i1 = (int)(d / 32); f.f0 = 1e-5f;
+        pg.elem(OP_LNAPPLY, f, blocks4(B));
+        dbconv();
     }
-    pg.gemm(NT(Y, d, inw + d * d, d, KV, 2 * d, R, 2 * d, inb + d, 0), 1);
-    pg.gemm(NT(E, d, einw + 2 * d * d, d, Ve, d, B, d, einb + 2 * d, 0), 1);
     // the dropout masks of the step (first read in P4), behind the phase's own work in dispatch order
     if (drop && c->tr_dropout_mode == 0) {
         int64_t nm, ne, nd;
@@ -1025,6 +1090,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
         e.p0 = Ve; e.q0 = Ae; e.n0 = B; e.i0 = (int)d; e.i1 = (int)hd; e.mask = m_emo; e.f0 = keep_scale;
         pg.elem(OP_EMO_EXPAND, e, Re * ((d + 255) / 256));
     }
+    if (fuse_ln) zero_maxima();
     // clean gradient bucket and the ones vector (first touched in P8): they ride under the attention blocks
     {
         ElemArgs e{};

@@ -407,8 +407,9 @@ def test_lds_dma_tiles_and_attention_blocks_agree_with_the_register_staged_ones(
     runs = {}
     for name, opts in (("dma", {}), ("no_dma", {"train_no_dma": 1}), ("attn_regs", {"train_attn_regs": 1}),
                        ("colsum_gemm", {"train_colsum_gemm": 1}),      # column sums as ones-vector products (before OP_COLSUM)
+                       ("ln_phase", {"train_no_ln_fuse": 1}),          # a LayerNorm phase instead of LayerNorm in the readers of Y0 / E0
                        ("round3", {"train_no_dma": 1, "train_attn_regs": 1, "train_colsum_gemm": 1})):
-        for k in ("train_no_dma", "train_attn_regs", "train_colsum_gemm"):
+        for k in ("train_no_dma", "train_attn_regs", "train_colsum_gemm", "train_no_ln_fuse"):
             e.set_option(k, opts.get(k, 0))
         tr.set_dropout(0.1, seed=3)                      # the same Philox masks in every run
         check_step = tr._lib.km_train_set_dropout_step(tr._h, 0)
@@ -416,7 +417,7 @@ def test_lds_dma_tiles_and_attention_blocks_agree_with_the_register_staged_ones(
         loss = float(tr.forward_backward_mel(dev(mel), dev(short), dev(emo), dev(target)).item())
         runs[name] = (loss, tr.grads(shapes))
     l0, g0 = runs["round3"]
-    for name in ("dma", "no_dma", "attn_regs", "colsum_gemm"):
+    for name in ("dma", "no_dma", "attn_regs", "colsum_gemm", "ln_phase"):
         l, g = runs[name]
         assert abs(l - l0) < 2e-6 * max(1.0, abs(l0)), name
         for k in g0:
