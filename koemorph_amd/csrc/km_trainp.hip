@@ -162,6 +162,14 @@ __device__ __forceinline__ void ln_bwd_row(const ElemArgs& a, int64_t row, int l
     if constexpr (NP > 0) {
 #pragma unroll
         for (int u = 0; u < NP; ++u) { dy[u] = a.p0[row * d + lane + 64 * u]; xh[u] = a.p1[row * d + lane + 64 * u]; gm[u] = a.p2[lane + 64 * u]; }
+        if (a.n1) {         // dy arrives as TWO partial products (the K halves of dY = dKV Wkv, n1 floats apart: P10 at small batches): their sum
+                            // is the gradient, and it is written back (q2) for the phase-12 column sum
+            float dyb[NR];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) dyb[u] = a.p0[a.n1 + row * d + lane + 64 * u];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) { dy[u] += dyb[u]; a.q2[row * d + lane + 64 * u] = dy[u]; }
+        }
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             xh[u] = (xh[u] - mu) * rs;
@@ -797,7 +805,7 @@ int64_t trainp_act_floats(Context* c, int64_t* fixed) {
     const int64_t d = c->d, H = c->H, NKk = c->NK, DH = c->DH, KP = trainp_kp(c);
     const int64_t per = KP * NKk + 2 * NKk * d + 2 * NKk + 2 * NKk * d /* KV */ + 3 * H * 28 * NKk /* P, Pd, dP */ + H * 28 * NKk /* dS */ +
                         3 * 28 * d + 28 * DH + 3 * 24 * d + 24 * DH + 64 /* z */ + (28 + 24) * DH /* dH */ + 6 * (28 + 24) * d / 2 /* dA dO2 dO1 x2 */ +
-                        2 * NKk * d /* dKV */ + 2 * NKk * d /* dY dY0 */ + 8 * d + 8 + 5 * 52 + 4 + d * c->KT /* dWce partial */ + 28 * d /* dQ partial */ +
+                        2 * NKk * d /* dKV */ + 3 * NKk * d /* dY (two K halves) dY0 */ + 8 * d + 8 + 5 * 52 + 4 + d * c->KT /* dWce partial */ + 28 * d /* dQ partial */ +
                         (trainp_mask_bytes(c) + 3) / 4 + 64 + 2 * (NKk + 1) * (d / 32 + 1) /* LayerNorm parts */;
     if (fixed) *fixed = 2 * 28 * d + 2 * d * d + 2 * DH * d + 2 * d + 2 * DH + 64 /* folds */ + d * KP /* channel encoder weight, rows of KP */ + 32 * (4 * d + 2 * DH + 4 * d) /* split partials */ + 1024;
     return per;
@@ -878,7 +886,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     float* dH1 = take(Rm * DH); float* dHe = take(Re * DH);
     float* dA = take(Rm * d); float* dO2 = take(Rm * d); float* dO1 = take(Rm * d);
     float* dAe = take(Re * d); float* dOe2 = take(Re * d); float* dOe1 = take(Re * d);
-    float* dKV = take(R * 2 * d); float* dY = take(R * d); float* dY0 = take(R * d); float* Tm = take(R * d); float* Te = take(B * d);
+    float* dKV = take(R * 2 * d); float* dY = take(2 * R * d) /* two K halves at small batches */; float* dY0 = take(R * d); float* Tm = take(R * d); float* Te = take(B * d);
     float* E0 = take(B * d); float* E = take(B * d); float* Ve = take(B * d); float* dVe = take(B * d); float* dE = take(B * d); float* dE0 = take(B * d);
     float* emu = take(B); float* ers = take(B);
     float* bs = take(B * 52); float* outb = take(B * 52); float* dz = take(B * 52); float* tfac = take(B * 52); float* txp = take(B * 52);
@@ -1172,7 +1180,17 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     colsum(He, Re, DH, DH, Gd("blendshape_decoder.3.weight"), 1, grow + Rm);
     RUN(pg.end_phase(st));
     // ================= P10: dY; in_proj [K | V] gradients; dQ; out_proj gradients; emotion value projection backward =================
-    pg.gemm(NN(dKV, 2 * d, inw + d * d, d, dY, d, R, d, 2 * d), 1);
+    // dY = dKV Wkv has the longest tile chain of the phase (K = 2 d: 16 steps at d_model 256).  At small batches -- fewer tiles than CUs --
+    // it runs as TWO products over the K halves (a batch of two, 8 steps each) whose sum the reader takes: OP_LN_BWD of P11 adds the halves
+    // and writes the sum back for P12's column sum
+    const bool split_dy = (R / 32) * (d / 64) * 2 <= 256 && (d == 64 || d == 256 || d == 512) && !c->opt.train_no_dy_split;
+    if (split_dy) {
+        GemmArgs g = NN(dKV, 2 * d, inw + d * d, d, dY, d, R, d, d);
+        g.a_bs1 = d; g.b_bs1 = d * d; g.c_bs1 = R * d;
+        pg.gemm(g, 2);
+    } else {
+        pg.gemm(NN(dKV, 2 * d, inw + d * d, d, dY, d, R, d, 2 * d), 1);
+    }
     pg.gemm(TN(dKV, 2 * d, Y, d, gin_w + d * d, d, 2 * d, d, R), 1);
     colsum(dKV, R, 2 * d, 2 * d, gin_b + d, 0, ones);
     reduce(dQ_part, (int)B, 28 * d, 28 * d, dQb, 0);
@@ -1194,6 +1212,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     {
         ElemArgs b{};
         b.p0 = dY; b.p1 = Y0; b.p2 = P("mel_norm.weight"); b.p3 = mu; b.p4 = rs; b.q0 = dY0; b.q1 = Tm; b.n0 = R; b.i0 = (int)d;
+        if (split_dy) { b.n1 = R * d; b.q2 = dY; }
         pg.elem(OP_LN_BWD, b, blocks4(R));
         ElemArgs e{};
         e.p0 = dE; e.p1 = E0; e.p2 = P("emotion_norm.weight"); e.p3 = emu; e.p4 = ers; e.q0 = dE0; e.q1 = Te; e.n0 = B; e.i0 = (int)d;
