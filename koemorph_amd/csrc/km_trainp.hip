@@ -569,7 +569,7 @@ struct Program {
     int blocks = 0;
     int launches = 0;
     bool use_dma = true, any_dma = false, dma_bm64 = false;      // LDS-DMA tiles (option train_no_dma switches them off)
-    int alone_max = 256;                 // see end_phase
+    int alone_max = 0;                   // see launch_cur: phases of up to this many workgroups get 8-stage rings (option train_alone_max; 0: never)
     int rc = KM_OK;
     size_t lds = 0;
     bool has_attn = false;        // the phase holds an attention block: phase_kernel<true>
@@ -738,7 +738,10 @@ struct Program {
         if (rc) return rc;
         if (cur.n_ops > 0) {
             ++launches;
-            // ring depth of the LDS-DMA tiles: a phase of at most alone_max workgroups has the chip to itself (one workgroup
+            // ring depth of the LDS-DMA tiles.  The 8-stage ring (the whole K = 256 of a small product requested at entry, 96 KB: one
+            // workgroup per CU) paid while the small phases held nothing but products (0.181 -> 0.176 ms at 8 windows); with the
+            // row / element operations that have since moved beside them it loses to the 4-stage ring with three workgroups per CU
+            // (0.1238 -> 0.1215 ms; train_alone_max 256 brings it back): a phase of at most alone_max workgroups has the chip to itself (one workgroup
             // per CU: deep rings); beyond that LDS is occupancy
             const bool alone = blocks <= alone_max;
             for (int i = 0; i < cur.n_ops; ++i) {
@@ -932,6 +935,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     pg.op_per_launch = c->opt.train_op_per_launch != 0; pg.dbg_stream = st;
     pg.use_dma = !c->opt.train_no_dma;
     if (c->opt.train_split_min_k > 0) { pg.min_k = c->opt.train_split_min_k; pg.chain = c->opt.train_split_min_k; }
+    if (c->opt.train_alone_max > 0) pg.alone_max = c->opt.train_alone_max;
     auto blocks4 = [](int64_t rows) { return (rows + 3) / 4; };            // one wave per row, 4 rows per block
     auto blocks256 = [](int64_t n) { return (n + 255) / 256; };
     // column sums as products with a vector: out (1 x n) (+)= w^T (1 x rows) M (rows x n); w = ones, or per-row loss gradients
