@@ -366,7 +366,7 @@ int km_train_step_audio(km_handle h, const float* audio_dev, int64_t B, int64_t 
         // front end -> power-mel; phase 0 of the program converts and packs it into the encoder input (B, KP, n_mels) at the
         // head of the phased workspace
         // (round 4: the front end writes the packed dB input itself -- MelPack -- where it can; option train_no_fe_pack)
-        const bool fe_packs = !c->opt.train_no_fe_pack && !c->opt.train_no_dma && !c->opt.train_op_per_launch &&
+        const bool fe_packs = !c->opt.train_no_fe_pack && !c->opt.train_no_dma &&
                               mel_packs(c, c->mel_plans[0], n_frames, c->T) && c->mel_plans[0]->cfg.n_mels == c->NK;
         const MelPack pack{c->trp_act, (int)c->T, (int)trainp_kp(c)};
         if (int rc = launch_mel_power(c, c->mel_plans[0], audio_dev, B, L, stream, 0, 0, 0, 1, nullptr, nullptr, nullptr, nullptr, nullptr,

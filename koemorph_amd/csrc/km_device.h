@@ -58,6 +58,18 @@ __device__ __forceinline__ void ln_combine(const float2* __restrict__ st, int np
     nmurs = -mean * rs;
     if (mean_out) *mean_out = mean;
 }
+// the same from parts held in registers (up to 8: d <= 256); terms beyond npart add an exact zero: the same bits as ln_combine
+__device__ __forceinline__ void ln_combine8(const float2 (&st)[8], int npart, float eps, float& rs, float& nmurs) {
+    float msum = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) msum += p < npart ? st[p].x : 0.f;
+    const float mean = msum / (float)npart;
+    float m2 = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) { const float dm = st[p].x - mean; m2 += p < npart ? st[p].y + 32.0f * dm * dm : 0.f; }
+    rs = 1.0f / sqrtf(m2 / (float)(32 * npart) + eps);
+    nmurs = -mean * rs;
+}
 __device__ __forceinline__ float ln_apply(float x, float rs, float nmurs, float gam, float bet) { return fmaf(fmaf(x, rs, nmurs), gam, bet); }
 
 template <int MODE>

@@ -336,6 +336,21 @@ __device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int
     // leave the youngest requests in flight) cover them
     DmaEpilogue<MT> ep;
     ep.prefetch(g, m0 + 16 * MT * wm, n0 + 32 * wn, lg, lj);
+    float2 lparts[XFA == 2 ? MT : 1][8];      // XFA == 2: the LayerNorm parts of this lane's fragment rows (d <= 256: registers)
+    int64_t lrow[XFA == 2 ? MT : 1];
+    float gbv[2][2];
+    if constexpr (XFA == 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int k = tid + 256 * u < g.K ? tid + 256 * u : 0; gbv[u][0] = ln->gamma[k]; gbv[u][1] = ln->beta[k]; }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = m0 + 16 * MT * wm + 16 * i + lj;
+            lrow[i] = (int64_t)z1 * g.M + (row < g.M ? row : g.M - 1);
+            const float2* st = reinterpret_cast<const float2*>(ln->stats) + lrow[i] * ln->npart;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) lparts[i][p] = st[p < ln->npart ? p : 0];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NS - 1; ++j) issue(j);
     // XFA: the A fragments are 10 log10(power) values; the rest of the dB conversion (reference of batch entry z1, top_db floor,
@@ -343,15 +358,15 @@ __device__ __forceinline__ void gemm_tile_dma_dev(const GemmArgs& g, int bx, int
     // value under the matrix pipe) instead of a conversion pass (and a launch) ahead of the product.  The reference is read here, behind the DMA
     // requests: its round trip runs beside the first stage's.
     if constexpr (XFA == 2) {
-        // behind the DMA requests of the prologue: the parts' round trip runs beside the first stage's (ahead of them it was one more
-        // memory round trip in front of every tile)
-        for (int k = tid; k < g.K; k += 256) { gb[k] = ln->gamma[k]; gb[g.K + k] = ln->beta[k]; }
+        // the values requested ahead of the DMA prologue (below) are used here, behind it: the compiler's counted wait for them leaves
+        // the younger DMA requests in flight
+        for (int u = 0; u < 2; ++u) { const int k = tid + 256 * u; if (k < g.K) { gb[k] = gbv[u][0]; gb[g.K + k] = gbv[u][1]; } }
+        for (int k = tid + 512; k < g.K; k += 256) { gb[k] = ln->gamma[k]; gb[g.K + k] = ln->beta[k]; }      // K > 512: the rest, plainly
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // in LDS before the prologue's (raw) barrier
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int row = m0 + 16 * MT * wm + 16 * i + lj;
-            const int64_t rr = (int64_t)z1 * g.M + (row < g.M ? row : g.M - 1);
-            ln_combine(reinterpret_cast<const float2*>(ln->stats) + rr * ln->npart, ln->npart, ln->eps, lrs[i], lnm[i]);
+            if (ln->npart <= 8) ln_combine8(lparts[i], ln->npart, ln->eps, lrs[i], lnm[i]);
+            else ln_combine(reinterpret_cast<const float2*>(ln->stats) + lrow[i] * ln->npart, ln->npart, ln->eps, lrs[i], lnm[i]);
         }
     }
     if constexpr (XFA == 1) {

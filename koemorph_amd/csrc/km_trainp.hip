@@ -979,7 +979,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     // prologue per tile, which the launch it saves outweighs up to ~20 windows (8 windows 0.1288-0.1301 -> 0.125 ms, 16: 0.1459 ->
     // 0.1433, 32: equal, 64: 0.229 -> 0.238: there the K / V product is bound by the matrix pipe and the LayerNorm phase is cheap beside it)
     const int ln_fuse_rows = c->opt.train_ln_fuse_rows > 0 ? c->opt.train_ln_fuse_rows : 1600;
-    const bool fuse_ln = pg.use_dma && !c->opt.train_no_ln_fuse && !c->opt.train_op_per_launch && d % 32 == 0 && ED % 32 == 0 && R <= ln_fuse_rows;
+    const bool fuse_ln = pg.use_dma && !c->opt.train_no_ln_fuse && d % 32 == 0 && ED % 32 == 0 && R <= ln_fuse_rows;
     if (fuse_ln) {
         pg.ln[0] = LnXform{statsY, P("mel_norm.weight"), P("mel_norm.bias"), (int)(d / 32), 1e-5f};
         pg.ln[1] = LnXform{statsE, P("emotion_norm.weight"), P("emotion_norm.bias"), (int)(d / 32), 1e-5f};
