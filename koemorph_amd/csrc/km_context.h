@@ -80,7 +80,7 @@ struct Options {
     int train_split_min_k = 0;     // > 0: split gradient products longer than this many rows into chains of about this length (A/B; default 1024 / 640)
     int train_alone_max = 0;       // > 0: a phase of up to this many workgroups gives its 32-row LDS-DMA tiles the 8-stage ring (default 256)
     int train_no_dy_split = 0;     // 1: dY = dKV Wkv as one product at every batch size (A/B of the two K halves summed by the LayerNorm backward)
-    int train_ln_fuse_rows = 0;    // > 0: LayerNorm by the reader up to this many key rows per step (default 1600 = 20 windows of 80 channels)
+    int train_ln_fuse_rows = 0;    // > 0: LayerNorm by the reader up to this many key rows per step (default 3200 = 40 windows of 80 channels)
     int train_no_ln_fuse = 0;      // 1: the training program keeps its LayerNorm phase (P2) instead of normalising in the readers of Y0 / E0 (LnXform)
     int train_colsum_gemm = 0;     // 1: column sums of the training program as products with a ones vector on the matrix pipe (rounds 2-4a) instead of OP_COLSUM
     int train_no_fe_pack = 0;      // 1: km_train_step_audio converts and packs the power-mel in phase 0 of the program (round 3/4 form) instead of inside the front-end launch

@@ -976,9 +976,10 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     if (xf) pg.xf = DbXform{*asrc->lp, asrc->melmax};
     // LayerNorm by the reader (option train_no_ln_fuse switches back to the LayerNorm phase): every product involved on the LDS-DMA tile
     // -- and a small batch: the reader pays two vector instructions per operand value, two LDS reads per k block and a pooling
-    // prologue per tile, which the launch it saves outweighs up to ~20 windows (8 windows 0.1288-0.1301 -> 0.125 ms, 16: 0.1459 ->
-    // 0.1433, 32: equal, 64: 0.229 -> 0.238: there the K / V product is bound by the matrix pipe and the LayerNorm phase is cheap beside it)
-    const int ln_fuse_rows = c->opt.train_ln_fuse_rows > 0 ? c->opt.train_ln_fuse_rows : 1600;
+    // prologue per tile, which the launch it saves outweighs up to ~40 windows (8 windows 0.1288-0.1301 -> 0.125 ms, 24: 0.1647 ->
+    // 0.1606, 32: 0.1717 -> 0.1683, 48: 0.2079 -> 0.2105, 64: 0.229 -> 0.238: there the K / V product is bound by the matrix pipe and the
+    // LayerNorm phase is cheap beside it)
+    const int ln_fuse_rows = c->opt.train_ln_fuse_rows > 0 ? c->opt.train_ln_fuse_rows : 3200;
     const bool fuse_ln = pg.use_dma && !c->opt.train_no_ln_fuse && d % 32 == 0 && ED % 32 == 0 && R <= ln_fuse_rows;
     if (fuse_ln) {
         pg.ln[0] = LnXform{statsY, P("mel_norm.weight"), P("mel_norm.bias"), (int)(d / 32), 1e-5f};
