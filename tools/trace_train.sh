@@ -29,6 +29,7 @@ tot = 0
 for (pos, n), v in acc.items():
     m = sum(v) / len(v); tot += m
     print(f"{pos:3d} {n:62s} {m:8.1f} us", file=out)
-print(f"launches per step {per}; sum of kernel time {tot:.1f} us; step period {sum(gaps)/len(gaps):.1f} us", file=out)
+print(f"launches per step {per}; sum of kernel time {tot:.1f} us; step period {sum(gaps)/len(gaps):.1f} us UNDER THE PROFILER (rocprofv3 adds host time per launch: "
+      f"a short step becomes host-bound; the un-profiled period is bench.py's ms_per_step, profiles/r04_workloads.json)", file=out)
 print(open(f"gpurun_out/trace_train_{B}.txt").read())
 PY
