@@ -79,7 +79,7 @@ struct Options {
     int train_dwce_parts = 0;      // > 0: partial sums of the channel-encoder gradient per step (a divisor of the batch; A/B)
     int train_split_min_k = 0;     // > 0: split gradient products longer than this many rows into chains of about this length (A/B; default 1024 / 640)
     int train_alone_max = 0;       // > 0: a phase of up to this many workgroups gives its 32-row LDS-DMA tiles the 8-stage ring (default 256)
-    int train_no_dy_split = 0;     // 1: dY = dKV Wkv as one product at every batch size (A/B of the two K halves summed by the LayerNorm backward)
+    int train_no_dy_split = 0;     // 1: dY = dKV Wkv as one product at every batch size (A/B of the two K halves summed by the LayerNorm backward); 2: two halves at every batch size (measured: 16 windows 0.1401 -> 0.1422 ms, 64: 0.2299 -> 0.2327)
     int train_ln_fuse_rows = 0;    // > 0: LayerNorm by the reader up to this many key rows per step (default 3200 = 40 windows of 80 channels)
     int train_no_ln_fuse = 0;      // 1: the training program keeps its LayerNorm phase (P2) instead of normalising in the readers of Y0 / E0 (LnXform)
     int train_colsum_gemm = 0;     // 1: column sums of the training program as products with a ones vector on the matrix pipe (rounds 2-4a) instead of OP_COLSUM

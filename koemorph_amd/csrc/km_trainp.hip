@@ -1188,7 +1188,7 @@ int train_forward_backward_phased(Context* c, const float* mel, int64_t B, int64
     // dY = dKV Wkv has the longest tile chain of the phase (K = 2 d: 16 steps at d_model 256).  At small batches -- fewer tiles than CUs --
     // it runs as TWO products over the K halves (a batch of two, 8 steps each) whose sum the reader takes: OP_LN_BWD of P11 adds the halves
     // and writes the sum back for P12's column sum
-    const bool split_dy = (R / 32) * (d / 64) * 2 <= 256 && (d == 64 || d == 256 || d == 512) && !c->opt.train_no_dy_split;
+    const bool split_dy = ((R / 32) * (d / 64) * 2 <= 256 || c->opt.train_no_dy_split == 2) && (d == 64 || d == 256 || d == 512) && c->opt.train_no_dy_split != 1;
     if (split_dy) {
         GemmArgs g = NN(dKV, 2 * d, inw + d * d, d, dY, d, R, d, d);
         g.a_bs1 = d; g.b_bs1 = d * d; g.c_bs1 = R * d;
