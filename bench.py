@@ -802,7 +802,7 @@ def run_c3(args, rk: Ranks):
                                f"{kw.get('dropout', 0.0)}, {'hipGraph replay, ' if args.graph else ''}MSE loss, clip 1.0, AdamW; ONE all-reduce of the flat {tr.n_params}-float "
                                "gradient bucket per step", "windows_per_gpu": B,
                    "parallelism": f"data parallel x{rk.world}, gradient all-reduce over {'RCCL' if rk.backend == 'nccl' else rk.backend}"},
-        "roofline": {"kernel": "whole step (15 launches; at 8 windows a phase is ~6.5 us of launch + set-up + one memory round trip around ~1.5 us of "
+        "roofline": {"kernel": "whole step (13 launches at 8 windows, 15 at 64; at 8 windows a phase is ~6.5 us of launch + set-up + one memory round trip around ~1.5 us of "
                                "tile loop: DESIGN 3.6, profiles/r04_train_trace_*.txt)", "bound": "mfma", "achieved": round(tf, 3),
                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 5), "traffic": None,
                      "flops_per_window": TRAIN_FLOPS_PER_WINDOW},

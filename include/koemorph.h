@@ -305,8 +305,8 @@ int km_train_set_dropout_step(km_handle h, int64_t step);
 
 /* Overlapping the data-parallel gradient all-reduce with the end of the backward pass (new construction: the reference is
  * single-process).  The flat bucket is laid out so that the tensors the backward pass finishes last come last:
- *   km_train_grad_split   *early_floats = E: floats [0, E) of flat_grad (83 % at d_model 256) are final after phase 11 of
- *                         14 of km_train_step*, the rest when the call's work completes
+ *   km_train_grad_split   *early_floats = E: floats [0, E) of flat_grad (83 % at d_model 256) are final after phase P11 of
+ *                         km_train_step*'s program (the last but one or two of its launches), the rest when the call's work completes
  *   km_train_wait_early   make `stream` wait (hipStreamWaitEvent) for that point of the most recent km_train_step*: a
  *                         side stream can then all-reduce flat_grad[0:E] while the launch stream still computes the tail */
 int km_train_grad_split(km_handle h, int64_t* early_floats);

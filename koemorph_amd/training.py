@@ -249,7 +249,7 @@ class Trainer:
     def _allreduce_two_piece(self, weight: Optional[float], overlap: bool) -> None:
         """The step's one gradient exchange, issued as two pieces: floats [0, E) of the bucket (83 %: everything but the
         tensors the backward pass finishes last, km_train_grad_split) are reduced on a side stream that waits only for
-        phase 11 of the 14 (km_train_wait_early), i.e. while the launch stream still computes the LayerNorm / channel
+        phase P11 of the program (km_train_wait_early), i.e. while the launch stream still computes the LayerNorm / channel
         encoder gradients; the rest follows on the launch stream when the step is done.  Every rank issues the same two
         collectives whether or not it ran a step (a rank without windows contributes zeros): only the placement differs."""
         import ctypes
