@@ -758,6 +758,13 @@ def cpu_baseline_c4(args, params, audio_np, emo_np, heads: int):
 # ---------------------------------------------------------------------------------------------------------------------
 # C3: the training step (forward, loss, backward, ONE gradient all-reduce over RCCL, clip, AdamW)
 # ---------------------------------------------------------------------------------------------------------------------
+def apply_bench_options(eng) -> None:
+    """KM_BENCH_OPTIONS="name=value,..." -> km_set_option on the workload's handle: timing aids and same-run A/B of two
+    implementations of the same arithmetic (train_op_per_launch=1, no_core_merge=1, ...)."""
+    for kv in filter(None, os.environ.get("KM_BENCH_OPTIONS", "").split(",")):
+        eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+
+
 def run_c3(args, rk: Ranks):
     torch = rk.torch
     from koemorph_amd import synth
@@ -768,8 +775,7 @@ def run_c3(args, rk: Ranks):
     eng = Engine()
     eng.load_state_dict(synth.make_core_params(0))
     eng.finalize(rk.dev)
-    for kv in filter(None, os.environ.get("KM_BENCH_OPTIONS", "").split(",")):      # timing aids, e.g. train_op_per_launch=1
-        eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    apply_bench_options(eng)
     kw = {}
     if "dropout" in Trainer.__init__.__code__.co_varnames:
         kw["dropout"] = args.dropout
@@ -822,6 +828,7 @@ def run_c4(args, rk: Ranks):
     eng = Engine(d_model=512, num_heads=H, mel_sequence_length=512, mel=MelConfig.model_batch(target_fps=60))
     eng.load_state_dict(synth.make_core_params(0, 512, 512, 256, "init"))
     eng.finalize(rk.dev)
+    apply_bench_options(eng)
     eng.reserve(B, L)
     params = synth.make_core_params(0, 512, 512, 256, "init")
     audio_np, emo_np = synth.make_audio(1 + rk.rank, B, L, "uniform"), synth.normal(2 + rk.rank, (B, 256))

@@ -42,18 +42,21 @@ __device__ __forceinline__ float row16_max(float v) {
 #define KM_SC_SKIP 0
 #endif
 
+constexpr int kScoresYsFloats = 16 * (80 + 1) * 4;      // one Y chunk image [k / 4][row, padded to 81][k % 4]
+
+// window b of the launch; Ys: the workgroup's two Y chunk buffers (the kernel's static array, or the head of core512_kernel's dynamic LDS)
 template <int D, int TPW>
-__global__ __launch_bounds__(512) void scores_softmax_kernel(const float* __restrict__ Y, const float* __restrict__ qk_pg,
-                                                             float* __restrict__ S, int rows /* H * 28 */) {
+__device__ __forceinline__ void scores_softmax_body(const float* __restrict__ Y, const float* __restrict__ qk_pg,
+                                                    float* __restrict__ S, int rows /* H * 28 */, int b, float (&Ys)[2][kScoresYsFloats]) {
     constexpr int NKc = 80, KB = D / 16, CH = 4, NCH = KB / CH, QS = NKc + 1;
+    static_assert(16 * QS * 4 == kScoresYsFloats, "Y chunk image");
     static_assert(KB % CH == 0 && CH == 4, "k blocks come in chunks of four (the A prefetch ring has four slots)");
     // Y_b reaches the MFMAs through LDS in chunks of 64 k ([k / 4][row, padded to 81][k % 4]: conflict-free b128 on both
     // sides), double buffered: read from L2 once per workgroup instead of once per wave.  The KEY ROWS are stored permuted
     // (key 4 j + t of the first 64 at row 16 t + j), so that the lane that reads row 16 t + j for column tile t ends up with
     // keys 4 j .. 4 j + 3 in its four accumulators: the softmaxed row leaves as one 16-byte store + one dword (keys 64..79)
     // per lane instead of five 64-byte segments.
-    __shared__ __attribute__((aligned(16))) float Ys[2][16 * QS * 4];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lg = lane >> 4, lj = lane & 15;
     const int MT = (rows + 15) >> 4;
@@ -198,6 +201,13 @@ __global__ __launch_bounds__(512) void scores_softmax_kernel(const float* __rest
             }
         }
     }
+}
+
+template <int D, int TPW>
+__global__ __launch_bounds__(512) void scores_softmax_kernel(const float* __restrict__ Y, const float* __restrict__ qk_pg,
+                                                             float* __restrict__ S, int rows /* H * 28 */) {
+    __shared__ __attribute__((aligned(16))) float Ys[2][kScoresYsFloats];
+    scores_softmax_body<D, TPW>(Y, qk_pg, S, rows, (int)blockIdx.x, Ys);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -346,21 +356,21 @@ __global__ __launch_bounds__(512) void attn_out_kernel(const float* __restrict__
 #define KM_VR_SKIP 0
 #endif
 
+// window b of the launch; gsm: the workgroup's dynamic LDS
 template <int D, int HPW>
-__global__ __launch_bounds__(512) void attn_out_vr_kernel(const float* __restrict__ S, const float* __restrict__ Y,
-                                                          const float* __restrict__ wv_bg, const float* __restrict__ wf_pg,
-                                                          const float* __restrict__ bf, const float* __restrict__ w2,
-                                                          const float* __restrict__ b2, const float* __restrict__ zemo,
-                                                          const float* __restrict__ wsum, float* __restrict__ out,
-                                                          float* __restrict__ raw) {
+__device__ __forceinline__ void attn_out_vr_body(const float* __restrict__ S, const float* __restrict__ Y,
+                                                 const float* __restrict__ wv_bg, const float* __restrict__ wf_pg,
+                                                 const float* __restrict__ bf, const float* __restrict__ w2,
+                                                 const float* __restrict__ b2, const float* __restrict__ zemo,
+                                                 const float* __restrict__ wsum, float* __restrict__ out,
+                                                 float* __restrict__ raw, int b, float* gsm) {
     constexpr int NKc = 80, KB = D / 16, CH = 4, NCH = KB / CH, QS = NKc + 1, OS = D + 8, NWv = 8, H = NWv * HPW;
     constexpr int TPH = 4 / HPW;                               // column tiles per head
     static_assert(D == 64 * NWv && KB % CH == 0 && CH % 2 == 0, "one wave per 64 columns; k blocks in chunks of four");
-    extern __shared__ __attribute__((aligned(16))) float gsm[];
     float* Ys = gsm;                                           // [2][16 * QS * 4]  Y chunk image [k / 4][row, padded][k % 4]
     float* Os = Ys + 2 * 16 * QS * 4;                          // [32][OS]
     float* R2 = Os + 32 * OS;                                  // [NWv][32]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lg = lane >> 4, lj = lane & 15;
     const float* Yb = Y + (int64_t)b * NKc * D;
@@ -539,6 +549,17 @@ __global__ __launch_bounds__(512) void attn_out_vr_kernel(const float* __restric
         if (raw) raw[(int64_t)b * 52 + tid] = bs;
         out[(int64_t)b * 52 + tid] = fminf(fmaxf(wsum[tid] * bs, 0.f), 1.f);
     }
+}
+
+template <int D, int HPW>
+__global__ __launch_bounds__(512) void attn_out_vr_kernel(const float* __restrict__ S, const float* __restrict__ Y,
+                                                          const float* __restrict__ wv_bg, const float* __restrict__ wf_pg,
+                                                          const float* __restrict__ bf, const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, const float* __restrict__ zemo,
+                                                          const float* __restrict__ wsum, float* __restrict__ out,
+                                                          float* __restrict__ raw) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    attn_out_vr_body<D, HPW>(S, Y, wv_bg, wf_pg, bf, w2, b2, zemo, wsum, out, raw, (int)blockIdx.x, gsm);
 }
 
 }  // namespace km

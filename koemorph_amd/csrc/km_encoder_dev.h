@@ -45,22 +45,30 @@ struct EncSrc {
 //    next block's fragments run under the iteration's 80 MFMAs;
 //  * a lane's CT column tiles are CT adjacent columns (n = 16 CT wave + CT lj + ct), so the epilogue stores 16-byte
 //    vectors, 256 contiguous bytes per row and wave, instead of 64-byte segments.
+// the kernel's LDS as one object, so that the body can also run as the first stage of core512_kernel (km_generic.hip)
+template <int NW>
+struct EncLds {
+    __attribute__((aligned(16))) float As[2 * 2 * 4 * 80 * 4];     // two buffers of two k blocks each, [k / 4][row][k % 4] per k block
+    __attribute__((aligned(16))) float Ps[2][80 * NW];             // LayerNorm partial sums [pass][row][wave]
+    __attribute__((aligned(16))) float Ts[2][80];                  // LayerNorm row totals [pass][row]
+};
+
+// window b of the launch; every thread of the workgroup runs the whole body (barriers inside)
 template <int NW, int CT, bool FUSE_DB>
-__global__ __launch_bounds__(64 * NW) void encoder_ln_kernel(const float* __restrict__ xp, const float* __restrict__ wpg,
-                                                             const float* __restrict__ bias, const float* __restrict__ gam,
-                                                             const float* __restrict__ bet, float* __restrict__ Y, int KP,
-                                                             EncSrc src) {
+__device__ __forceinline__ void encoder_ln_body(const float* __restrict__ xp, const float* __restrict__ wpg,
+                                                const float* __restrict__ bias, const float* __restrict__ gam,
+                                                const float* __restrict__ bet, float* __restrict__ Y, int KP,
+                                                const EncSrc& src, int b, EncLds<NW>& L) {
     constexpr int NKc = 80, NTHR = 64 * NW, D = 16 * CT * NW;
     static_assert(NKc % NW == 0, "rows must divide evenly among the waves");
     static_assert(CT == 2 || CT == 4, "a lane's columns are stored as one 8- or 16-byte vector");
     constexpr int ABUF = 4 * NKc * 4;                 // floats of one A tile image [k / 4][row][k % 4]
-    __shared__ __attribute__((aligned(16))) float As[2 * 2 * ABUF];     // two buffers of two k blocks each
-    __shared__ __attribute__((aligned(16))) float Ps[2][NKc * NW];      // LayerNorm partial sums [pass][row][wave]
-    __shared__ __attribute__((aligned(16))) float Ts[2][NKc];           // LayerNorm row totals [pass][row]
+    float* As = L.As;
+    float (&Ps)[2][NKc * NW] = L.Ps;
+    float (&Ts)[2][NKc] = L.Ts;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lg = lane >> 4, lj = lane & 15;
-    const int b = blockIdx.x;
     const int kt = KP / 16;
     // Tiles are fetched with buffer loads: a thread (or a row, or a k block past the end) with nothing to fetch points
     // past the descriptor's range and gets zeros without a memory access, so no load sits under a branch.
@@ -244,6 +252,15 @@ __global__ __launch_bounds__(64 * NW) void encoder_ln_kernel(const float* __rest
             if constexpr (CT == 4) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
             else *reinterpret_cast<float2*>(dst) = make_float2(o[0], o[1]);
         }
+}
+
+template <int NW, int CT, bool FUSE_DB>
+__global__ __launch_bounds__(64 * NW) void encoder_ln_kernel(const float* __restrict__ xp, const float* __restrict__ wpg,
+                                                             const float* __restrict__ bias, const float* __restrict__ gam,
+                                                             const float* __restrict__ bet, float* __restrict__ Y, int KP,
+                                                             EncSrc src) {
+    __shared__ EncLds<NW> L;
+    encoder_ln_body<NW, CT, FUSE_DB>(xp, wpg, bias, gam, bet, Y, KP, src, (int)blockIdx.x, L);
 }
 
 }  // namespace km

@@ -542,6 +542,59 @@ static int launch_encoder_ln(Context* c, int64_t B, hipStream_t st, const float*
     return KM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// core512_kernel: the whole d_model 512 core of one window in ONE workgroup -- encoder + LayerNorm, scores + softmax, value
+// projection + P V + decoder + tail: the three kernels of round 2 / 3 as three stages of one launch (their bodies, unchanged).  Each of
+// them was one 512-thread workgroup per window already, i.e. one workgroup per CU at the C4 batch: every kernel boundary drained and
+// refilled the whole chip (profiles/r04_c4_pmc_*.txt: CUs busy 0.89 / 0.78 / 0.91 of the three launches).  Y_b and the softmaxed
+// scores still go through memory -- written and read by the SAME workgroup now, so they come back from its own L2 -- and a
+// __syncthreads() orders the stages.  LDS: the encoder's 26 KB static + the 109 KB dynamic image of the last stage, whose head doubles
+// as the scores stage's Y buffers.
+// ---------------------------------------------------------------------------------------------------------
+struct Core512Args {
+    const float* xp; const float* wce_pg; const float* bce; const float* ln_g; const float* ln_b; float* Y; int KP; EncSrc src;
+    const float* qk_pg; float* S; int rows;
+    const float* wv_bg; const float* wf_pg; const float* bf; const float* w2; const float* b2; const float* zemo; const float* wsum;
+    float* out; float* raw;
+};
+template <int TPW, int HPW, bool FUSE_DB>
+__global__ __launch_bounds__(512) void core512_kernel(Core512Args a) {
+    __shared__ EncLds<8> el;
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    const int b = (int)blockIdx.x;
+    encoder_ln_body<8, 4, FUSE_DB>(a.xp, a.wce_pg, a.bce, a.ln_g, a.ln_b, a.Y, a.KP, a.src, b, el);
+    __syncthreads();          // Y_b is in memory for every wave of this workgroup
+    scores_softmax_body<512, TPW>(a.Y, a.qk_pg, a.S, a.rows, b, *reinterpret_cast<float (*)[2][kScoresYsFloats]>(gsm));
+    __syncthreads();          // ... and the window's attention weights
+    attn_out_vr_body<512, HPW>(a.S, a.Y, a.wv_bg, a.wf_pg, a.bf, a.w2, a.b2, a.zemo, a.wsum, a.out, a.raw, b, gsm);
+}
+
+static bool core512_merge_ok(Context* c, const float* attn) {
+    return c->d == 512 && c->NK == 80 && c->DH == 256 && (c->H == 8 || c->H == 16) && !attn && !c->opt.no_ln_fusion &&
+           !c->opt.no_score_fusion && !c->opt.no_out_fusion && !c->opt.no_v_fusion && !c->opt.no_core_merge && c->packed.count("qk_pg") &&
+           c->packed.count("wf_pg") && c->packed.count("wv_bg");
+}
+
+template <bool FUSE_DB>
+static int launch_core512(Context* c, int64_t B, const float* xp, int KP, const EncSrc& src, const float* zemo, float* out, float* raw,
+                          hipStream_t st) {
+    const int d = c->d, H = c->H, NKk = c->NK;
+    float* Y = c->ws_generic;
+    float* S = Y + 2 * B * NKk * d;
+    Core512Args a{xp, dv(c, "wce_pg"), dv(c, "bce"), dv(c, "ln_g"), dv(c, "ln_b"), Y, KP, src, dv(c, "qk_pg"), S, H * 28,
+                  dv(c, "wv_bg"), dv(c, "wf_pg"), dv(c, "bf"), dv(c, "w2"), dv(c, "b2"), zemo, dv(c, "wsum"), out, raw};
+    constexpr int lds = (2 * 16 * 81 * 4 + 32 * (512 + 8) + 8 * 32) * (int)sizeof(float);
+    static PerDeviceOnce once;
+    if (once.first(c->device)) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&core512_kernel<2, 1, FUSE_DB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&core512_kernel<4, 2, FUSE_DB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    if (H == 8) hipLaunchKernelGGL((core512_kernel<2, 1, FUSE_DB>), dim3((unsigned)B), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((core512_kernel<4, 2, FUSE_DB>), dim3((unsigned)B), dim3(512), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
 // d_model -> (waves, column tiles per wave) of the fused encoder + LayerNorm kernel
 template <bool FUSE_DB>
 static int launch_encoder_ln_for(Context* c, int64_t B, hipStream_t st, const float* xp, int KP, const EncSrc& src) {
@@ -565,6 +618,7 @@ int launch_core_generic_packed(Context* c, const float* xp, int64_t B, const flo
     const bool fuse_ln = !c->opt.no_ln_fusion;
     hipStream_t st = (hipStream_t)stream;
     bool ln_done = fuse_ln;
+    if (core512_merge_ok(c, attn)) return launch_core512<false>(c, B, xp, KP, EncSrc{}, zemo, out, raw, st);
     if (fuse_ln && (d == 512 || d == 256 || d == 64)) {
         if (int rc = launch_encoder_ln_for<false>(c, B, st, xp, KP, EncSrc{})) return rc;
     } else {
@@ -590,6 +644,11 @@ int launch_core_generic_power(Context* c, MelPlan* plan, int64_t B, int64_t n_fr
     const int KP = (c->KT + 15) / 16 * 16;
     hipStream_t st = (hipStream_t)stream;
     EncSrc src{c->ws_melpow, c->ws_melmax, (int)n_frames, c->T, plan_log_params(plan)};
+    if (core512_merge_ok(c, attn)) {
+        if (int rc = launch_core512<true>(c, B, nullptr, KP, src, zemo, out, raw, st)) return rc;
+        c->melmax_dirty = false;
+        return KM_OK;
+    }
     if (int rc = launch_encoder_ln_for<true>(c, B, st, nullptr, KP, src)) return rc;
     c->melmax_dirty = false;     // every slot the encoder read was just written by the front end and is re-zeroed by the encoder
     return core_generic_after_encoder(c, B, zemo, out, raw, attn, stream, true);
