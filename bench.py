@@ -869,8 +869,8 @@ def run_c4(args, rk: Ranks):
                      "achieved": round(exe, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(exe / PEAK_F32_MFMA_TFLOPS, 4), "algorithmic_frac": round(alg / PEAK_F32_MFMA_TFLOPS, 4),
                      "traffic": None, "executed_flops_per_window": executed_flops_per_frame_c4(H),
-                     "note": "MFMA FLOPs the three core kernels issue (bench.py header) over the WHOLE step incl. the VALU front end; "
-                             "per kernel: profiles/r04_c4_kernel_stats.txt (r03_/r02_ for earlier rounds), r02_c4_harness.txt"},
+                     "note": "MFMA FLOPs the three core stages issue (bench.py header; one launch, core512_kernel, since round 4) over the WHOLE step incl. the VALU "
+                             "front end; per stage as separate kernels (KM_BENCH_OPTIONS=no_core_merge=1): profiles/r04_c4_kernel_stats.txt, r02_c4_harness.txt"},
         "cpu_baseline": cpu,
     }
 

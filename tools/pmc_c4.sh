@@ -5,7 +5,7 @@ H=${1:-8}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pmcc4_$H
 rm -rf $O; mkdir -p $O
-KM_BENCH_NO_SPINUP=1 timeout -k 5 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE --output-format csv -d $O/a -- python3 bench.py --workload c4 --heads $H --steps 20 --warmup 5 --cpu-seconds 0 > $O/a.log 2>&1
+KM_BENCH_OPTIONS=no_core_merge=1 KM_BENCH_NO_SPINUP=1 timeout -k 5 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE --output-format csv -d $O/a -- python3 bench.py --workload c4 --heads $H --steps 20 --warmup 5 --cpu-seconds 0 > $O/a.log 2>&1
 python3 - "$O" "$H" <<'PY'
 import csv, glob, sys, collections
 O, H = sys.argv[1], sys.argv[2]

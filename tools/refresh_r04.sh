@@ -15,8 +15,8 @@ if [ "$1" = "1" ]; then
     python3 profiles/summarize.py traffic $(find $O/fetch -name "*counter_collection.csv" | head -1) $(find $O/write -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json
     python3 tools/pmc_sq_json.py gpurun_out/sq $O/pmc_sq.json
     # C4 per-kernel stats at 8 and 16 heads
-    timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4h8 -o c4 -- python3 bench.py --workload c4 --steps 50 --cpu-seconds 0 > $O/c4_h8_prof.json 2> $O/c4h8.err
-    timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4h16 -o c4 -- python3 bench.py --workload c4 --heads 16 --steps 50 --cpu-seconds 0 > $O/c4_h16_prof.json 2> $O/c4h16.err
+    KM_BENCH_OPTIONS=no_core_merge=1 timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4h8 -o c4 -- python3 bench.py --workload c4 --steps 50 --cpu-seconds 0 > $O/c4_h8_prof.json 2> $O/c4h8.err
+    KM_BENCH_OPTIONS=no_core_merge=1 timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4h16 -o c4 -- python3 bench.py --workload c4 --heads 16 --steps 50 --cpu-seconds 0 > $O/c4_h16_prof.json 2> $O/c4h16.err
     { echo "== C4, 8 heads (rocprofv3 --kernel-trace --stats -- python3 bench.py --workload c4 --steps 50)"; python3 profiles/summarize.py stats $(find $O/c4h8 -name "*kernel_stats.csv" | head -1);
       echo "== C4, 16 heads"; python3 profiles/summarize.py stats $(find $O/c4h16 -name "*kernel_stats.csv" | head -1); } > $O/c4_kernel_stats.txt
     echo c4 done
