@@ -70,6 +70,7 @@ struct Options {
     int mel_two_frame = 0;         // 1: two-frames-per-wave front end (A/B baseline)
     int emotion_separate = 0;      // 1: emotion logits in their own kernel
     int no_ln_fusion = 0, no_db_fusion = 0, no_score_fusion = 0, no_out_fusion = 0, no_v_fusion = 0;   // generic chain A/B
+    int legacy_no_merge = 0;       // 1: the legacy model's attention and tail as two launches instead of one (legacy_attn_tail_kernel)
     int no_core_merge = 0;         // 1: the d_model 512 core as its three launches (encoder + LayerNorm, scores, output) instead of one workgroup per window walking the three stages (core512_kernel)
     int legacy_no_tail_fusion = 0; // 1: SimplifiedKoeMorphModel out_proj + decoder as four GEMM launches + a row kernel (A/B, tests)
     int legacy_no_enc_fusion = 0;  // 1: SimplifiedKoeMorphModel audio encoder + key / value projections as four GEMM launches (A/B, tests)

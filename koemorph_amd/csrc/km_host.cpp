@@ -655,7 +655,7 @@ const OptName kOptNames[] = {
     {"generic_staged", &Options::generic_staged}, {"mel_two_frame", &Options::mel_two_frame},
     {"emotion_separate", &Options::emotion_separate}, {"no_ln_fusion", &Options::no_ln_fusion},
     {"no_db_fusion", &Options::no_db_fusion}, {"no_score_fusion", &Options::no_score_fusion},
-    {"no_out_fusion", &Options::no_out_fusion}, {"no_v_fusion", &Options::no_v_fusion}, {"no_core_merge", &Options::no_core_merge}, {"train_chain", &Options::train_chain}, {"kmm_no_fuse", &Options::kmm_no_fuse}, {"legacy_no_attn_fusion", &Options::legacy_no_attn_fusion}, {"legacy_no_enc_fusion", &Options::legacy_no_enc_fusion}, {"legacy_no_tail_fusion", &Options::legacy_no_tail_fusion},
+    {"no_out_fusion", &Options::no_out_fusion}, {"no_v_fusion", &Options::no_v_fusion}, {"no_core_merge", &Options::no_core_merge}, {"legacy_no_merge", &Options::legacy_no_merge}, {"train_chain", &Options::train_chain}, {"kmm_no_fuse", &Options::kmm_no_fuse}, {"legacy_no_attn_fusion", &Options::legacy_no_attn_fusion}, {"legacy_no_enc_fusion", &Options::legacy_no_enc_fusion}, {"legacy_no_tail_fusion", &Options::legacy_no_tail_fusion},
     {"train_no_split", &Options::train_no_split}, {"train_dwce_parts", &Options::train_dwce_parts},
     {"train_tail_groups", &Options::train_tail_groups}, {"train_bm32_below", &Options::train_bm32_below}, {"train_op_per_launch", &Options::train_op_per_launch}, {"train_split_min_k", &Options::train_split_min_k}, {"train_no_dma", &Options::train_no_dma}, {"train_attn_regs", &Options::train_attn_regs}, {"train_no_fe_pack", &Options::train_no_fe_pack}, {"train_colsum_gemm", &Options::train_colsum_gemm}, {"train_no_ln_fuse", &Options::train_no_ln_fuse}, {"train_ln_fuse_rows", &Options::train_ln_fuse_rows}, {"train_no_dy_split", &Options::train_no_dy_split}, {"train_alone_max", &Options::train_alone_max},
 };

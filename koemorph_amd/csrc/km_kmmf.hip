@@ -25,6 +25,7 @@
 
 #include "km_context.h"
 #include "km_device.h"
+#include "km_legacy_attn_dev.h"
 #include "km_gemm.h"
 #include "km_kmmf.h"
 
@@ -925,13 +926,13 @@ __global__ __launch_bounds__(LNTH) void legacy_encoder_kernel(const float* __res
 // (Linear ReLU Linear ReLU Linear Sigmoid, simplified_model.py:63-72) on the 52 query rows resident in LDS and the mean over those
 // rows (:144-147).  Replaces four NT GEMM launches + a row kernel.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void legacy_tail_kernel(const float* __restrict__ O, const float* __restrict__ blob, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// window b of the launch; smem: the workgroup's dynamic LDS (2 x 64 x XS floats)
+__device__ __forceinline__ void legacy_tail_body(const float* __restrict__ O, const float* __restrict__ blob, float* __restrict__ out, int64_t b,
+                                                 float* smem) {
     float* A = smem;                 // [64][264] images; rows 52 .. 63 hold whatever the stores below leave (rows are independent)
     float* Bi = smem + 64 * XS;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, j = lane & 15;
-    const int64_t b = blockIdx.x;
     for (int i = tid; i < 64 * 64; i += NTH) {
         const int q = i >> 6, c4 = i & 63;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -991,6 +992,27 @@ __global__ __launch_bounds__(512) void legacy_tail_kernel(const float* __restric
         s += __shfl_xor(s, 32);
         if (g == 0 && col < NQ) out[b * NQ + col] = s / (float)NQ;
     }
+}
+
+__global__ __launch_bounds__(512) void legacy_tail_kernel(const float* __restrict__ O, const float* __restrict__ blob, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    legacy_tail_body(O, blob, out, (int64_t)blockIdx.x, smem);
+}
+
+// legacy_attn_tail_kernel: the attention of a window -- its 8 heads on the workgroup's 8 waves (legacy_attention_body: no LDS, no barrier) --
+// and then its tail (legacy_tail_body), one launch: both were one-window-per-workgroup shaped already (the attention as two 4-wave
+// workgroups per window), so the boundary between them only drained and refilled the chip.  O_b goes through memory, written and
+// read by the same workgroup.
+__global__ __launch_bounds__(512) void legacy_attn_tail_kernel(const float* __restrict__ Qs, const float* __restrict__ Kp,
+                                                              const float* __restrict__ Vp, float* __restrict__ O, int Tm,
+                                                              unsigned* __restrict__ zero_max, const float* __restrict__ blob,
+                                                              float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int64_t b = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    legacy_attention_body(Qs, Kp, Vp, O, b * 8 + wave, Tm, 8, NQ, zero_max);
+    __syncthreads();      // the window's 52 x 256 attention output is in memory for every wave of this workgroup
+    legacy_tail_body(O, blob, out, b, smem);
 }
 
 }  // namespace kf
@@ -1071,6 +1093,19 @@ int launch_legacy_tail_fused(Context* c, const float* O, int64_t B, float* out, 
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kf::legacy_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     2 * 64 * kf::XS * 4));
     hipLaunchKernelGGL(kf::legacy_tail_kernel, dim3((unsigned)B), dim3(kf::NTH), 2 * 64 * kf::XS * 4, (hipStream_t)stream, O, dvp(c, "lgf_tail"), out);
+    HIP_TRY(hipGetLastError());
+    return KM_OK;
+}
+
+// SimplifiedKoeMorphModel: attention (8 heads of 32, 52 queries) + everything behind it, one launch
+int launch_legacy_attn_tail_fused(Context* c, const float* Kp, const float* Vp, float* O, int64_t B, int Tm, unsigned* zero_max, float* out,
+                                  void* stream) {
+    static PerDeviceOnce once;
+    if (once.first(c->device))
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&kf::legacy_attn_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * 64 * kf::XS * 4));
+    hipLaunchKernelGGL(kf::legacy_attn_tail_kernel, dim3((unsigned)B), dim3(kf::NTH), 2 * 64 * kf::XS * 4, (hipStream_t)stream, dvp(c, "l_q"), Kp, Vp, O,
+                       Tm, zero_max, dvp(c, "lgf_tail"), out);
     HIP_TRY(hipGetLastError());
     return KM_OK;
 }
