@@ -197,3 +197,30 @@ def test_generic_path_at_d256_other_window_against_oracle():
             ref = core.core_forward_np(params, mel, short, emo, num_heads=H, mel_sequence_length=T)["blendshapes"]
             got = e.core_forward(dev(mel), dev(short), dev(emo))["blendshapes"].cpu().numpy()
             assert np.abs(got - ref).max() < TOL
+
+
+@pytest.mark.parametrize("heads", [8, 16])
+def test_d512_core_in_one_launch_is_the_three_kernels_bit_for_bit(heads):
+    """Round 4: at d_model 512 the encoder + LayerNorm, scores + softmax and output kernels run as three stages of ONE launch
+    (core512_kernel: the same three bodies, a __syncthreads() between them; option no_core_merge brings the three launches back).
+    From audio (dB conversion inside the first stage, window maxima re-zeroed by it) and from caller-provided mel: identical bits."""
+    from koemorph_amd.engine import Engine, MelConfig
+    params = synth.make_core_params(21, 512, 512, 256, "trained")
+    L = 512 * 266
+    audio = dev(synth.make_audio(22, 5, L, "uniform"))
+    emo = dev(synth.normal(23, (5, 256)))
+    mel, short, _ = synth.make_core_inputs(24, 5, 513, style="mel01")
+    res = []
+    for no_merge in (0, 1):
+        e = Engine(d_model=512, num_heads=heads, mel_sequence_length=512, mel=MelConfig.model_batch(target_fps=60))
+        e.load_state_dict(params)
+        e.finalize()
+        e.set_option("no_core_merge", no_merge)
+        e.reserve(5, L)
+        a = [e.forward_audio(audio, emo).cpu().numpy() for _ in range(2)]          # twice: the maxima were handed back clean
+        m = e.core_forward(dev(mel), dev(short), emo)["blendshapes"].cpu().numpy()
+        res.append((a, m))
+    assert np.array_equal(res[0][0][0], res[0][0][1]) and np.array_equal(res[1][0][0], res[1][0][1])
+    assert np.array_equal(res[0][0][0], res[1][0][0])
+    assert np.array_equal(res[0][1], res[1][1])
+

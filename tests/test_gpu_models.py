@@ -282,13 +282,15 @@ def test_legacy_simplified_koemorph_model():
     for T in (257, 256, 250, 16, 5):
         melT = synth.uniform(10 + T, (5, T, 80), 0, 1)
         res = {}
-        for mode in (0, 1, 2, 4, 7):   # bit 0: attention as batched products, 1: encoder + K / V projections, 2: out_proj + decoder as GEMM launches
-            _lib.check(lib.km_set_option(h, b"legacy_no_attn_fusion", mode & 1))
+        for mode in (0, 1, 2, 4, 7, 8):   # bit 0: attention as batched products, 1: encoder + K / V projections, 2: out_proj + decoder as GEMM launches,
+            _lib.check(lib.km_set_option(h, b"legacy_no_attn_fusion", mode & 1))           # 3: attention and tail as two launches instead of one
             _lib.check(lib.km_set_option(h, b"legacy_no_enc_fusion", (mode >> 1) & 1))
-            _lib.check(lib.km_set_option(h, b"legacy_no_tail_fusion", mode >> 2))
+            _lib.check(lib.km_set_option(h, b"legacy_no_tail_fusion", (mode >> 2) & 1))
+            _lib.check(lib.km_set_option(h, b"legacy_no_merge", mode >> 3))
             res[mode] = m.forward_mel(dev(melT)).cpu().numpy()
-        for name in (b"legacy_no_attn_fusion", b"legacy_no_enc_fusion", b"legacy_no_tail_fusion"):
+        for name in (b"legacy_no_attn_fusion", b"legacy_no_enc_fusion", b"legacy_no_tail_fusion", b"legacy_no_merge"):
             _lib.check(lib.km_set_option(h, name, 0))
+        assert np.array_equal(res[0], res[8]), T          # one launch or two: the same two bodies
         want = legacy.legacy_forward_mel(params, melT)
         for mode in res:
             assert np.abs(res[mode] - want).max() < 5e-6, (T, mode)
