@@ -686,7 +686,8 @@ __device__ __forceinline__ bool load_frame_rp_fast(const float* __restrict__ x, 
     }
     const float* xp = x + start + 2 * lane;
     // (round 4, measured and dropped on the rotating, HBM-resident inputs: one dword per 128-byte line of the frame AFTER next touched a
-    // frame early -- step 0.1397 against 0.1334-0.1353 ms, tools/ab_c2.sh; and non-temporal sample loads, so that the audio stream would not displace the power-mel rows the core
+    // frame early -- step 0.1397 against 0.1334-0.1353 ms, tools/ab_c2.sh; the next frame requested at the START of the current one instead of
+    // behind its first pass (no spills, but 16 more registers live through pass 1) -- 0.1354-0.1361 against 0.1337-0.1348; and non-temporal sample loads, so that the audio stream would not displace the power-mel rows the core
     // reads next -- front end 63.6 -> 70 us, core 79.3 -> 82.6 us on rotating inputs)
 #pragma unroll
     for (int i = 0; i < 8; ++i) z[i] = melrp::v2f{xp[128 * i], xp[128 * i + 1]};
