@@ -422,3 +422,36 @@ def test_lds_dma_tiles_and_attention_blocks_agree_with_the_register_staged_ones(
         assert abs(l - l0) < 2e-6 * max(1.0, abs(l0)), name
         for k in g0:
             np.testing.assert_allclose(g[k], g0[k], atol=1e-8 + 2e-5 * np.abs(g0[k]).max(), rtol=2e-4, err_msg=f"{name}: {k}")
+
+
+@pytest.mark.parametrize("d,H,T,B", [(64, 4, 64, 3), (256, 8, 128, 5), (512, 8, 96, 2), (128, 4, 256, 4)])
+def test_program_variants_agree_from_audio_at_other_shapes(d, H, T, B):
+    """The round-4 forms of the training program -- front-end packing + conversion on the fragments, LayerNorm by the reader, dY in two K
+    halves, OP_COLSUM, LDS-DMA tiles -- each against the register-tile program of round 3 (train_no_dma, which switches all of them but the
+    column sums off), from audio, at shapes none of the goldens has: other widths, windows and odd batch sizes (d_model 128: generic
+    LayerNorm rows; 512: sixteen statistic parts per row; window 96 / 128: other packed widths).  Loss after three optimizer steps and the
+    gradient of a fourth step."""
+    from koemorph_amd.engine import Engine
+    params = synth.make_core_params(3, d, T, 256, "trained")
+    L = T * 533 + 40
+    audio, emo, target = dev(synth.make_audio(5, B, L)), dev(synth.normal(6, (B, 256))), dev(synth.uniform(7, (B, 52), 0, 1))
+    res = {}
+    for name, opts in (("default", {}), ("no_pack", {"train_no_fe_pack": 1}), ("ln_phase", {"train_no_ln_fuse": 1}), ("dy_whole", {"train_no_dy_split": 1}),
+                       ("colsum_gemm", {"train_colsum_gemm": 1}), ("round3", {"train_no_dma": 1})):
+        e = Engine(d_model=d, num_heads=H, mel_sequence_length=T)
+        e.load_state_dict(params)
+        e.finalize()
+        for k, v in opts.items():
+            e.set_option(k, v)
+        tr = Trainer(e, max_windows=B, lr=1e-3, dropout=0.1)
+        tr.set_dropout(0.1, seed=5)
+        for _ in range(3):
+            tr.step(audio, emo, target)
+        loss = float(tr.forward_backward(audio, emo, target).item())
+        res[name] = (loss, tr.flat_grad.cpu().numpy().copy())
+    l0, g0 = res["round3"]
+    assert np.isfinite(l0) and np.abs(g0).max() > 0
+    for name, (l, g) in res.items():
+        assert abs(l - l0) < 2e-5 * max(1.0, abs(l0)), name
+        assert np.abs(g - g0).max() <= 2e-4 * np.abs(g0).max(), name
+
